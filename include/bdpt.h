@@ -1,0 +1,309 @@
+/*
+ * bdpt.h — C ABI of the MI355X-native bidirectional path-tracing render pass.
+ *
+ * This is the drop-in boundary.  Every entry point names the
+ * reference interface it replaces (paths relative to /root/reference/src):
+ *
+ *   bdpt_create / bdpt_destroy      RayLaunch::create + compileRayProgram
+ *                                   (SharedUtils/RayLaunch.h:85-101,
+ *                                    BidirectionalPathtracing/Passes/BDPTPass.cpp:34-47)
+ *   bdpt_set_scene                  RayLaunch::setScene -> RtProgramVars/RtScene::createTlas,
+ *                                   RtModel::buildAccelerationStructure
+ *                                   (SharedUtils/RayLaunch.cpp:105-167,
+ *                                    Falcor/Framework/Source/Raytracing/RtModel.cpp:181-254,
+ *                                    Falcor/Framework/Source/Raytracing/RtScene.cpp:220-308)
+ *   bdpt_set_camera                 gCamera constant buffer (CameraData,
+ *                                   Falcor/Framework/Source/Data/HostDeviceSharedCode.h:69-99;
+ *                                   Camera::calculateCameraParameters, Graphics/Camera/Camera.cpp:129-136)
+ *   bdpt_gbuffer_execute            LightProbeGBufferPass::execute -> DispatchRays of GBufferRayGen
+ *                                   (CommonPasses/LightProbeGBufferPass.cpp:104-161,
+ *                                    CommonPasses/Data/CommonPasses/lightProbeGBuffer.rt.hlsl:63-159)
+ *   bdpt_execute                    BDPTPass::execute -> RayLaunch::execute -> DispatchRays of
+ *                                   SimpleDiffuseGIRayGen (BidirectionalPathtracing/Passes/BDPTPass.cpp:70-107,
+ *                                   SharedUtils/RayLaunch.cpp:200-223,
+ *                                   BidirectionalPathtracing/Data/BDPTMain.rt.hlsl:42-234)
+ *   bdpt_splat_buffer / bdpt_resolve  the cross-pixel gOutput[id] read-modify-write of the
+ *                                   light-tracing loop (BDPTMain.rt.hlsl:186-204), made
+ *                                   deterministic: fixed-point atomics into a separate buffer,
+ *                                   one final saturate
+ *   bdpt_accumulate                 SimpleAccumulationPass::execute + accumulate.ps.hlsl
+ *                                   (CommonPasses/SimpleAccumulationPass.cpp:104-134,
+ *                                    CommonPasses/Data/CommonPasses/accumulate.ps.hlsl:28-42)
+ *   bdpt_get_counters               (none in the reference; replaces nothing — ray tallies
+ *                                    needed by the Mrays/s metric)
+ *   bdpt_last_error                 Falcor logError / silent no-op conventions
+ *                                   (BidirectionalPathtracing/Passes/BDPTPass.cpp:76)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success and a negative BDPT_E_* code on failure; nothing throws across the
+ * boundary; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All image buffers are device pointers, row-major, pitch = width.
+ */
+#ifndef BDPT_H_
+#define BDPT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDPT_OK 0
+#define BDPT_E_INVALID (-1)  /* bad argument */
+#define BDPT_E_STATE (-2)    /* scene / camera / size not set */
+#define BDPT_E_HIP (-3)      /* HIP runtime error, see bdpt_last_error */
+#define BDPT_E_NOMEM (-4)
+#define BDPT_E_LIMIT (-5)    /* exceeds a documented limit (lights, depth) */
+
+#define BDPT_MAX_LIGHTS 16   /* MAX_LIGHT_SOURCES, Falcor Data/HostDeviceSharedMacros.h:152 */
+#define BDPT_MAX_DEPTH 16    /* reference caps at 8 (BDPTPass.h:33); storage here is depth-parametric */
+
+/* Light types, Falcor Data/HostDeviceSharedMacros.h:145-150 */
+#define BDPT_LIGHT_POINT 0
+#define BDPT_LIGHT_DIRECTIONAL 1
+
+/* Material flag bit layout is Falcor's (Data/HostDeviceSharedMacros.h:69-123). */
+#define BDPT_SHADING_MODEL_METAL_ROUGH 0u
+#define BDPT_SHADING_MODEL_SPEC_GLOSS 2u
+#define BDPT_CHANNEL_UNUSED 0u
+#define BDPT_CHANNEL_CONST 1u
+#define BDPT_CHANNEL_TEXTURE 2u
+#define BDPT_NORMAL_MAP_UNUSED 0u
+#define BDPT_NORMAL_MAP_RGB 1u
+#define BDPT_NORMAL_MAP_RG 2u
+#define BDPT_ALPHA_MODE_OPAQUE 0u
+#define BDPT_ALPHA_MODE_MASK 1u
+#define BDPT_FLAG_SHADING_MODEL(f) (((f) >> 0) & 7u)
+#define BDPT_FLAG_DIFFUSE_TYPE(f) (((f) >> 3) & 7u)
+#define BDPT_FLAG_SPECULAR_TYPE(f) (((f) >> 6) & 7u)
+#define BDPT_FLAG_EMISSIVE_TYPE(f) (((f) >> 9) & 7u)
+#define BDPT_FLAG_NORMAL_MAP_TYPE(f) (((f) >> 12) & 3u)
+#define BDPT_FLAG_ALPHA_MODE(f) (((f) >> 17) & 3u)
+#define BDPT_FLAG_DOUBLE_SIDED(f) (((f) >> 19) & 1u)
+#define BDPT_MAKE_FLAGS(model, dif, spec, emis, nmap, alpha, dbl)                              \
+  ((uint32_t)(((model) & 7u) | (((dif) & 7u) << 3) | (((spec) & 7u) << 6) | (((emis) & 7u) << 9) | \
+              (((nmap) & 3u) << 12) | (((alpha) & 3u) << 17) | (((dbl) & 1u) << 19)))
+
+/* MaterialData (Falcor Data/HostDeviceSharedCode.h:119-135) without the
+ * resource handles; textures are indices into bdpt_scene_desc.textures. 64 B. */
+typedef struct bdpt_material {
+  float baseColor[4];
+  float specular[4];
+  float emissive[3];
+  float alphaThreshold;
+  float IoR;
+  uint32_t flags;
+  int16_t texBaseColor; /* -1 = none */
+  int16_t texSpecular;
+  int16_t texEmissive;
+  int16_t texNormal;
+} bdpt_material;
+
+/* One mip-0 RGBA8 image.  The reference binds a linear/wrap sampler to every
+ * scene texture (SharedUtils/SceneLoaderWrapper.cpp:65-68) and only samples
+ * at explicit LOD 0 on this path (BDPTUtils.hlsli:6, lightProbeGBuffer.rt.hlsl:102). */
+typedef struct bdpt_texture {
+  const uint8_t* rgba8; /* host pointer, width*height*4 bytes, row 0 first */
+  uint32_t width;
+  uint32_t height;
+  uint32_t srgb; /* 1: rgb channels are sRGB-encoded (Falcor default for colour textures) */
+  uint32_t reserved;
+} bdpt_texture;
+
+/* The LightData fields this path reads (Falcor Data/HostDeviceSharedCode.h:199-217). 64 B. */
+typedef struct bdpt_light {
+  float posW[3];
+  uint32_t type;
+  float dirW[3];
+  float openingAngle;
+  float intensity[3];
+  float cosOpeningAngle;
+  float penumbraAngle;
+  float reserved[3];
+} bdpt_light;
+
+/* World-space, instancing flattened (the reference loads with
+ * Model::LoadFlags::RemoveInstancing, SharedUtils/SceneLoaderWrapper.cpp:58).
+ * Every vertex stream has 12-byte stride, including texcoords (.xy used), as in
+ * Falcor's ray-tracing vertex fetch (ShadingUtils/Raytracing.slang:79-85). */
+typedef struct bdpt_scene_desc {
+  uint32_t numVertices;
+  uint32_t numTriangles;
+  uint32_t numMaterials;
+  uint32_t numTextures;
+  uint32_t numLights;
+  uint32_t reserved;
+  const float* positions;
+  const float* normals;
+  const float* bitangents; /* may be NULL when no material has a normal map */
+  const float* texcoords;  /* may be NULL when no material samples a texture */
+  const uint32_t* indices;     /* 3 per triangle */
+  const uint32_t* triMaterial; /* 1 per triangle */
+  const bdpt_material* materials;
+  const bdpt_texture* textures;
+  const bdpt_light* lights;
+} bdpt_scene_desc;
+
+/* posW + cameraU/V/W of CameraData (Data/HostDeviceSharedCode.h:86-92). */
+typedef struct bdpt_camera {
+  float posW[3];
+  float cameraU[3];
+  float cameraV[3];
+  float cameraW[3];
+} bdpt_camera;
+
+/* GlobalCB of BDPTMain.rt.hlsl:12-22 plus build-only switches. */
+typedef struct bdpt_params {
+  float minT;            /* gMinT, default 1e-4 (SharedUtils/ResourceManager.h:150) */
+  uint32_t frameCount;   /* gFrameCount, starts at 0x1337 (BDPTPass.h:44) */
+  uint32_t matIndex;     /* gMatIndex 0 = GGX, 1 = Lambertian */
+  float refractiveIndex; /* gRefractiveIndex — read by no shader, kept for layout */
+  uint32_t maxDepth;     /* gMaxDepth */
+  float emitMult;        /* gEmitMult — read by no shader */
+  float clampUpper;      /* gClampUpper, default 0.9 */
+  float pixelJitter[2];  /* gPixelJitter = kMSAA[(frame+1)%8]/16 + 0.5 */
+  uint32_t flags;        /* BDPT_PARAM_* */
+} bdpt_params;
+
+#define BDPT_PARAM_COUNTERS 1u      /* tally rays / node / triangle visits (slower; not for timing) */
+#define BDPT_PARAM_DEFER_RESOLVE 2u /* leave splats in the splat buffer; caller runs bdpt_resolve */
+#define BDPT_PARAM_NO_NEE 4u        /* partial images for stage-wise parity (SURVEY §8c iv) */
+#define BDPT_PARAM_NO_SPLAT 8u
+#define BDPT_PARAM_NO_CONNECT 16u
+/* sampleGGXBRDF never writes its `out bool isSpecular` (MaterialUtils.hlsli:209-252): undefined in
+ * HLSL.  Default build definition: false.  With this flag: true iff the GGX lobe was sampled. */
+#define BDPT_PARAM_SPECULAR_FROM_LOBE 32u
+
+/* RayGenCB of lightProbeGBuffer.rt.hlsl:45-52 + the miss shader's env map. */
+typedef struct bdpt_gbuffer_params {
+  float pixelJitter[2]; /* (0.5,0.5) when jitter is off */
+  float lensRadius;
+  float focalLen;
+  uint32_t frameCount;  /* starts at 0xdeadbeef (CommonPasses/LightProbeGBufferPass.h:79) */
+  uint32_t useThinLens;
+  uint32_t envWidth;    /* gEnvMapRes */
+  uint32_t envHeight;
+  const float* envMap;  /* device RGBA32F, envWidth*envHeight*4 floats; NULL = constant envColor */
+  float envColor[4];    /* default (0.5,0.5,0.8,1) (SharedUtils/ResourceManager.cpp:77-87) */
+} bdpt_gbuffer_params;
+
+/* The six G-buffer channels in the formats the first requester fixes
+ * (CommonPasses/LightProbeGBufferPass.cpp:46-51): position RGBA32F, the rest
+ * RGBA16F.  Device pointers, width*height texels each (full frame). */
+typedef struct bdpt_gbuffer {
+  float* worldPosition;          /* float4 */
+  uint16_t* worldNormal;         /* half4: N.xyz, distance */
+  uint16_t* materialDiffuse;     /* half4: diffuse.rgb, opacity | env colour on miss */
+  uint16_t* materialSpecRough;   /* half4: specular.rgb, linearRoughness */
+  uint16_t* materialExtraParams; /* half4: IoR, lightMap.rgb */
+  uint16_t* emissive;            /* half4: emissive.rgb, 0 */
+} bdpt_gbuffer;
+
+/* Rows [y0,y1) of the full width×height frame are this context's tile.  The
+ * light sub-path of every tile pixel still splats anywhere in the frame. */
+typedef struct bdpt_tile {
+  uint32_t y0;
+  uint32_t y1;
+} bdpt_tile;
+
+typedef struct bdpt_counters {
+  uint64_t raysPrimary;
+  uint64_t raysEyeExtend;
+  uint64_t raysLightExtend;
+  uint64_t raysNee;
+  uint64_t raysSplat;
+  uint64_t raysConnect;
+  uint64_t nodeVisitsClosest; /* interior-node visits, closest-hit queries */
+  uint64_t triTestsClosest;
+  uint64_t nodeVisitsShadow;  /* interior-node visits, any-hit queries */
+  uint64_t triTestsShadow;
+  uint64_t pixelsValid;       /* G-buffer pixels with geometry */
+  uint64_t splatsLanded;
+} bdpt_counters;
+
+typedef struct bdpt_bvh_info {
+  uint32_t numNodes;
+  uint32_t numTriangles;
+  uint32_t maxDepth;
+  uint32_t nodeBytes; /* bytes per interior node */
+  uint32_t triBytes;  /* bytes per leaf triangle */
+  float sahCost;
+} bdpt_bvh_info;
+
+typedef struct bdpt_ctx bdpt_ctx;
+
+int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx);
+void bdpt_destroy(bdpt_ctx* ctx);
+const char* bdpt_last_error(const bdpt_ctx* ctx);
+
+int bdpt_set_scene(bdpt_ctx* ctx, const bdpt_scene_desc* scene);
+int bdpt_get_bvh_info(const bdpt_ctx* ctx, bdpt_bvh_info* out);
+int bdpt_set_camera(bdpt_ctx* ctx, const bdpt_camera* cam);
+
+/* Camera::calculateCameraParameters (Graphics/Camera/Camera.cpp:129-136) with
+ * fovY = focalLengthToFovY (Utils/Math/FalcorMath.h:148-151).  Host-only helper. */
+int bdpt_camera_look_at(const float pos[3], const float target[3], const float up[3], float focalLengthMm,
+                        float frameHeightMm, float aspect, float focalDistance, bdpt_camera* out);
+
+/* kMSAA jitter table shared by both passes (BDPTPass.cpp:20, LightProbeGBufferPass.cpp:36):
+ * out = kMSAA[(frameCounterBeforeIncrement + 1) % 8] / 16 + 0.5. */
+void bdpt_msaa_jitter(uint32_t frameCounterBeforeIncrement, float out[2]);
+
+/* Size the per-pixel path state for a width×height frame of which rows
+ * [tile.y0, tile.y1) are rendered here, at up to maxDepth. */
+int bdpt_resize(bdpt_ctx* ctx, uint32_t width, uint32_t height, bdpt_tile tile, uint32_t maxDepth);
+
+/* Primary-visibility pass.  Writes the tile rows of all six channels. */
+int bdpt_gbuffer_execute(bdpt_ctx* ctx, const bdpt_gbuffer_params* p, const bdpt_gbuffer* out, void* stream);
+
+/* The BDPT pass.  `out` is the full-frame RGBA32F "PipelineOutput" channel;
+ * only the tile rows are written (cleared to 0 first, as getClearedTexture does,
+ * BDPTPass.cpp:73).  Without BDPT_PARAM_DEFER_RESOLVE the splats of this call are
+ * folded in before returning control to the stream. */
+int bdpt_execute(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream);
+
+/* Full-frame fixed-point splat accumulator: uint64[4] per pixel (r,g,b in
+ * 2^-32 units, splat count), zeroed by every bdpt_execute before its splat stage.
+ * Exposed so a multi-GPU host can sum it across ranks (integer sum: exact and
+ * order-independent) before bdpt_resolve. */
+int bdpt_splat_buffer(bdpt_ctx* ctx, uint64_t** out_device_ptr, uint64_t* out_num_u64);
+
+/* out[tile rows] = saturate(out + splat) where the splat count is non-zero.
+ * `splat` may be the context's own buffer or a reduced copy holding at least the
+ * tile rows at the same full-frame indexing (splat_row0 = first row it holds). */
+int bdpt_resolve(bdpt_ctx* ctx, const uint64_t* splat, uint32_t splat_row0, float* out, void* stream);
+
+/* Running mean of accumulate.ps.hlsl:28-42 over `numTexels` RGBA32F texels:
+ *   cur = accumCount < maxAccumCount ? (accumCount*last + cur)/(accumCount+1) : last;  last = cur. */
+int bdpt_accumulate(bdpt_ctx* ctx, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount,
+                    uint64_t numTexels, void* stream);
+
+/* Counters of the most recent bdpt_gbuffer_execute + bdpt_execute pair run with
+ * BDPT_PARAM_COUNTERS.  Synchronises the stream it was launched on. */
+int bdpt_get_counters(bdpt_ctx* ctx, bdpt_counters* out);
+
+/* Per-stage device time (ms) of the most recent bdpt_execute, measured with
+ * HIP events on the launch stream.  names/ms hold up to `cap` entries; returns
+ * the number written (>= 0) or a negative error. */
+int bdpt_get_stage_times(bdpt_ctx* ctx, const char** names, float* ms, int cap);
+int bdpt_enable_stage_timing(bdpt_ctx* ctx, int enable);
+
+int bdpt_sync(bdpt_ctx* ctx, void* stream);
+
+/* Test hooks through the same library (used by the parity tests; they launch
+ * the device functions of the hot path on caller-supplied inputs). */
+/* initRand/nextRand stream: out[i*draws + k] = k-th nextRand seed state for (val0[i], val1[i]). */
+int bdpt_test_rng(bdpt_ctx* ctx, const uint32_t* val0, const uint32_t* val1, uint32_t n, uint32_t draws,
+                  uint32_t* out_states, float* out_floats);
+/* Closest-hit / any-hit queries on host ray arrays (origin xyz, dir xyz, tmin, tmax per ray).
+ * hit: prim (int32, -1 miss), t, u, v per ray.  mode 0 closest, 1 closest+cull-back, 2 any-hit (prim = 0/-1). */
+int bdpt_test_trace(bdpt_ctx* ctx, const float* rays, uint32_t n, int mode, int32_t* out_prim, float* out_tuv);
+/* BSDF known-answer hook: inputs are n records of 20 floats
+ * (N3 V3 L3 dif3 spec3 rough isSpecular seed(bits) pad2); outputs n records of 16 floats
+ * (sampleBRDF: weight3 L3 pdf isSpec | evalBRDF: f3 | pad).  matIndex bit 1 = BDPT_PARAM_SPECULAR_FROM_LOBE. */
+int bdpt_test_bsdf(bdpt_ctx* ctx, const float* in, uint32_t n, uint32_t matIndex, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDPT_H_ */

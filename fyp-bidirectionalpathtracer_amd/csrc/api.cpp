@@ -1,0 +1,575 @@
+// api.cpp — the C ABI of include/bdpt.h: context, scene upload + BVH build, per-tile path
+// buffers, stage launches.  Nothing here allocates or synchronises inside bdpt_execute /
+// bdpt_gbuffer_execute (workspaces are sized by bdpt_set_scene / bdpt_resize), so both can be
+// captured into a hipGraph by the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bdpt.h"
+#include "bvh.h"
+#include "kernels.h"
+
+using namespace bdpt;
+
+namespace {
+constexpr int kMaxStages = 64;
+}
+
+struct bdpt_ctx {
+  int device = 0;
+  std::string err;
+  // scene
+  bool haveScene = false, haveCamera = false, haveSize = false;
+  SceneDev S{};
+  std::vector<void*> sceneAllocs;
+  bdpt_bvh_info bvhInfo{};
+  bdpt_camera cam{};
+  // frame
+  uint32_t W = 0, H = 0, maxDepth = 0;
+  bdpt_tile tile{0, 0};
+  PathBuf P{};
+  std::vector<void*> frameAllocs;
+  unsigned long long* splat = nullptr;
+  DevCounters* counters = nullptr;
+  hipStream_t lastStream = nullptr;
+  // stage timing
+  bool timing = false;
+  hipEvent_t ev[kMaxStages + 1]{};
+  const char* stageNames[kMaxStages]{};
+  int numStages = 0;
+  bool evCreated = false;
+};
+
+namespace {
+
+bool fail(bdpt_ctx* c, const std::string& m) {
+  if (c) c->err = m;
+  return false;
+}
+#define HIPCHK(ctx, expr)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+      return BDPT_E_HIP;                                                                        \
+    }                                                                                           \
+  } while (0)
+
+template <class T>
+int devAlloc(bdpt_ctx* c, std::vector<void*>& pool, T** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    fail(c, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    return BDPT_E_NOMEM;
+  }
+  pool.push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return BDPT_OK;
+}
+template <class T>
+int devUpload(bdpt_ctx* c, std::vector<void*>& pool, const T** out, const T* host, size_t count) {
+  T* d = nullptr;
+  int rc = devAlloc(c, pool, &d, count);
+  if (rc) return rc;
+  if (count) HIPCHK(c, hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *out = d;
+  return BDPT_OK;
+}
+void freePool(std::vector<void*>& pool) {
+  for (void* p : pool) (void)hipFree(p);
+  pool.clear();
+}
+
+void stageMark(bdpt_ctx* c, hipStream_t st, const char* name) {
+  if (!c->timing || c->numStages >= kMaxStages) return;
+  c->stageNames[c->numStages] = name;
+  c->numStages++;
+  (void)hipEventRecord(c->ev[c->numStages], st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
+  if (!out_ctx) return BDPT_E_INVALID;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return BDPT_E_HIP;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return BDPT_E_HIP;
+  bdpt_ctx* c = new bdpt_ctx();
+  c->device = device_ordinal;
+  *out_ctx = c;
+  return BDPT_OK;
+}
+
+void bdpt_destroy(bdpt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  freePool(c->sceneAllocs);
+  freePool(c->frameAllocs);
+  if (c->evCreated)
+    for (int i = 0; i <= kMaxStages; i++) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+}
+
+const char* bdpt_last_error(const bdpt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
+  if (!c || !d) return BDPT_E_INVALID;
+  if (!d->positions || !d->normals || !d->indices || !d->triMaterial || !d->materials || !d->numMaterials) {
+    fail(c, "scene: positions, normals, indices, triMaterial and materials are required");
+    return BDPT_E_INVALID;
+  }
+  if (d->numLights == 0 || !d->lights) {
+    fail(c, "scene: at least one light is required (SceneLoaderWrapper adds a directional light when a file has none)");
+    return BDPT_E_INVALID;
+  }
+  if (d->numLights > BDPT_MAX_LIGHTS) {
+    fail(c, "scene: more than BDPT_MAX_LIGHTS lights");
+    return BDPT_E_LIMIT;
+  }
+  if (d->numTriangles >= (1u << 28)) {
+    fail(c, "scene: triangle count exceeds the 2^28 leaf-reference limit");
+    return BDPT_E_LIMIT;
+  }
+  for (uint32_t t = 0; t < d->numTriangles; t++) {
+    if (d->triMaterial[t] >= d->numMaterials) {
+      fail(c, "scene: triMaterial out of range");
+      return BDPT_E_INVALID;
+    }
+    for (int k = 0; k < 3; k++)
+      if (d->indices[(size_t)t * 3 + k] >= d->numVertices) {
+        fail(c, "scene: vertex index out of range");
+        return BDPT_E_INVALID;
+      }
+  }
+  for (uint32_t m = 0; m < d->numMaterials; m++) {
+    const bdpt_material& mm = d->materials[m];
+    const int ids[4] = {mm.texBaseColor, mm.texSpecular, mm.texEmissive, mm.texNormal};
+    for (int id : ids)
+      if (id >= (int)d->numTextures) {
+        fail(c, "scene: material texture index out of range");
+        return BDPT_E_INVALID;
+      }
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  freePool(c->sceneAllocs);
+  c->haveScene = false;
+  c->S = SceneDev{};
+
+  // per-triangle traversal flags: BLAS OPAQUE iff AlphaModeOpaque (Falcor Raytracing/RtModel.cpp:221-224),
+  // TRIANGLE_CULL_DISABLE iff double-sided (Raytracing/RtScene.cpp:175-178)
+  std::vector<uint32_t> triFlags(d->numTriangles);
+  for (uint32_t t = 0; t < d->numTriangles; t++) {
+    const uint32_t f = d->materials[d->triMaterial[t]].flags;
+    triFlags[t] = (BDPT_FLAG_ALPHA_MODE(f) != BDPT_ALPHA_MODE_OPAQUE ? kTriNonOpaque : 0u) |
+                  (BDPT_FLAG_DOUBLE_SIDED(f) ? kTriDoubleSided : 0u);
+  }
+  Bvh bvh;
+  buildBvh(d->positions, d->indices, d->numTriangles, triFlags.data(), bvh);
+  if (bvh.maxDepth > (uint32_t)kBvhMaxDepth) {
+    fail(c, "bvh deeper than the traversal stack");
+    return BDPT_E_LIMIT;
+  }
+  c->bvhInfo.numNodes = (uint32_t)bvh.nodes.size();
+  c->bvhInfo.numTriangles = d->numTriangles;
+  c->bvhInfo.maxDepth = bvh.maxDepth;
+  c->bvhInfo.nodeBytes = sizeof(BvhNode);
+  c->bvhInfo.triBytes = sizeof(BvhTri);
+  c->bvhInfo.sahCost = bvh.sahCost;
+
+  // per-primitive shading records: 3 x (position, normal, uv) + material id, 112 B
+  std::vector<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4, 0.0f);
+  for (uint32_t t = 0; t < d->numTriangles; t++) {
+    float* r = &shade[(size_t)t * kShadeRecF4 * 4];
+    for (int k = 0; k < 3; k++) {
+      const uint32_t vi = d->indices[(size_t)t * 3 + k];
+      const float* p = d->positions + (size_t)vi * 3;
+      const float* nn = d->normals + (size_t)vi * 3;
+      float* q = r + k * 8;
+      q[0] = p[0];
+      q[1] = p[1];
+      q[2] = p[2];
+      q[3] = nn[0];
+      q[4] = nn[1];
+      q[5] = nn[2];
+      q[6] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
+      q[7] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
+    }
+    uint32_t mid = d->triMaterial[t];
+    std::memcpy(r + 24, &mid, 4);
+  }
+
+  int rc;
+  const BvhNode* dNodes;
+  const BvhTri* dTris;
+  const float* dShade;
+  if ((rc = devUpload(c, c->sceneAllocs, &dNodes, bvh.nodes.data(), bvh.nodes.size()))) return rc;
+  if ((rc = devUpload(c, c->sceneAllocs, &dTris, bvh.tris.data(), bvh.tris.size()))) return rc;
+  if ((rc = devUpload(c, c->sceneAllocs, &dShade, shade.data(), shade.size()))) return rc;
+  c->S.nodes = reinterpret_cast<const float4*>(dNodes);
+  c->S.tris = reinterpret_cast<const float4*>(dTris);
+  c->S.shade = reinterpret_cast<const float4*>(dShade);
+  if ((rc = devUpload(c, c->sceneAllocs, &c->S.indices, d->indices, (size_t)d->numTriangles * 3))) return rc;
+  if (d->bitangents) {
+    if ((rc = devUpload(c, c->sceneAllocs, &c->S.bitangents, d->bitangents, (size_t)d->numVertices * 3))) return rc;
+    c->S.hasBitangents = 1;
+  }
+  if ((rc = devUpload(c, c->sceneAllocs, &c->S.materials, d->materials, d->numMaterials))) return rc;
+  std::vector<TexDev> texs(d->numTextures);
+  for (uint32_t i = 0; i < d->numTextures; i++) {
+    const bdpt_texture& t = d->textures[i];
+    if (!t.rgba8 || !t.width || !t.height) {
+      fail(c, "scene: empty texture");
+      return BDPT_E_INVALID;
+    }
+    const uint8_t* px;
+    if ((rc = devUpload(c, c->sceneAllocs, &px, t.rgba8, (size_t)t.width * t.height * 4))) return rc;
+    texs[i] = TexDev{px, t.width, t.height, t.srgb, 0};
+  }
+  if ((rc = devUpload(c, c->sceneAllocs, &c->S.textures, texs.data(), texs.size()))) return rc;
+  SceneConst sc;
+  std::memset(&sc, 0, sizeof(sc));
+  std::memcpy(sc.lights, d->lights, sizeof(bdpt_light) * d->numLights);
+  for (int i = 0; i < 256; i++) {
+    double cc = (double)i / 255.0;
+    double l = (cc <= 0.04045) ? cc / 12.92 : std::pow((cc + 0.055) / 1.055, 2.4);
+    sc.srgbLut[i] = (float)l;
+  }
+  if ((rc = devUpload(c, c->sceneAllocs, &c->S.sc, &sc, 1))) return rc;
+  c->S.numLights = d->numLights;
+  c->haveScene = true;
+  return BDPT_OK;
+}
+
+int bdpt_get_bvh_info(const bdpt_ctx* c, bdpt_bvh_info* out) {
+  if (!c || !out) return BDPT_E_INVALID;
+  if (!c->haveScene) return BDPT_E_STATE;
+  *out = c->bvhInfo;
+  return BDPT_OK;
+}
+
+int bdpt_set_camera(bdpt_ctx* c, const bdpt_camera* cam) {
+  if (!c || !cam) return BDPT_E_INVALID;
+  c->cam = *cam;
+  c->haveCamera = true;
+  return BDPT_OK;
+}
+
+int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, uint32_t maxDepth) {
+  if (!c) return BDPT_E_INVALID;
+  if (!width || !height || tile.y0 > tile.y1 || tile.y1 > height) {
+    fail(c, "resize: bad frame or tile");
+    return BDPT_E_INVALID;
+  }
+  if (maxDepth > BDPT_MAX_DEPTH) {
+    fail(c, "resize: maxDepth exceeds BDPT_MAX_DEPTH");
+    return BDPT_E_LIMIT;
+  }
+  if ((uint64_t)width * height >= (1ull << 32)) {
+    fail(c, "resize: frame too large");
+    return BDPT_E_LIMIT;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  freePool(c->frameAllocs);
+  c->haveSize = false;
+  c->W = width;
+  c->H = height;
+  c->tile = tile;
+  c->maxDepth = maxDepth;
+  PathBuf P{};
+  P.Np = (tile.y1 - tile.y0) * width;
+  P.D1 = std::max<uint32_t>(maxDepth, 1) + 1;
+  const size_t np = std::max<uint32_t>(P.Np, 1);
+  int rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.v, (size_t)2 * P.D1 * NF * np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.rayDir, (size_t)6 * np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.seedL, np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.eyeLast, np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.lightLast, np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.lightReal, np))) return rc;
+  for (int q = 0; q < 3; q++)
+    if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)2 * BDPT_MAX_DEPTH + 8))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &c->splat, (size_t)width * height * 4))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &c->counters, 1))) return rc;
+  HIPCHK(c, hipMemset(c->splat, 0, (size_t)width * height * 4 * sizeof(unsigned long long)));
+  HIPCHK(c, hipMemset(c->counters, 0, sizeof(DevCounters)));
+  c->P = P;
+  if (!c->evCreated) {
+    for (int i = 0; i <= kMaxStages; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    c->evCreated = true;
+  }
+  c->haveSize = true;
+  return BDPT_OK;
+}
+
+int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_gbuffer* out, void* stream) {
+  if (!c || !gp || !out) return BDPT_E_INVALID;
+  if (!c->haveScene || !c->haveCamera || !c->haveSize) {
+    fail(c, "gbuffer_execute: scene, camera and size must be set first");
+    return BDPT_E_STATE;
+  }
+  if (!out->worldPosition || !out->worldNormal || !out->materialDiffuse || !out->materialSpecRough ||
+      !out->materialExtraParams || !out->emissive) {
+    fail(c, "gbuffer_execute: all six channels are required");
+    return BDPT_E_INVALID;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GBufferDev G{};
+  G.cam = c->cam;
+  G.gp = *gp;
+  G.W = c->W;
+  G.H = c->H;
+  G.y0 = c->tile.y0;
+  G.y1 = c->tile.y1;
+  G.gb = *out;
+  G.counters = nullptr;  // primary rays are tallied analytically by bdpt_get_counters (one per tile pixel)
+  launchGBuffer(c->S, G, st);
+  HIPCHK(c, hipGetLastError());
+  c->lastStream = st;
+  return BDPT_OK;
+}
+
+int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream) {
+  if (!c || !p || !in || !out) return BDPT_E_INVALID;
+  if (!c->haveScene || !c->haveCamera || !c->haveSize) {
+    fail(c, "execute: scene, camera and size must be set first");
+    return BDPT_E_STATE;
+  }
+  if (p->maxDepth > c->maxDepth) {
+    fail(c, "execute: params.maxDepth exceeds the depth given to bdpt_resize");
+    return BDPT_E_LIMIT;
+  }
+  if (p->matIndex > 1) {
+    fail(c, "execute: matIndex must be 0 (GGX) or 1 (Lambertian)");
+    return BDPT_E_INVALID;
+  }
+  if (!in->worldPosition || !in->worldNormal || !in->materialDiffuse || !in->materialSpecRough || !in->emissive) {
+    fail(c, "execute: G-buffer channels missing");
+    return BDPT_E_INVALID;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const PathBuf& P = c->P;
+  FrameDev F{};
+  F.cam = c->cam;
+  F.p = *p;
+  F.W = c->W;
+  F.H = c->H;
+  F.y0 = c->tile.y0;
+  F.y1 = c->tile.y1;
+  F.out = out;
+  F.splat = c->splat;
+  F.gb = *in;
+  F.counters = (p->flags & BDPT_PARAM_COUNTERS) ? c->counters : nullptr;
+  const int D = (int)p->maxDepth;
+
+  c->numStages = 0;
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
+  HIPCHK(c, hipMemsetAsync(P.qcount, 0, ((size_t)2 * BDPT_MAX_DEPTH + 8) * sizeof(uint32_t), st));
+  HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->W * c->H * 4 * sizeof(unsigned long long), st));
+  if (F.counters) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
+  stageMark(c, st, "clear");
+
+  launchInitPaths(c->S, F, P, st);
+  stageMark(c, st, "init_paths");
+
+  // eye walk: vertices 2..D (BDPTMain.rt.hlsl:106-112)
+  int qc = 1;  // next free queue counter
+  {
+    const uint32_t* qin = P.queue[0];
+    const uint32_t* cin = &P.qcount[0];
+    int ping = 1;
+    for (int k = 1; k <= D - 1; k++) {
+      launchExtend(c->S, F, P, PATH_EYE, k, D, qin, cin, P.queue[ping], &P.qcount[qc], st);
+      qin = P.queue[ping];
+      cin = &P.qcount[qc];
+      qc++;
+      ping = 3 - ping;
+    }
+    stageMark(c, st, "eye_extend");
+  }
+  // light walk: vertices 1..D (BDPTMain.rt.hlsl:138-145)
+  {
+    const uint32_t* qin = P.queue[0];
+    const uint32_t* cin = &P.qcount[0];
+    int ping = 1;
+    for (int k = 0; k <= D - 1; k++) {
+      launchExtend(c->S, F, P, PATH_LIGHT, k, D, qin, cin, P.queue[ping], &P.qcount[qc], st);
+      qin = P.queue[ping];
+      cin = &P.qcount[qc];
+      qc++;
+      ping = 3 - ping;
+    }
+    stageMark(c, st, "light_extend");
+  }
+  launchNee(c->S, F, P, st);
+  stageMark(c, st, "nee");
+  if (!(p->flags & BDPT_PARAM_NO_SPLAT)) {
+    launchSplat(c->S, F, P, st);
+    stageMark(c, st, "splat");
+  }
+  if (!(p->flags & BDPT_PARAM_NO_CONNECT)) {
+    launchConnect(c->S, F, P, st);
+    stageMark(c, st, "connect");
+  }
+  if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
+    launchResolve(c->splat, 0, out, c->W, c->tile.y0, c->tile.y1, st);
+    stageMark(c, st, "resolve");
+  }
+  HIPCHK(c, hipGetLastError());
+  c->lastStream = st;
+  return BDPT_OK;
+}
+
+int bdpt_splat_buffer(bdpt_ctx* c, uint64_t** out_ptr, uint64_t* out_n) {
+  if (!c || !out_ptr) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  *out_ptr = reinterpret_cast<uint64_t*>(c->splat);
+  if (out_n) *out_n = (uint64_t)c->W * c->H * 4;
+  return BDPT_OK;
+}
+
+int bdpt_resolve(bdpt_ctx* c, const uint64_t* splat, uint32_t splat_row0, float* out, void* stream) {
+  if (!c || !splat || !out) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  if (splat_row0 > c->tile.y0) {
+    fail(c, "resolve: splat buffer does not cover the tile");
+    return BDPT_E_INVALID;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  launchResolve(reinterpret_cast<const unsigned long long*>(splat), splat_row0, out, c->W, c->tile.y0, c->tile.y1, st);
+  HIPCHK(c, hipGetLastError());
+  return BDPT_OK;
+}
+
+int bdpt_accumulate(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount,
+                    uint64_t numTexels, void* stream) {
+  if (!c || !lastFrame || !curFrame) return BDPT_E_INVALID;
+  launchAccumulate(lastFrame, curFrame, accumCount, maxAccumCount, numTexels, reinterpret_cast<hipStream_t>(stream));
+  HIPCHK(c, hipGetLastError());
+  return BDPT_OK;
+}
+
+int bdpt_get_counters(bdpt_ctx* c, bdpt_counters* out) {
+  if (!c || !out) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  HIPCHK(c, hipStreamSynchronize(c->lastStream));
+  DevCounters h;
+  HIPCHK(c, hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+  static_assert(sizeof(DevCounters) == sizeof(bdpt_counters), "counter layouts must match");
+  std::memcpy(out, &h, sizeof(h));
+  out->raysPrimary = (uint64_t)c->P.Np;  // GBufferRayGen traces exactly one ray per tile pixel
+  return BDPT_OK;
+}
+
+int bdpt_enable_stage_timing(bdpt_ctx* c, int enable) {
+  if (!c) return BDPT_E_INVALID;
+  c->timing = enable != 0;
+  return BDPT_OK;
+}
+
+int bdpt_get_stage_times(bdpt_ctx* c, const char** names, float* ms, int cap) {
+  if (!c || !names || !ms) return BDPT_E_INVALID;
+  if (!c->timing || c->numStages == 0) return 0;
+  HIPCHK(c, hipEventSynchronize(c->ev[c->numStages]));
+  int n = std::min(cap, c->numStages);
+  for (int i = 0; i < n; i++) {
+    names[i] = c->stageNames[i];
+    float t = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+    ms[i] = t;
+  }
+  return n;
+}
+
+int bdpt_sync(bdpt_ctx* c, void* stream) {
+  if (!c) return BDPT_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  return BDPT_OK;
+}
+
+// ---- test hooks --------------------------------------------------------------------------------
+int bdpt_test_rng(bdpt_ctx* c, const uint32_t* val0, const uint32_t* val1, uint32_t n, uint32_t draws, uint32_t* out_states,
+                  float* out_floats) {
+  if (!c || !val0 || !val1 || !out_states || !out_floats) return BDPT_E_INVALID;
+  std::vector<void*> pool;
+  const uint32_t *d0, *d1;
+  uint32_t* ds;
+  float* df;
+  int rc;
+  if ((rc = devUpload(c, pool, &d0, val0, n)) || (rc = devUpload(c, pool, &d1, val1, n)) ||
+      (rc = devAlloc(c, pool, &ds, (size_t)n * draws)) || (rc = devAlloc(c, pool, &df, (size_t)n * draws))) {
+    freePool(pool);
+    return rc;
+  }
+  launchTestRng(d0, d1, n, draws, ds, df, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out_states, ds, (size_t)n * draws * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_floats, df, (size_t)n * draws * 4, hipMemcpyDeviceToHost);
+  freePool(pool);
+  if (e != hipSuccess) {
+    fail(c, hipGetErrorString(e));
+    return BDPT_E_HIP;
+  }
+  return BDPT_OK;
+}
+
+int bdpt_test_trace(bdpt_ctx* c, const float* rays, uint32_t n, int mode, int32_t* out_prim, float* out_tuv) {
+  if (!c || !rays || !out_prim || !out_tuv || mode < 0 || mode > 2) return BDPT_E_INVALID;
+  if (!c->haveScene) return BDPT_E_STATE;
+  std::vector<void*> pool;
+  const float* dr;
+  int32_t* dp;
+  float* dt;
+  int rc;
+  if ((rc = devUpload(c, pool, &dr, rays, (size_t)n * 8)) || (rc = devAlloc(c, pool, &dp, n)) ||
+      (rc = devAlloc(c, pool, &dt, (size_t)n * 3))) {
+    freePool(pool);
+    return rc;
+  }
+  launchTestTrace(c->S, dr, n, mode, dp, dt, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out_prim, dp, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_tuv, dt, (size_t)n * 12, hipMemcpyDeviceToHost);
+  freePool(pool);
+  if (e != hipSuccess) {
+    fail(c, hipGetErrorString(e));
+    return BDPT_E_HIP;
+  }
+  return BDPT_OK;
+}
+
+int bdpt_test_bsdf(bdpt_ctx* c, const float* in, uint32_t n, uint32_t matIndex, float* out) {
+  if (!c || !in || !out) return BDPT_E_INVALID;
+  std::vector<void*> pool;
+  const float* di;
+  float* dout;
+  int rc;
+  if ((rc = devUpload(c, pool, &di, in, (size_t)n * 20)) || (rc = devAlloc(c, pool, &dout, (size_t)n * 16))) {
+    freePool(pool);
+    return rc;
+  }
+  launchTestBsdf(di, n, matIndex, dout, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 64, hipMemcpyDeviceToHost);
+  freePool(pool);
+  if (e != hipSuccess) {
+    fail(c, hipGetErrorString(e));
+    return BDPT_E_HIP;
+  }
+  return BDPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// kernels.h — device-side views and launch entry points shared by kernels.hip and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bdpt.h"
+
+namespace bdpt {
+
+constexpr int kWave = 64;         // gfx950 wavefront
+constexpr int kStackEntries = 32; // per-lane traversal stack in LDS (kBvhMaxDepth = 30)
+constexpr int kShadeRecF4 = 7;    // float4s per triangle shading record (112 B)
+
+// Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45, minus pdfForward which only
+// the never-called MIS code reads).
+enum : int { F_COL = 0, F_POS = 3, F_N = 6, F_V = 9, F_DIF = 12, F_SPEC = 15, F_ROUGH = 18, F_ISSPEC = 19, NF = 20 };
+enum : int { PATH_EYE = 0, PATH_LIGHT = 1 };
+
+struct TexDev {
+  const uint8_t* px;
+  uint32_t w, h, srgb, pad;
+};
+
+struct SceneConst {
+  bdpt_light lights[BDPT_MAX_LIGHTS];
+  float srgbLut[256];
+};
+
+struct SceneDev {
+  const float4* nodes;     // 4 per node
+  const float4* tris;      // 3 per leaf triangle, leaf order
+  const float4* shade;     // kShadeRecF4 per primitive, primitive order
+  const float* bitangents; // 3 per vertex (normal-mapped primary hits only)
+  const uint32_t* indices; // 3 per primitive
+  const bdpt_material* materials;
+  const TexDev* textures;
+  const SceneConst* sc;
+  uint32_t numLights;
+  uint32_t hasBitangents;
+};
+
+struct DevCounters {  // mirrors bdpt_counters field order
+  unsigned long long v[12];
+};
+enum : int {
+  C_RAYS_PRIMARY = 0, C_RAYS_EYE, C_RAYS_LIGHT, C_RAYS_NEE, C_RAYS_SPLAT, C_RAYS_CONNECT,
+  C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS
+};
+
+// Per-tile path state, SoA by tile-local pixel index p in [0, Np).
+struct PathBuf {
+  float* v;            // planes: ((path*(D1) + k)*NF + field)*Np + p
+  float* rayDir;       // planes: (path*3 + axis)*Np + p
+  uint32_t* seedL;     // RNG state after sampleLight
+  uint8_t* eyeLast;    // last stored eye vertex (ghost included); 0 = pixel has no geometry
+  uint8_t* lightLast;  // last stored light vertex (ghost included)
+  uint8_t* lightReal;  // number of light vertices produced by hits (takeContribution, BDPTMain.rt.hlsl:144)
+  uint32_t* queue[3];  // [0] valid pixels; [1],[2] ping-pong extension queues
+  uint32_t* qcount;    // [0] valid count, [1..] one counter per extension step
+  uint32_t Np, D1;
+};
+
+struct FrameDev {
+  bdpt_camera cam;
+  bdpt_params p;
+  uint32_t W, H, y0, y1;
+  float* out;          // full-frame RGBA32F
+  unsigned long long* splat;  // full-frame 4 x u64
+  bdpt_gbuffer gb;
+  DevCounters* counters;  // null unless BDPT_PARAM_COUNTERS
+};
+
+struct GBufferDev {
+  bdpt_camera cam;
+  bdpt_gbuffer_params gp;
+  uint32_t W, H, y0, y1;
+  bdpt_gbuffer gb;
+  DevCounters* counters;
+};
+
+// launchers (kernels.hip)
+void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
+void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
+                  const uint32_t* countIn, uint32_t* qout, uint32_t* countOut, hipStream_t st);
+void launchNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
+                   hipStream_t st);
+void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);
+void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t draws, uint32_t* states, float* floats,
+                   hipStream_t st);
+void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode, int32_t* prim, float* tuv, hipStream_t st);
+void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st);
+
+}  // namespace bdpt

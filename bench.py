@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the BDPT render pass on MI355X (BASELINE.json metric).
+
+One "step" = one pipeline frame of the hot path (G-buffer pass + BDPT pass + accumulation) at
+1 spp over the whole 1920x1080 image, depth 8, on the Sponza stand-in scene (seeded procedural
+atrium, 262,144 triangles, textured GGX — the real Sponza asset is in neither the reference
+tree nor this image).  With N GPUs the image is tiled into N row bands (scene
+replicated); each rank renders its band, the fixed-point splat buffers are summed with one RCCL
+reduce-scatter per frame, and each rank resolves + accumulates its band.  value = rays actually
+traced by all ranks / max-over-ranks wall time of the K timed steps.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene atrium|cornell] ...
+For N > 1 launch with torch.distributed.run (one rank per GPU).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
+
+
+def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
+    """B_ray = 32 + nodeBytes*n_int + triBytes*n_tri + O (O = 4 shadow / 20 closest);
+    388 B per closest-hit shade; 200 B per connection pair; 116 B per NEE/splat term; 120 B per pixel-frame."""
+    closest = cnt["raysPrimary"] + cnt["raysEyeExtend"] + cnt["raysLightExtend"]
+    shadow = cnt["raysNee"] + cnt["raysSplat"] + cnt["raysConnect"]
+    b = {}
+    b["closest"] = 52 * closest + node_b * cnt["nodeVisitsClosest"] + tri_b * cnt["triTestsClosest"] + 388 * closest
+    b["nee"] = 116 * cnt["raysNee"]
+    b["splat"] = 116 * cnt["raysSplat"]
+    b["connect_pairs"] = 200 * n_pairs_eval
+    b["shadow_rays"] = 36 * shadow + node_b * cnt["nodeVisitsShadow"] + tri_b * cnt["triTestsShadow"]
+    b["fixed"] = 120 * n_pix_tile
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--mat", type=int, default=None, help="0 GGX (default for atrium), 1 Lambertian (default for cornell)")
+    ap.add_argument("--triangles", type=int, default=262144)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render pass has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    W, H, D = args.width, args.height, args.depth
+    mat = args.mat if args.mat is not None else (0 if args.scene == "atrium" else 1)
+    scene = pkg.Scene.atrium(1, args.triangles) if args.scene == "atrium" else pkg.Scene.cornell()
+
+    # tile = contiguous band of rows; bands padded to equal height so reduce-scatter chunks are equal
+    rows = (H + world - 1) // world
+    y0, y1 = min(rank * rows, H), min((rank + 1) * rows, H)
+    pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, tile=(y0, y1), accum_limit=10000)
+    ctx = pipe.ctx
+    info = ctx.bvh_info()
+    splat_full = None
+    if world > 1:
+        splat_full = torch.zeros(rows * world * W * 4, dtype=torch.int64, device=dev)
+        splat_mine = torch.zeros(rows * W * 4, dtype=torch.int64, device=dev)
+        ctx.set_splat_buffer(C.c_void_p(splat_full.data_ptr()), splat_full.numel())
+
+    def step(flags=0):
+        """One pipeline frame on this rank's tile."""
+        if world == 1:
+            pipe.render_frame(accumulate=True, extra_flags=flags)
+        else:
+            pipe.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE)
+            dist.reduce_scatter_tensor(splat_mine, splat_full, op=dist.ReduceOp.SUM)
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            ctx.resolve(C.c_void_p(splat_mine.data_ptr()), y0, C.c_void_p(pipe.output.data_ptr()), st)
+            n = pipe.accum_count
+            pipe.accum_count += 1
+            ctx.accumulate(C.c_void_p(pipe.last_frame[y0:y1].data_ptr()), C.c_void_p(pipe.output[y0:y1].data_ptr()), n,
+                           pipe.accum_limit, (y1 - y0) * W, st)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- untimed: node/triangle visit statistics of the first timed frame (deterministic per frame)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    saved = (pipe.gbuffer_frame, pipe.bdpt_frame, pipe.accum_count)
+    step(pkg.abi.PARAM_COUNTERS)
+    torch.cuda.synchronize(dev)
+    stat = ctx.counters().as_dict()
+    pipe.gbuffer_frame, pipe.bdpt_frame, pipe.accum_count = saved
+    barrier()
+
+    # ---- timed region: exactly K steps, stage times from HIP events on the launch stream
+    ctx.enable_stage_timing(True)
+    rays_total = 0
+    stage_ms = {}
+    per_stage_rays = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, ms in ctx.stage_times():  # synchronises on this frame's last event
+            stage_ms[name] = stage_ms.get(name, 0.0) + ms
+        c = ctx.counters().as_dict()
+        rays_total += sum(c[k] for k in ("raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat",
+                                         "raysConnect"))
+        for k in ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect"):
+            per_stage_rays[k] = per_stage_rays.get(k, 0) + c[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.enable_stage_timing(False)
+
+    t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, rays_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, rays_all = elapsed, float(rays_total)
+
+    if rank == 0:
+        K = args.steps
+        mrays = rays_all / elapsed_max / 1e6
+        # roofline of the dominant kernel (connect): algorithmic bytes per launch / mean launch duration
+        n_shadow = max(1, stat["raysNee"] + stat["raysSplat"] + stat["raysConnect"])
+        n_int_s = stat["nodeVisitsShadow"] / n_shadow
+        n_tri_s = stat["triTestsShadow"] / n_shadow
+        n_closest = max(1, stat["raysEyeExtend"] + stat["raysLightExtend"])
+        n_int_c = stat["nodeVisitsClosest"] / n_closest
+        n_tri_c = stat["triTestsClosest"] / n_closest
+        # defined connection pairs per valid pixel (cameraLength <= totalLength): sum_{t=2..D} min(t, D-1)
+        pairs_per_pixel = sum(min(tl, D - 1) for tl in range(2, D + 1))
+        conn_rays_per_launch = per_stage_rays.get("raysConnect", 0) / K
+        conn_bytes = conn_rays_per_launch * (36 + info.nodeBytes * n_int_s + info.triBytes * n_tri_s) + \
+            200.0 * pairs_per_pixel * stat["pixelsValid"]
+        conn_ms = stage_ms.get("connect", 0.0) / K
+        achieved = conn_bytes / (conn_ms * 1e-3) / 1e9 if conn_ms > 0 else 0.0
+        dominant = max(stage_ms.items(), key=lambda kv: kv[1])[0] if stage_ms else "connect"
+        out = {
+            "metric": "Mrays/s, BDPT pass, Sponza-class scene 1080p depth 8",
+            "value": round(mrays, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / K * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("procedural atrium (Sponza stand-in), %d triangles, textured GGX" % scene.desc.numTriangles)
+                if args.scene == "atrium" else "Cornell box, 32 triangles, Lambertian",
+                "resolution": [W, H], "max_depth": D, "spp_per_step": 1, "mat_index": mat,
+                "parallelism": "tile%d" % world,
+                "rays_per_frame": int(rays_all / K),
+                "rays_reference_equivalent_per_frame": int(stat["pixelsValid"] * ((D + 1) ** 2 - 1) + (y1 - y0) * W)
+                if world == 1 else None,
+                "bvh": {"nodes": info.numNodes, "node_bytes": info.nodeBytes, "tri_bytes": info.triBytes,
+                        "max_depth": info.maxDepth, "sah_cost": round(info.sahCost, 2)},
+                "visits_per_ray": {"shadow_nodes": round(n_int_s, 2), "shadow_tris": round(n_tri_s, 2),
+                                   "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
+                "stage_ms_per_step": {k: round(v / K, 3) for k, v in stage_ms.items()},
+                "stage_mrays": {k: round(per_stage_rays.get(r, 0) / (stage_ms[k] * 1e-3) / 1e6, 1)
+                                for k, r in (("eye_extend", "raysEyeExtend"), ("light_extend", "raysLightExtend"),
+                                             ("nee", "raysNee"), ("splat", "raysSplat"), ("connect", "raysConnect"))
+                                if stage_ms.get(k, 0) > 0},
+                "dominant_stage": dominant,
+            },
+            "roofline": {
+                "kernel": "connect_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(conn_bytes), "ms_per_launch": round(conn_ms, 3),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    pipe.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def effective_cpus():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s):
+    """The oracle (scalar C++ restatement, kind "port") on this box's host cores, on a band of rows of
+    the same frame in the middle of the image, sized from a short probe to take about budget_s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    cores = effective_cpus()
+    gp = pipe.gbuffer_params()
+    p = pipe.bdpt_params()
+
+    def run(rows):
+        ya = max(0, H // 2 - rows // 2)
+        yb = min(H, ya + rows)
+        orc = ob.OracleRender(pkg.abi, scene.desc, W, H, ya, yb)
+        t0 = time.perf_counter()
+        orc.gbuffer(pipe.cam, gp, threads=cores)
+        cnt = orc.bdpt(pipe.cam, p, threads=cores)
+        dt = time.perf_counter() - t0
+        rays = cnt.total_rays() + (yb - ya) * W
+        orc.close()
+        return rays, dt, yb - ya
+
+    rays, dt, r = run(max(2, min(H, cores // 4 + 2)))
+    rate = rays / max(dt, 1e-6)
+    rows = int(max(r, min(H, budget_s * rate / max(1.0, rays / r))))
+    rays, dt, r = run(rows)
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d middle rows of the same %dx%d depth-%d frame (%d rays, %.1f s); the oracle traces every ray the "
+                      "reference issues, incl. zero-contribution ones the GPU path skips" % (r, W, H, D, rays, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,9 @@ class Context:
         self._check(self._lib.bdpt_splat_buffer(self._h, C.byref(p), C.byref(n)), "bdpt_splat_buffer")
         return p.value, n.value
 
+    def set_splat_buffer(self, ptr, num_u64):
+        self._check(self._lib.bdpt_set_splat_buffer(self._h, ptr, num_u64), "bdpt_set_splat_buffer")
+
     def resolve(self, splat_ptr, splat_row0, out_ptr, stream=None):
         self._check(self._lib.bdpt_resolve(self._h, splat_ptr, splat_row0, out_ptr, stream), "bdpt_resolve")
 

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "bdpt_gbuffer_execute": (C.c_int, [C.c_void_p, C.POINTER(GBufferParams), C.POINTER(GBuffer), C.c_void_p]),
     "bdpt_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bdpt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bdpt_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                   C.c_void_p]),

@@ -34,7 +34,8 @@ struct bdpt_ctx {
   bdpt_tile tile{0, 0};
   PathBuf P{};
   std::vector<void*> frameAllocs;
-  unsigned long long* splat = nullptr;
+  unsigned long long* splat = nullptr;     // buffer in use (own or caller-provided)
+  unsigned long long* ownSplat = nullptr;
   DevCounters* counters = nullptr;
   hipStream_t lastStream = nullptr;
   // stage timing
@@ -302,7 +303,8 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   for (int q = 0; q < 3; q++)
     if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)2 * BDPT_MAX_DEPTH + 8))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &c->splat, (size_t)width * height * 4))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &c->ownSplat, (size_t)width * height * 4))) return rc;
+  c->splat = c->ownSplat;
   if ((rc = devAlloc(c, c->frameAllocs, &c->counters, 1))) return rc;
   HIPCHK(c, hipMemset(c->splat, 0, (size_t)width * height * 4 * sizeof(unsigned long long)));
   HIPCHK(c, hipMemset(c->counters, 0, sizeof(DevCounters)));
@@ -372,14 +374,14 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   F.out = out;
   F.splat = c->splat;
   F.gb = *in;
-  F.counters = (p->flags & BDPT_PARAM_COUNTERS) ? c->counters : nullptr;
+  F.counters = c->counters;  // ray tallies are always on; node/triangle visits need BDPT_PARAM_COUNTERS
   const int D = (int)p->maxDepth;
 
   c->numStages = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
   HIPCHK(c, hipMemsetAsync(P.qcount, 0, ((size_t)2 * BDPT_MAX_DEPTH + 8) * sizeof(uint32_t), st));
   HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->W * c->H * 4 * sizeof(unsigned long long), st));
-  if (F.counters) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
+  HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
   stageMark(c, st, "clear");
 
   launchInitPaths(c->S, F, P, st);
@@ -438,6 +440,21 @@ int bdpt_splat_buffer(bdpt_ctx* c, uint64_t** out_ptr, uint64_t* out_n) {
   if (!c->haveSize) return BDPT_E_STATE;
   *out_ptr = reinterpret_cast<uint64_t*>(c->splat);
   if (out_n) *out_n = (uint64_t)c->W * c->H * 4;
+  return BDPT_OK;
+}
+
+int bdpt_set_splat_buffer(bdpt_ctx* c, uint64_t* device_ptr, uint64_t num_u64) {
+  if (!c) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  if (!device_ptr) {
+    c->splat = c->ownSplat;
+    return BDPT_OK;
+  }
+  if (num_u64 < (uint64_t)c->W * c->H * 4) {
+    fail(c, "set_splat_buffer: buffer smaller than width*height*4");
+    return BDPT_E_INVALID;
+  }
+  c->splat = reinterpret_cast<unsigned long long*>(device_ptr);
   return BDPT_OK;
 }
 

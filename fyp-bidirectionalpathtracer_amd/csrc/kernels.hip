@@ -320,6 +320,13 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
 BD void addCount(DevCounters* c, int idx, uint32_t n) {
   if (n) atomicAdd(&c->v[idx], (unsigned long long)n);
 }
+// Sum over the active lanes of the wave, one atomic per wave (always-on ray tallies).
+BD void waveAddCount(DevCounters* c, int idx, uint32_t n) {
+  uint32_t v = n;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&c->v[idx], (unsigned long long)v);
+}
 
 // ------------------------------------------------------------------------------------------------
 // vertex planes
@@ -572,7 +579,6 @@ __global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, P
     uint32_t nNodes = 0, nTris = 0;
     Hit h = traverse<0, COUNT>(S, o, d, F.p.minT, 1.0e38f, s_stack + threadIdx.x, nNodes, nTris);
     if (COUNT) {
-      addCount(F.counters, path == PATH_EYE ? C_RAYS_EYE : C_RAYS_LIGHT, 1);
       addCount(F.counters, C_NODE_CLOSEST, nNodes);
       addCount(F.counters, C_TRI_CLOSEST, nTris);
     }
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, P
       }
     }
   }
+  waveAddCount(F.counters, path == PATH_EYE ? C_RAYS_EYE : C_RAYS_LIGHT, active ? 1u : 0u);
   wavePush(survive, p, qout, countOut);
 }
 
@@ -627,12 +634,8 @@ __global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, P
 // is skipped when the visible-light value is already 0 after clampVec (identical output).
 // ------------------------------------------------------------------------------------------------
 template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  __shared__ int s_stack[kStackEntries * kWave];
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  if (i >= n) return;
+BD void neeLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nRays, uint32_t& nNodes,
+                uint32_t& nTris) {
   const uint32_t p = P.queue[0][i];
   const size_t pix = (size_t)F.y0 * F.W + p;
   float4* out4 = reinterpret_cast<float4*>(F.out);
@@ -641,7 +644,6 @@ __global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, Path
   const uint32_t D = F.p.maxDepth;
   const int eyeLast = P.eyeLast[p];
   const int lightsCount = (int)S.numLights;
-  uint32_t nNodes = 0, nTris = 0, nRays = 0;
   f3 prevColor = mk(1.0f);  // cameraPath[0].color
   for (uint32_t t = 0; t < D; t++) {
     const float r = nextRand(seed);
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, Path
       f3 shade = prevColor * direct;
       shade = clampVec(shade / (float)(t + 2), F.p.clampUpper);
       if (!allZero(shade)) {
-        Hit h = traverse<2, COUNT>(S, pos, L, F.p.minT, distToLight, s_stack + threadIdx.x, nNodes, nTris);
+        Hit h = traverse<2, COUNT>(S, pos, L, F.p.minT, distToLight, stk, nNodes, nTris);
         nRays++;
         if (h.prim < 0) add = shade;
       }
@@ -682,11 +684,20 @@ __global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, Path
     }
   }
   out4[pix] = acc;
+}
+template <bool GGX, bool COUNT>
+__global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  __shared__ int s_stack[kStackEntries * kWave];
+  const uint32_t n = P.qcount[0];
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;
+  if (i < n) neeLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nRays, nNodes, nTris);
+  waveAddCount(F.counters, C_RAYS_NEE, nRays);
+  waveAddCount(F.counters, C_PIX_VALID, i < n ? 1u : 0u);
   if (COUNT) {
-    addCount(F.counters, C_RAYS_NEE, nRays);
-    addCount(F.counters, C_NODE_SHADOW, nNodes);
-    addCount(F.counters, C_TRI_SHADOW, nTris);
-    addCount(F.counters, C_PIX_VALID, 1);
+    waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
+    waveAddCount(F.counters, C_TRI_SHADOW, nTris);
   }
 }
 
@@ -696,25 +707,20 @@ __global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, Path
 // out-of-frame indices are discarded (quirk 8).
 // ------------------------------------------------------------------------------------------------
 template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  __shared__ int s_stack[kStackEntries * kWave];
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  if (i >= n) return;
+BD void splatLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nRays, uint32_t& nNodes,
+                  uint32_t& nTris, uint32_t& nSplat) {
   const uint32_t p = P.queue[0][i];
   const int real = P.lightReal[p];
   const f3 camPos = ld3(F.cam.posW);
   const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
   const f3 cameraN = normalize(Wc);
-  uint32_t nNodes = 0, nTris = 0, nRays = 0, nSplat = 0;
   for (int t = 0; t < real; t++) {
     Vtx lv;
     loadSurf(P, PATH_LIGHT, t + 1, p, lv);
     const f3 dirToCamera = normalize(camPos - lv.pos);
     const float disToCamera = length(camPos - lv.pos);
     if (!(dot(cameraN, dirToCamera) < 0)) continue;
-    Hit h = traverse<2, COUNT>(S, lv.pos, dirToCamera, F.p.minT, disToCamera, s_stack + threadIdx.x, nNodes, nTris);
+    Hit h = traverse<2, COUNT>(S, lv.pos, dirToCamera, F.p.minT, disToCamera, stk, nNodes, nTris);
     nRays++;
     if (h.prim >= 0) continue;
     // pixel index
@@ -746,11 +752,20 @@ __global__ __launch_bounds__(kWave) void splat_kernel(SceneDev S, FrameDev F, Pa
     atomicAdd(&sp[3], 1ull);
     nSplat++;
   }
+}
+template <bool GGX, bool COUNT>
+__global__ __launch_bounds__(kWave) void splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  __shared__ int s_stack[kStackEntries * kWave];
+  const uint32_t n = P.qcount[0];
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0, nSplat = 0;
+  if (i < n) splatLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nRays, nNodes, nTris, nSplat);
+  waveAddCount(F.counters, C_RAYS_SPLAT, nRays);
+  waveAddCount(F.counters, C_SPLATS, nSplat);
   if (COUNT) {
-    addCount(F.counters, C_RAYS_SPLAT, nRays);
-    addCount(F.counters, C_NODE_SHADOW, nNodes);
-    addCount(F.counters, C_TRI_SHADOW, nTris);
-    addCount(F.counters, C_SPLATS, nSplat);
+    waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
+    waveAddCount(F.counters, C_TRI_SHADOW, nTris);
   }
 }
 
@@ -782,12 +797,8 @@ BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx
 }
 
 template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  __shared__ int s_stack[kStackEntries * kWave];
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  if (i >= n) return;
+BD void connectLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nRays, uint32_t& nNodes,
+                    uint32_t& nTris) {
   const uint32_t p = P.queue[0][i];
   const size_t pix = (size_t)F.y0 * F.W + p;
   float4* out4 = reinterpret_cast<float4*>(F.out);
@@ -795,7 +806,6 @@ __global__ __launch_bounds__(kWave) void connect_kernel(SceneDev S, FrameDev F, 
   const int D = (int)F.p.maxDepth;
   const int eyeLast = P.eyeLast[p], lightLast = P.lightLast[p];
   const f3 camPos = ld3(F.cam.posW);
-  uint32_t nNodes = 0, nTris = 0, nRays = 0;
   bool sat = false;
   for (int totalLength = 2; totalLength <= D; totalLength++) {
     for (int cameraLength = 1; cameraLength <= D - 1; cameraLength++) {
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(kWave) void connect_kernel(SceneDev S, FrameDev F, 
       if (allZero(shade) && sat) continue;
       const float lengthAB = length(le.pos - ce.pos);
       const f3 dirAB = (le.pos - ce.pos) / lengthAB;
-      Hit h = traverse<2, COUNT>(S, ce.pos, dirAB, F.p.minT, lengthAB, s_stack + threadIdx.x, nNodes, nTris);
+      Hit h = traverse<2, COUNT>(S, ce.pos, dirAB, F.p.minT, lengthAB, stk, nNodes, nTris);
       nRays++;
       if (h.prim < 0) {
         acc.x = saturate(acc.x + shade.x);
@@ -860,10 +870,19 @@ __global__ __launch_bounds__(kWave) void connect_kernel(SceneDev S, FrameDev F, 
     }
   }
   out4[pix] = acc;
+}
+template <bool GGX, bool COUNT>
+__global__ __launch_bounds__(kWave) void connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  __shared__ int s_stack[kStackEntries * kWave];
+  const uint32_t n = P.qcount[0];
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;
+  if (i < n) connectLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nRays, nNodes, nTris);
+  waveAddCount(F.counters, C_RAYS_CONNECT, nRays);
   if (COUNT) {
-    addCount(F.counters, C_RAYS_CONNECT, nRays);
-    addCount(F.counters, C_NODE_SHADOW, nNodes);
-    addCount(F.counters, C_TRI_SHADOW, nTris);
+    waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
+    waveAddCount(F.counters, C_TRI_SHADOW, nTris);
   }
 }
 
@@ -984,7 +1003,7 @@ void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hip
 
 #define BDPT_DISPATCH(KERNEL, GRID, ...)                                                         \
   do {                                                                                           \
-    const bool ggx_ = (F.p.matIndex == 0), cnt_ = (F.counters != nullptr);                       \
+    const bool ggx_ = (F.p.matIndex == 0), cnt_ = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;                       \
     if (ggx_ && cnt_)                                                                            \
       hipLaunchKernelGGL((KERNEL<true, true>), dim3(GRID), dim3(kWave), 0, st, __VA_ARGS__);     \
     else if (ggx_)                                                                               \

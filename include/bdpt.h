@@ -22,7 +22,8 @@
  *                                   SimpleDiffuseGIRayGen (BidirectionalPathtracing/Passes/BDPTPass.cpp:70-107,
  *                                   SharedUtils/RayLaunch.cpp:200-223,
  *                                   BidirectionalPathtracing/Data/BDPTMain.rt.hlsl:42-234)
- *   bdpt_splat_buffer / bdpt_resolve  the cross-pixel gOutput[id] read-modify-write of the
+ *   bdpt_splat_buffer / bdpt_set_splat_buffer / bdpt_resolve
+ *                                   the cross-pixel gOutput[id] read-modify-write of the
  *                                   light-tracing loop (BDPTMain.rt.hlsl:186-204), made
  *                                   deterministic: fixed-point atomics into a separate buffer,
  *                                   one final saturate
@@ -165,7 +166,7 @@ typedef struct bdpt_params {
   uint32_t flags;        /* BDPT_PARAM_* */
 } bdpt_params;
 
-#define BDPT_PARAM_COUNTERS 1u      /* tally rays / node / triangle visits (slower; not for timing) */
+#define BDPT_PARAM_COUNTERS 1u      /* also tally node / triangle visits (slower; not for timing).  Ray tallies are always on. */
 #define BDPT_PARAM_DEFER_RESOLVE 2u /* leave splats in the splat buffer; caller runs bdpt_resolve */
 #define BDPT_PARAM_NO_NEE 4u        /* partial images for stage-wise parity (SURVEY §8c iv) */
 #define BDPT_PARAM_NO_SPLAT 8u
@@ -268,6 +269,10 @@ int bdpt_execute(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, fl
  * order-independent) before bdpt_resolve. */
 int bdpt_splat_buffer(bdpt_ctx* ctx, uint64_t** out_device_ptr, uint64_t* out_num_u64);
 
+/* Make the pass accumulate splats into caller-owned device memory (e.g. a tensor that a
+ * collective library can reduce in place); NULL restores the context's own buffer. */
+int bdpt_set_splat_buffer(bdpt_ctx* ctx, uint64_t* device_ptr, uint64_t num_u64);
+
 /* out[tile rows] = saturate(out + splat) where the splat count is non-zero.
  * `splat` may be the context's own buffer or a reduced copy holding at least the
  * tile rows at the same full-frame indexing (splat_row0 = first row it holds). */
@@ -278,8 +283,8 @@ int bdpt_resolve(bdpt_ctx* ctx, const uint64_t* splat, uint32_t splat_row0, floa
 int bdpt_accumulate(bdpt_ctx* ctx, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount,
                     uint64_t numTexels, void* stream);
 
-/* Counters of the most recent bdpt_gbuffer_execute + bdpt_execute pair run with
- * BDPT_PARAM_COUNTERS.  Synchronises the stream it was launched on. */
+/* Counters of the most recent bdpt_execute (ray tallies always; node/triangle visits when it ran
+ * with BDPT_PARAM_COUNTERS).  Synchronises the stream it was launched on. */
 int bdpt_get_counters(bdpt_ctx* ctx, bdpt_counters* out);
 
 /* Per-stage device time (ms) of the most recent bdpt_execute, measured with

@@ -164,12 +164,13 @@ def main():
         n_closest = max(1, stat["raysEyeExtend"] + stat["raysLightExtend"])
         n_int_c = stat["nodeVisitsClosest"] / n_closest
         n_tri_c = stat["triTestsClosest"] / n_closest
-        # defined connection pairs per valid pixel (cameraLength <= totalLength): sum_{t=2..D} min(t, D-1)
-        pairs_per_pixel = sum(min(tl, D - 1) for tl in range(2, D + 1))
-        conn_rays_per_launch = per_stage_rays.get("raysConnect", 0) / K
-        conn_bytes = conn_rays_per_launch * (36 + info.nodeBytes * n_int_s + info.triBytes * n_tri_s) + \
-            200.0 * pairs_per_pixel * stat["pixelsValid"]
-        conn_ms = stage_ms.get("connect", 0.0) / K
+        # dominant kernel: the persistent any-hit trace kernel (NEE + splat + connection rays).
+        # Algorithmic bytes per ray: 32 (ray) + nodeBytes*n_int + triBytes*n_tri + 4 (visibility)
+        shadow_rays_per_launch = (per_stage_rays.get("raysNee", 0) + per_stage_rays.get("raysSplat", 0) +
+                                  per_stage_rays.get("raysConnect", 0)) / K
+        bytes_per_ray = 36 + info.nodeBytes * n_int_s + info.triBytes * n_tri_s
+        conn_bytes = shadow_rays_per_launch * bytes_per_ray
+        conn_ms = stage_ms.get("trace_shadow", 0.0) / K
         achieved = conn_bytes / (conn_ms * 1e-3) / 1e9 if conn_ms > 0 else 0.0
         dominant = max(stage_ms.items(), key=lambda kv: kv[1])[0] if stage_ms else "connect"
         out = {
@@ -199,15 +200,16 @@ def main():
                                    "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
                 "stage_ms_per_step": {k: round(v / K, 3) for k, v in stage_ms.items()},
                 "stage_mrays": {k: round(per_stage_rays.get(r, 0) / (stage_ms[k] * 1e-3) / 1e6, 1)
-                                for k, r in (("eye_extend", "raysEyeExtend"), ("light_extend", "raysLightExtend"),
-                                             ("nee", "raysNee"), ("splat", "raysSplat"), ("connect", "raysConnect"))
+                                for k, r in (("eye_extend", "raysEyeExtend"), ("light_extend", "raysLightExtend"))
                                 if stage_ms.get(k, 0) > 0},
+                "trace_shadow_mrays": round(shadow_rays_per_launch / (conn_ms * 1e-3) / 1e6, 1) if conn_ms > 0 else None,
                 "dominant_stage": dominant,
             },
             "roofline": {
-                "kernel": "connect_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "kernel": "trace_kernel<2> (any-hit, NEE+splat+connection rays)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_launch": int(conn_bytes), "ms_per_launch": round(conn_ms, 3),
+                "bytes_per_ray": round(bytes_per_ray, 1), "rays_per_launch": int(shadow_rays_per_launch),
             },
         }
         if not args.no_cpu_baseline:

@@ -78,7 +78,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect",
         "nodeVisitsClosest", "triTestsClosest", "nodeVisitsShadow", "triTestsShadow", "pixelsValid",
-        "splatsLanded")]
+        "splatsLanded", "raysConnectLazy")]
 
     def total_rays(self):
         return (self.raysPrimary + self.raysEyeExtend + self.raysLightExtend + self.raysNee + self.raysSplat +

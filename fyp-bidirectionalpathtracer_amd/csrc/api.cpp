@@ -18,10 +18,13 @@ using namespace bdpt;
 
 namespace {
 constexpr int kMaxStages = 64;
+// path-queue counters, their fetch cursors, then the shadow sub-queue counters and cursors
+constexpr size_t kCursorWords = 4 * BDPT_MAX_DEPTH + 8 + 2 * kNumSubQueues;
 }
 
 struct bdpt_ctx {
   int device = 0;
+  int numCUs = 256;
   std::string err;
   // scene
   bool haveScene = false, haveCamera = false, haveSize = false;
@@ -107,6 +110,9 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
   if (hipSetDevice(device_ordinal) != hipSuccess) return BDPT_E_HIP;
   bdpt_ctx* c = new bdpt_ctx();
   c->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+    c->numCUs = prop.multiProcessorCount;
   *out_ctx = c;
   return BDPT_OK;
 }
@@ -302,7 +308,34 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightReal, np))) return rc;
   for (int q = 0; q < 3; q++)
     if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], np))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)2 * BDPT_MAX_DEPTH + 8))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)kCursorWords))) return rc;
+  P.qhead = P.qcount + 2 * BDPT_MAX_DEPTH + 4;
+  P.rayCount = P.qcount + 4 * BDPT_MAX_DEPTH + 8;
+  P.rayHead = P.rayCount + kNumSubQueues;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrim, np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitV, np))) return rc;
+  {
+    // one shadow ray per NEE term, per splat term and per defined connection pair, at most
+    const uint32_t D = std::max<uint32_t>(maxDepth, 1);
+    const uint64_t slots = (uint64_t)2 * D + numConnectPairs(D);
+    // workgroup b appends to sub-queue b % kNumSubQueues: size each for the workgroups it serves
+    const uint64_t blocks = (np + kWave - 1) / kWave;
+    const uint64_t subCap = ((blocks + kNumSubQueues - 1) / kNumSubQueues) * kWave * slots;
+    const uint64_t cap = subCap * kNumSubQueues;
+    P.raySubCap = (uint32_t)subCap;
+    if (cap >= (1ull << 32) - 1) {
+      fail(c, "resize: shadow-ray queue would exceed 2^32 entries; render in smaller tiles");
+      return BDPT_E_LIMIT;
+    }
+    P.rayCap = (uint32_t)cap;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.rayQ, (size_t)7 * cap))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.rayContrib, (size_t)3 * cap))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.rayVis, (size_t)cap))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.slotRay, (size_t)slots * np))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.splatPix, (size_t)D * np))) return rc;
+  }
   if ((rc = devAlloc(c, c->frameAllocs, &c->ownSplat, (size_t)width * height * 4))) return rc;
   c->splat = c->ownSplat;
   if ((rc = devAlloc(c, c->frameAllocs, &c->counters, 1))) return rc;
@@ -379,7 +412,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
 
   c->numStages = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
-  HIPCHK(c, hipMemsetAsync(P.qcount, 0, ((size_t)2 * BDPT_MAX_DEPTH + 8) * sizeof(uint32_t), st));
+  HIPCHK(c, hipMemsetAsync(P.qcount, 0, (size_t)kCursorWords * sizeof(uint32_t), st));
   HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->W * c->H * 4 * sizeof(unsigned long long), st));
   HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
   stageMark(c, st, "clear");
@@ -394,7 +427,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     const uint32_t* cin = &P.qcount[0];
     int ping = 1;
     for (int k = 1; k <= D - 1; k++) {
-      launchExtend(c->S, F, P, PATH_EYE, k, D, qin, cin, P.queue[ping], &P.qcount[qc], st);
+      launchExtend(c->S, F, P, PATH_EYE, k, D, qin, cin, &P.qhead[qc], P.queue[ping], &P.qcount[qc], c->numCUs, st);
       qin = P.queue[ping];
       cin = &P.qcount[qc];
       qc++;
@@ -408,7 +441,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     const uint32_t* cin = &P.qcount[0];
     int ping = 1;
     for (int k = 0; k <= D - 1; k++) {
-      launchExtend(c->S, F, P, PATH_LIGHT, k, D, qin, cin, P.queue[ping], &P.qcount[qc], st);
+      launchExtend(c->S, F, P, PATH_LIGHT, k, D, qin, cin, &P.qhead[qc], P.queue[ping], &P.qcount[qc], c->numCUs, st);
       qin = P.queue[ping];
       cin = &P.qcount[qc];
       qc++;
@@ -416,16 +449,12 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     }
     stageMark(c, st, "light_extend");
   }
-  launchNee(c->S, F, P, st);
-  stageMark(c, st, "nee");
-  if (!(p->flags & BDPT_PARAM_NO_SPLAT)) {
-    launchSplat(c->S, F, P, st);
-    stageMark(c, st, "splat");
-  }
-  if (!(p->flags & BDPT_PARAM_NO_CONNECT)) {
-    launchConnect(c->S, F, P, st);
-    stageMark(c, st, "connect");
-  }
+  launchGenShadow(c->S, F, P, st);
+  stageMark(c, st, "gen_shadow");
+  launchTraceShadow(c->S, F, P, c->numCUs, st);
+  stageMark(c, st, "trace_shadow");
+  launchGather(c->S, F, P, st);
+  stageMark(c, st, "gather");
   if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
     launchResolve(c->splat, 0, out, c->W, c->tile.y0, c->tile.y1, st);
     stageMark(c, st, "resolve");
@@ -483,10 +512,14 @@ int bdpt_get_counters(bdpt_ctx* c, bdpt_counters* out) {
   if (!c || !out) return BDPT_E_INVALID;
   if (!c->haveSize) return BDPT_E_STATE;
   HIPCHK(c, hipStreamSynchronize(c->lastStream));
-  DevCounters h;
+  static DevCounters h;
   HIPCHK(c, hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-  static_assert(sizeof(DevCounters) == sizeof(bdpt_counters), "counter layouts must match");
-  std::memcpy(out, &h, sizeof(h));
+  static_assert(sizeof(bdpt_counters) == 13 * sizeof(uint64_t), "counter fields");
+  uint64_t* o = reinterpret_cast<uint64_t*>(out);
+  for (int f = 0; f < 13; f++) {
+    o[f] = 0;
+    for (uint32_t sh = 0; sh < kCounterShards; sh++) o[f] += h.v[sh][f];
+  }
   out->raysPrimary = (uint64_t)c->P.Np;  // GBufferRayGen traces exactly one ray per tile pixel
   return BDPT_OK;
 }

@@ -1,0 +1,279 @@
+// device_trace.hpp — BVH traversal for gfx950: per-lane LDS stack, while-while loop structure,
+// and the persistent trace kernel whose idle lanes are refilled from a ray queue.
+//
+// Replaces DXR TraceRay (BDPT/globalIlluminationRay.hlsli:11, BDPT/standardShadowRay.hlsli:20-22,
+// CP lightProbeGBuffer.rt.hlsl:151-158) — fixed-function in the reference's driver.
+// MODE 0 closest hit, 1 closest hit with back-face culling (RAY_FLAG_CULL_BACK_FACING_TRIANGLES),
+// 2 any hit (ACCEPT_FIRST_HIT_AND_END_SEARCH | SKIP_CLOSEST_HIT_SHADER).
+// Hit iff tmin < t < tmax; closest-hit ties resolve to the lowest primitive index so the result
+// does not depend on traversal order (and equals a brute-force scan).
+#pragma once
+#include "device_scene.hpp"
+
+namespace bdpt {
+#define BD __device__ __forceinline__
+
+struct Hit {
+  int prim;
+  float t, u, v;
+};
+
+constexpr int kDone = (int)0x80000000;  // traversal cursor value: stack exhausted
+
+struct TravState {
+  f3 o, d, idir;
+  float tmin, tmax;
+  int cur, sp;
+  Hit best;
+};
+
+BD void travInit(TravState& T, f3 o, f3 d, float tmin, float tmax) {
+  T.o = o;
+  T.d = d;
+  T.idir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  T.tmin = tmin;
+  T.tmax = tmax;
+  T.cur = 0;
+  T.sp = 0;
+  T.best.prim = -1;
+  T.best.t = tmax;
+  T.best.u = 0.0f;
+  T.best.v = 0.0f;
+}
+
+BD int travPop(TravState& T, const int* stk) {
+  if (T.sp == 0) return kDone;
+  T.sp--;
+  return stk[T.sp * kWave];
+}
+
+// One interior-node visit: test both children, descend into the nearer, push the farther.
+BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
+  const float4* np = S.nodes + (size_t)T.cur * 4;
+  const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+  const int4 q3 = reinterpret_cast<const int4*>(np)[3];
+  const f3 o = T.o, idir = T.idir;
+  float ax0 = (q0.x - o.x) * idir.x, ax1 = (q0.w - o.x) * idir.x;
+  float ay0 = (q0.y - o.y) * idir.y, ay1 = (q1.x - o.y) * idir.y;
+  float az0 = (q0.z - o.z) * idir.z, az1 = (q1.y - o.z) * idir.z;
+  float tn0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), T.tmin));
+  float tf0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), T.best.t));
+  float bx0 = (q1.z - o.x) * idir.x, bx1 = (q2.y - o.x) * idir.x;
+  float by0 = (q1.w - o.y) * idir.y, by1 = (q2.z - o.y) * idir.y;
+  float bz0 = (q2.x - o.z) * idir.z, bz1 = (q2.w - o.z) * idir.z;
+  float tn1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), T.tmin));
+  float tf1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), T.best.t));
+  const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+  if (h0 && h1) {
+    const bool swap = tn1 < tn0;
+    stk[T.sp * kWave] = swap ? q3.x : q3.y;
+    T.sp++;
+    T.cur = swap ? q3.y : q3.x;
+  } else if (h0) {
+    T.cur = q3.x;
+  } else if (h1) {
+    T.cur = q3.y;
+  } else {
+    T.cur = travPop(T, stk);
+  }
+}
+
+// All triangles of the leaf in T.cur; returns true when an any-hit query is finished.
+template <int MODE, bool COUNT>
+BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
+  const uint32_t enc = (uint32_t)(-1 - T.cur);
+  const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+  for (uint32_t k = 0; k < cnt; k++) {
+    const float4* tp = S.tris + (size_t)(first + k) * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    if (COUNT) nTris++;
+    const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
+    const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
+    const f3 pvec = cross(T.d, e2);
+    const float det = dot(e1, pvec);
+    if (MODE == 1 && !(flags & 2u)) {
+      if (!(det > 0.0f)) continue;
+    } else {
+      if (det == 0.0f) continue;
+    }
+    const float inv = 1.0f / det;
+    const f3 tvec = T.o - v0;
+    const float u = dot(tvec, pvec) * inv;
+    if (u < 0.0f || u > 1.0f) continue;
+    const f3 qvec = cross(tvec, e1);
+    const float v = dot(T.d, qvec) * inv;
+    if (v < 0.0f || u + v > 1.0f) continue;
+    const float t = dot(e2, qvec) * inv;
+    if (!((t > T.tmin) && (t < T.tmax))) continue;
+    if ((flags & 1u) && alphaTestFails(S, prim, u, v)) continue;  // any-hit shader: IgnoreHit()
+    if (MODE == 2) {
+      T.best.prim = 0;
+      T.best.t = t;
+      return true;
+    }
+    if (t < T.best.t || (t == T.best.t && T.best.prim >= 0 && (int)prim < T.best.prim)) {
+      T.best.prim = (int)prim;
+      T.best.t = t;
+      T.best.u = u;
+      T.best.v = v;
+    }
+  }
+  return false;
+}
+
+// Whole query by one lane (coherent primary rays, test hooks, the few lazy rays of the gather stage).
+template <int MODE, bool COUNT>
+BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk, uint32_t& nNodes, uint32_t& nTris) {
+  TravState T;
+  travInit(T, o, d, tmin, tmax);
+  while (T.cur != kDone) {
+    while (T.cur >= 0) {
+      if (COUNT) nNodes++;
+      nodeStep(S, T, stk);
+    }
+    if (T.cur == kDone) break;
+    if (leafStep<MODE, COUNT>(S, T, nTris)) break;
+    T.cur = travPop(T, stk);
+  }
+  return T.best;
+}
+
+BD void addCount(DevCounters* c, int idx, uint32_t n) {
+  if (n) atomicAdd(&c->v[blockIdx.x % kCounterShards][idx], (unsigned long long)n);
+}
+// Sum over the wave (every lane must call it), one atomic per wave into the workgroup's shard.
+BD void waveAddCount(DevCounters* c, int idx, uint32_t n) {
+  uint32_t v = n;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&c->v[blockIdx.x % kCounterShards][idx], (unsigned long long)v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent trace kernel.  Each wave owns 64 traversal slots; whenever kRefillIdle or more lanes
+// have retired their ray the wave takes that many new rays from the queue with ONE atomic
+// (ballot + popcount prefix), so lanes do not idle behind the longest ray of a static batch.
+// Inside, the loop is while-while: all lanes descend interior nodes together, then all lanes
+// that reached a leaf intersect triangles together.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRefillIdle = 16;
+
+struct RayQueue {         // SoA planes, stride = cap: ox oy oz dx dy dz tmax
+  const float* rays;
+  uint32_t cap;           // plane stride
+  uint32_t subCap;        // capacity of one sub-queue (ray id = q*subCap + offset)
+  uint32_t numSub;        // number of sub-queues (1 for the closest-hit path queues)
+  const uint32_t* count;  // [numSub] queued rays (device counters written by the producer)
+  uint32_t* head;         // [numSub] next unfetched offset
+};
+
+struct ShadowOut {
+  uint8_t* vis;  // 1 = unoccluded, by ray id
+};
+struct ClosestOut {  // by ray id
+  int* prim;
+  float* t;
+  float* u;
+  float* v;
+};
+// Closest-hit rays are read through an indirection: ray id i -> path p = qin[i]; origin = vertex
+// plane, direction = rayDir plane.
+struct ClosestIn {
+  const uint32_t* qin;
+  const float* pos;  // 3 planes, stride Np
+  const float* dir;  // 3 planes, stride Np
+  uint32_t Np;
+  float tmin;
+};
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, ClosestIn CI, ShadowOut SO, ClosestOut CO,
+                                                      DevCounters* counters, float shadowTmin) {
+  __shared__ int s_stack[kStackEntries * kWave];
+  int* stk = s_stack + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63u);
+  bool has = false, exhausted = false;
+  uint32_t rid = 0;
+  TravState T;
+  T.cur = kDone;
+  uint32_t nNodes = 0, nTris = 0;
+  // wave-uniform fetch state: current sub-queue and the chunk [chunkPos, chunkEnd) taken from it
+  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0;
+  for (;;) {
+    const unsigned long long idleMask = __ballot(!has);
+    const int idle = __popcll(idleMask);
+    if (!exhausted && idle >= kRefillIdle) {
+      while (chunkPos >= chunkEnd && !exhausted) {  // wave-uniform loop: take a new chunk
+        const uint32_t nq = Q.count[q];
+        uint32_t base = nq;
+        if (__hip_atomic_load(&Q.head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
+          if (lane == 0) base = atomicAdd(&Q.head[q], kFetchChunk);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        }
+        if (base < nq) {
+          chunkPos = base;
+          chunkEnd = (base + kFetchChunk < nq) ? base + kFetchChunk : nq;
+          tried = 0;
+        } else {
+          q = (q + 1 == Q.numSub) ? 0u : q + 1;
+          if (++tried >= Q.numSub) exhausted = true;
+        }
+      }
+      if (!exhausted) {
+        const uint32_t avail = chunkEnd - chunkPos;
+        const uint32_t take = ((uint32_t)idle < avail) ? (uint32_t)idle : avail;
+        const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+        if (!has && rank < take) {
+          const uint32_t idx = q * Q.subCap + chunkPos + rank;
+          rid = idx;
+          if (MODE == 2) {
+            const float* r = Q.rays + idx;
+            const size_t c = Q.cap;
+            travInit(T, mk(r[0], r[c], r[2 * c]), mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
+          } else {
+            const uint32_t p = CI.qin[idx];
+            const size_t np = CI.Np;
+            travInit(T, mk(CI.pos[p], CI.pos[np + p], CI.pos[2 * np + p]), mk(CI.dir[p], CI.dir[np + p], CI.dir[2 * np + p]),
+                     CI.tmin, 1.0e38f);
+          }
+          has = true;
+        }
+        chunkPos += take;
+      }
+    }
+    if (__ballot(has) == 0ull) break;  // exhausted and every lane retired
+    if (has) {
+      while (T.cur >= 0) {
+        if (COUNT) nNodes++;
+        nodeStep(S, T, stk);
+      }
+      bool finished = (T.cur == kDone);
+      if (!finished) {
+        finished = leafStep<MODE, COUNT>(S, T, nTris);
+        if (!finished) {
+          T.cur = travPop(T, stk);
+          finished = (T.cur == kDone);
+        }
+      }
+      if (finished) {
+        if (MODE == 2) {
+          SO.vis[rid] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
+        } else {
+          CO.prim[rid] = T.best.prim;
+          CO.t[rid] = T.best.t;
+          CO.u[rid] = T.best.u;
+          CO.v[rid] = T.best.v;
+        }
+        has = false;
+        T.cur = kDone;
+      }
+    }
+  }
+  if (COUNT) {
+    waveAddCount(counters, MODE == 2 ? C_NODE_SHADOW : C_NODE_CLOSEST, nNodes);
+    waveAddCount(counters, MODE == 2 ? C_TRI_SHADOW : C_TRI_CLOSEST, nTris);
+  }
+}
+
+#undef BD
+}  // namespace bdpt

@@ -7,9 +7,16 @@
 
 namespace bdpt {
 
-constexpr int kWave = 64;         // gfx950 wavefront
-constexpr int kStackEntries = 32; // per-lane traversal stack in LDS (kBvhMaxDepth = 30)
-constexpr int kShadeRecF4 = 7;    // float4s per triangle shading record (112 B)
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kStackEntries = 32;  // per-lane traversal stack in LDS (kBvhMaxDepth = 30)
+constexpr int kShadeRecF4 = 7;     // float4s per triangle shading record (112 B)
+constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+// Hot single-word atomics top out near 90 M/s on this chip (MI355X_MICROARCH.md "dequeue"), so
+// producer and consumer cursors of the shadow-ray queue are sharded over sub-queues, consumers
+// take kFetchChunk rays per atomic, and the statistics counters are sharded per workgroup.
+constexpr uint32_t kNumSubQueues = 32;
+constexpr uint32_t kFetchChunk = 256;
+constexpr uint32_t kCounterShards = 64;
 
 // Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45, minus pdfForward which only
 // the never-called MIS code reads).
@@ -27,11 +34,11 @@ struct SceneConst {
 };
 
 struct SceneDev {
-  const float4* nodes;     // 4 per node
-  const float4* tris;      // 3 per leaf triangle, leaf order
-  const float4* shade;     // kShadeRecF4 per primitive, primitive order
-  const float* bitangents; // 3 per vertex (normal-mapped primary hits only)
-  const uint32_t* indices; // 3 per primitive
+  const float4* nodes;      // 4 per node
+  const float4* tris;       // 3 per leaf triangle, leaf order
+  const float4* shade;      // kShadeRecF4 per primitive, primitive order
+  const float* bitangents;  // 3 per vertex (normal-mapped primary hits only)
+  const uint32_t* indices;  // 3 per primitive
   const bdpt_material* materials;
   const TexDev* textures;
   const SceneConst* sc;
@@ -39,17 +46,25 @@ struct SceneDev {
   uint32_t hasBitangents;
 };
 
-struct DevCounters {  // mirrors bdpt_counters field order
-  unsigned long long v[12];
+struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; one 128-byte line per shard
+  unsigned long long v[kCounterShards][16];
 };
 enum : int {
   C_RAYS_PRIMARY = 0, C_RAYS_EYE, C_RAYS_LIGHT, C_RAYS_NEE, C_RAYS_SPLAT, C_RAYS_CONNECT,
-  C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS
+  C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS, C_RAYS_LAZY
 };
+
+// Number of connection pairs the reference defines for depth D (cameraLength <= totalLength,
+// BDPTMain.rt.hlsl:212-216): sum_{t=2..D} min(t, D-1).
+inline __host__ __device__ uint32_t numConnectPairs(uint32_t D) {
+  uint32_t n = 0;
+  for (uint32_t t = 2; t <= D; t++) n += (t < D - 1) ? t : (D - 1);
+  return n;
+}
 
 // Per-tile path state, SoA by tile-local pixel index p in [0, Np).
 struct PathBuf {
-  float* v;            // planes: ((path*(D1) + k)*NF + field)*Np + p
+  float* v;            // vertex planes: ((path*D1 + k)*NF + field)*Np + p
   float* rayDir;       // planes: (path*3 + axis)*Np + p
   uint32_t* seedL;     // RNG state after sampleLight
   uint8_t* eyeLast;    // last stored eye vertex (ghost included); 0 = pixel has no geometry
@@ -57,6 +72,22 @@ struct PathBuf {
   uint8_t* lightReal;  // number of light vertices produced by hits (takeContribution, BDPTMain.rt.hlsl:144)
   uint32_t* queue[3];  // [0] valid pixels; [1],[2] ping-pong extension queues
   uint32_t* qcount;    // [0] valid count, [1..] one counter per extension step
+  uint32_t* qhead;     // fetch cursors of the persistent trace kernel, one per launch
+  // closest-hit records by queue position
+  int* hitPrim;
+  float* hitT;
+  float* hitU;
+  float* hitV;
+  // shadow-ray queue (NEE + splat + connection rays of one frame)
+  float* rayQ;           // 7 planes, stride rayCap
+  float* rayContrib;     // 3 planes, stride rayCap: the clamped contribution the ray gates
+  uint8_t* rayVis;       // visibility by ray id
+  uint32_t* rayCount;    // [kNumSubQueues] rays queued per sub-queue
+  uint32_t* rayHead;     // [kNumSubQueues] fetch cursors
+  uint32_t raySubCap;    // capacity of one sub-queue; ray id = subQueue*raySubCap + offset
+  uint32_t* slotRay;     // planes: slot*Np + p -> ray id or kNoRay.  slots: [0,D) NEE, [D,2D) splat, [2D,..) pairs
+  uint32_t* splatPix;    // planes: t*Np + p -> full-frame pixel index of splat t
+  uint32_t rayCap;
   uint32_t Np, D1;
 };
 
@@ -64,10 +95,10 @@ struct FrameDev {
   bdpt_camera cam;
   bdpt_params p;
   uint32_t W, H, y0, y1;
-  float* out;          // full-frame RGBA32F
+  float* out;                 // full-frame RGBA32F
   unsigned long long* splat;  // full-frame 4 x u64
   bdpt_gbuffer gb;
-  DevCounters* counters;  // null unless BDPT_PARAM_COUNTERS
+  DevCounters* counters;
 };
 
 struct GBufferDev {
@@ -81,11 +112,12 @@ struct GBufferDev {
 // launchers (kernels.hip)
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+// one bounce = persistent closest-hit trace over qin + dense shade/compact into qout
 void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
-                  const uint32_t* countIn, uint32_t* qout, uint32_t* countOut, hipStream_t st);
-void launchNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
-void launchSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
-void launchConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+                  const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st);
+void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st);
+void launchGather(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
                    hipStream_t st);
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);

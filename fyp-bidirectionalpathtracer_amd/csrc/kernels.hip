@@ -1,26 +1,30 @@
 // kernels.hip — the wavefront BDPT pipeline for gfx950 (CDNA4, wave64).
 //
-// Stage kernels (one launch each per frame, per bounce for the two walks):
-//   gbuffer_kernel    primary visibility            CP lightProbeGBuffer.rt.hlsl:63-159
-//   init_paths_kernel eye vertex 1 + light vertex 0 BDPTMain.rt.hlsl:51-103, 124-135
-//   extend_kernel     one bounce of a sub-path      globalIlluminationRay.hlsli:1-45 (closest hit + shade)
-//   nee_kernel        next-event estimation         BDPTMain.rt.hlsl:155-167
-//   splat_kernel      light tracing to the camera   BDPTMain.rt.hlsl:171-208
-//   connect_kernel    s x t vertex connections      BDPTMain.rt.hlsl:212-233
-//   resolve_kernel    fold the splat buffer in      (build definition)
-//   accumulate_kernel running mean                  CP accumulate.ps.hlsl:28-42
+// Per frame (all on one HIP stream, no host synchronisation in between):
+//   gbuffer_kernel      primary visibility                      CP lightProbeGBuffer.rt.hlsl:63-159
+//   init_paths_kernel   eye vertex 1 + light vertex 0           BDPTMain.rt.hlsl:51-103, 124-135
+//   per bounce of each sub-path:
+//     trace_kernel<0>   persistent closest-hit traversal        globalIlluminationRay.hlsli:1-12 (TraceRay)
+//     shade_kernel      hit/miss shading + queue compaction     globalIlluminationRay.hlsli:14-45
+//   gen_shadow_kernel   NEE / splat / connection terms -> rays  BDPTMain.rt.hlsl:161-233
+//   trace_kernel<2>     persistent any-hit traversal            standardShadowRay.hlsli:7-49
+//   gather_kernel       ordered sums, splat atomics             BDPTMain.rt.hlsl:166, 199, 230
+//   resolve_kernel      fold the splat buffer in                (build definition)
+//   accumulate_kernel   running mean                            CP accumulate.ps.hlsl:28-42
 //
-// Layout: path vertices are SoA planes indexed by tile-local pixel, so a wave reads 64
-// consecutive floats per field; live paths are compacted between bounces with
-// __ballot + popcount prefix + one atomic per wave; each lane's BVH traversal stack lives in
-// LDS, interleaved by lane (entry e of lane l at word e*64+l) so pushes and pops never
-// bank-conflict.  One workgroup = one wave (64 threads): no __syncthreads anywhere, and a
-// finished wave frees its slot immediately.
+// Layout: path vertices and rays are SoA planes, so a wave reads 64 consecutive floats per field;
+// live paths and generated rays are compacted with __ballot + popcount prefix + one atomic per
+// wave; all BVH traversal happens in one persistent kernel whose lanes are refilled from the ray
+// queue as they retire (device_trace.hpp), with each lane's stack in LDS interleaved by lane
+// (entry e of lane l at word e*64+l: pushes and pops never bank-conflict).  One workgroup = one
+// wave (64 threads): no __syncthreads anywhere, and a finished wave frees its slot immediately.
 #include "kernels.h"
 
 #include <algorithm>
 
 #include "device_math.hpp"
+#include "device_scene.hpp"
+#include "device_trace.hpp"
 
 namespace bdpt {
 
@@ -39,293 +43,6 @@ BD void wavePush(bool active, uint32_t value, uint32_t* queue, uint32_t* counter
   base = (uint32_t)__shfl((int)base, leader);
   const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
   if (active) queue[base + prefix] = value;
-}
-
-// ------------------------------------------------------------------------------------------------
-// textures, vertex fetch, shading data
-// ------------------------------------------------------------------------------------------------
-struct f4 {
-  float x, y, z, w;
-};
-BD f4 lerp4(f4 a, f4 b, float s) {
-  return f4{a.x + (b.x - a.x) * s, a.y + (b.y - a.y) * s, a.z + (b.z - a.z) * s, a.w + (b.w - a.w) * s};
-}
-BD int wrapi(int i, int n) {
-  int m = i % n;
-  return (m < 0) ? m + n : m;
-}
-BD f4 texel(const SceneDev& S, const TexDev& t, int ix, int iy) {
-  const uchar4 p = *reinterpret_cast<const uchar4*>(t.px + ((size_t)iy * t.w + (size_t)ix) * 4);
-  f4 r;
-  if (t.srgb) {
-    r.x = S.sc->srgbLut[p.x];
-    r.y = S.sc->srgbLut[p.y];
-    r.z = S.sc->srgbLut[p.z];
-  } else {
-    r.x = (float)p.x / 255.0f;
-    r.y = (float)p.y / 255.0f;
-    r.z = (float)p.z / 255.0f;
-  }
-  r.w = (float)p.w / 255.0f;
-  return r;
-}
-// linear filter, wrap addressing, mip 0 (sampler: SharedUtils/SceneLoaderWrapper.cpp:65-68)
-BD f4 sampleBilinear(const SceneDev& S, int texId, float u, float v) {
-  const TexDev t = S.textures[texId];
-  float x = u * (float)t.w - 0.5f;
-  float y = v * (float)t.h - 0.5f;
-  float x0 = floorf(x), y0 = floorf(y);
-  float fx = x - x0, fy = y - y0;
-  int ix0 = wrapi((int)x0, (int)t.w), iy0 = wrapi((int)y0, (int)t.h);
-  int ix1 = wrapi(ix0 + 1, (int)t.w), iy1 = wrapi(iy0 + 1, (int)t.h);
-  f4 t00 = texel(S, t, ix0, iy0), t10 = texel(S, t, ix1, iy0);
-  f4 t01 = texel(S, t, ix0, iy1), t11 = texel(S, t, ix1, iy1);
-  return lerp4(lerp4(t00, t10, fx), lerp4(t01, t11, fx), fy);
-}
-// Falcor ShadingUtils/Shading.slang:88-94
-BD f4 sampleTexture(const SceneDev& S, int texId, float u, float v, f4 factor, uint32_t mode) {
-  if (mode == BDPT_CHANNEL_UNUSED) return f4{0, 0, 0, 0};
-  if (mode == BDPT_CHANNEL_CONST || texId < 0) return factor;
-  return sampleBilinear(S, texId, u, v);
-}
-
-struct MatDev {
-  f4 baseColor, specular;
-  f3 emissive;
-  float alphaThreshold, IoR;
-  uint32_t flags;
-  int texBase, texSpec, texEmis, texNorm;
-};
-BD MatDev loadMaterial(const SceneDev& S, uint32_t id) {
-  const float4* m = reinterpret_cast<const float4*>(S.materials + id);
-  float4 a = m[0], b = m[1], c = m[2], d = m[3];
-  MatDev r;
-  r.baseColor = f4{a.x, a.y, a.z, a.w};
-  r.specular = f4{b.x, b.y, b.z, b.w};
-  r.emissive = mk(c.x, c.y, c.z);
-  r.alphaThreshold = c.w;
-  r.IoR = d.x;
-  r.flags = __float_as_uint(d.y);
-  uint32_t t0 = __float_as_uint(d.z), t1 = __float_as_uint(d.w);
-  r.texBase = (int)(int16_t)(t0 & 0xffffu);
-  r.texSpec = (int)(int16_t)(t0 >> 16);
-  r.texEmis = (int)(int16_t)(t1 & 0xffffu);
-  r.texNorm = (int)(int16_t)(t1 >> 16);
-  return r;
-}
-
-// BDPT/BDPTUtils.hlsli:115-127
-BD bool alphaTestFails(const SceneDev& S, uint32_t prim, float bu, float bv) {
-  const float4* r = S.shade + (size_t)prim * kShadeRecF4;
-  const MatDev m = loadMaterial(S, __float_as_uint(r[6].x));
-  float u = 0, v = 0;
-  const uint32_t mode = BDPT_FLAG_DIFFUSE_TYPE(m.flags);
-  if (mode == BDPT_CHANNEL_TEXTURE && m.texBase >= 0) {
-    float b0 = 1.0f - bu - bv;
-    float4 r1 = r[1], r3 = r[3], r5 = r[5];
-    u += r1.z * b0;
-    v += r1.w * b0;
-    u += r3.z * bu;
-    v += r3.w * bu;
-    u += r5.z * bv;
-    v += r5.w * bv;
-  }
-  f4 base = sampleTexture(S, m.texBase, u, v, m.baseColor, mode);
-  return base.w < m.alphaThreshold;
-}
-
-struct Shading {
-  f3 posW, V, N, diffuse, specular, emissive;
-  float opacity, linearRoughness, roughness, IoR;
-};
-// getVertexAttributes (Falcor ShadingUtils/Raytracing.slang:60-106) + simplePrepareShadingData
-// (BDPT/BDPTUtils.hlsli:2-52); NMAP adds applyNormalMap for the primary hit
-// (Falcor ShadingUtils/Shading.slang:135-157, 189-259).
-template <bool NMAP>
-BD Shading shadeHit(const SceneDev& S, uint32_t prim, float bu, float bv, f3 camPosW) {
-  const float4* r = S.shade + (size_t)prim * kShadeRecF4;
-  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
-  const float b0 = 1.0f - bu - bv;
-  float u = 0, v = 0;
-  f3 normalW = mk(0), posW = mk(0);
-  u += r1.z * b0;
-  v += r1.w * b0;
-  normalW = normalW + mk(r0.w, r1.x, r1.y) * b0;
-  posW = posW + mk(r0.x, r0.y, r0.z) * b0;
-  u += r3.z * bu;
-  v += r3.w * bu;
-  normalW = normalW + mk(r2.w, r3.x, r3.y) * bu;
-  posW = posW + mk(r2.x, r2.y, r2.z) * bu;
-  u += r5.z * bv;
-  v += r5.w * bv;
-  normalW = normalW + mk(r4.w, r5.x, r5.y) * bv;
-  posW = posW + mk(r4.x, r4.y, r4.z) * bv;
-  normalW = normalize(normalW);
-
-  const MatDev m = loadMaterial(S, __float_as_uint(r6.x));
-  Shading sd;
-  f4 base = sampleTexture(S, m.texBase, u, v, m.baseColor, BDPT_FLAG_DIFFUSE_TYPE(m.flags));
-  sd.opacity = m.baseColor.w;
-  sd.posW = posW;
-  sd.V = normalize(camPosW - posW);
-  sd.N = normalize(normalW);
-  f4 spec = sampleTexture(S, m.texSpec, u, v, m.specular, BDPT_FLAG_SPECULAR_TYPE(m.flags));
-  f3 baseRgb = mk(base.x, base.y, base.z);
-  if (BDPT_FLAG_SHADING_MODEL(m.flags) == BDPT_SHADING_MODEL_METAL_ROUGH) {
-    sd.diffuse = lerp3(baseRgb, mk(0), spec.z);
-    sd.specular = lerp3(mk(0.04f), baseRgb, spec.z);
-    sd.linearRoughness = spec.y;
-  } else {
-    sd.diffuse = baseRgb;
-    sd.specular = mk(spec.x, spec.y, spec.z);
-    sd.linearRoughness = 1.0f - spec.w;
-  }
-  sd.linearRoughness = maxf(0.08f, sd.linearRoughness);
-  sd.roughness = sd.linearRoughness * sd.linearRoughness;
-  f4 em = sampleTexture(S, m.texEmis, u, v, f4{m.emissive.x, m.emissive.y, m.emissive.z, 1.0f}, BDPT_FLAG_EMISSIVE_TYPE(m.flags));
-  sd.emissive = mk(em.x, em.y, em.z);
-  sd.IoR = m.IoR;
-  const bool doubleSided = BDPT_FLAG_DOUBLE_SIDED(m.flags) != 0;
-  if (NMAP) {
-    const uint32_t mapType = BDPT_FLAG_NORMAL_MAP_TYPE(m.flags);
-    if (mapType != BDPT_NORMAL_MAP_UNUSED && m.texNorm >= 0 && S.hasBitangents) {
-      f3 bitW = mk(0);
-      const float bw[3] = {b0, bu, bv};
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        uint32_t vi = S.indices[(size_t)prim * 3 + i];
-        bitW = bitW + ld3(S.bitangents + (size_t)vi * 3) * bw[i];
-      }
-      bitW = normalize(bitW);
-      f3 B = normalize(bitW - sd.N * dot(bitW, sd.N));
-      f3 T = normalize(cross(B, sd.N));
-      f4 mp = sampleBilinear(S, m.texNorm, u, v);
-      f3 mapN;
-      if (mapType == BDPT_NORMAL_MAP_RGB) {
-        mapN = normalize(mk(mp.x, mp.y, mp.z) * 2.0f - mk(1.0f));
-      } else {
-        float nx = mp.x * 2.0f - 1.0f, ny = mp.y * 2.0f - 1.0f;
-        float nz = saturate(mp.x * mp.x + mp.y * mp.y);
-        nz = sqrtf(1.0f - nz);
-        mapN = normalize(mk(nx, ny, nz));
-      }
-      sd.N = T * mapN.x + B * mapN.y + sd.N * mapN.z;
-    }
-  }
-  float NdotV = dot(sd.N, sd.V);
-  if (NdotV <= 0.0f && doubleSided) sd.N = -sd.N;
-  return sd;
-}
-
-// ------------------------------------------------------------------------------------------------
-// BVH traversal.  MODE 0 closest hit, 1 closest hit with back-face culling (primary rays,
-// RAY_FLAG_CULL_BACK_FACING_TRIANGLES), 2 any hit (ACCEPT_FIRST_HIT_AND_END_SEARCH).
-// Hit iff tmin < t < tmax; closest-hit ties resolve to the lowest primitive index so the result
-// does not depend on traversal order (and equals a brute-force scan).
-// ------------------------------------------------------------------------------------------------
-struct Hit {
-  int prim;
-  float t, u, v;
-};
-
-template <int MODE, bool COUNT>
-BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk, uint32_t& nNodes, uint32_t& nTris) {
-  Hit best;
-  best.prim = -1;
-  best.t = tmax;
-  best.u = 0.0f;
-  best.v = 0.0f;
-  const f3 idir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  int sp = 0;
-  int cur = 0;
-  for (;;) {
-    if (cur >= 0) {
-      const float4* np = S.nodes + (size_t)cur * 4;
-      const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-      const int4 q3 = reinterpret_cast<const int4*>(np)[3];
-      if (COUNT) nNodes++;
-      float ax0 = (q0.x - o.x) * idir.x, ax1 = (q0.w - o.x) * idir.x;
-      float ay0 = (q0.y - o.y) * idir.y, ay1 = (q1.x - o.y) * idir.y;
-      float az0 = (q0.z - o.z) * idir.z, az1 = (q1.y - o.z) * idir.z;
-      float tn0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), tmin));
-      float tf0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), best.t));
-      float bx0 = (q1.z - o.x) * idir.x, bx1 = (q2.y - o.x) * idir.x;
-      float by0 = (q1.w - o.y) * idir.y, by1 = (q2.z - o.y) * idir.y;
-      float bz0 = (q2.x - o.z) * idir.z, bz1 = (q2.w - o.z) * idir.z;
-      float tn1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), tmin));
-      float tf1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), best.t));
-      const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-      if (h0 && h1) {
-        const bool swap = tn1 < tn0;
-        const int nearC = swap ? q3.y : q3.x;
-        const int farC = swap ? q3.x : q3.y;
-        stk[sp * kWave] = farC;
-        sp++;
-        cur = nearC;
-      } else if (h0) {
-        cur = q3.x;
-      } else if (h1) {
-        cur = q3.y;
-      } else {
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * kWave];
-      }
-    } else {
-      const uint32_t enc = (uint32_t)(-1 - cur);
-      const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; k++) {
-        const float4* tp = S.tris + (size_t)(first + k) * 3;
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        if (COUNT) nTris++;
-        const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
-        const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
-        const f3 pvec = cross(d, e2);
-        const float det = dot(e1, pvec);
-        if (MODE == 1 && !(flags & 2u)) {
-          if (!(det > 0.0f)) continue;
-        } else {
-          if (det == 0.0f) continue;
-        }
-        const float inv = 1.0f / det;
-        const f3 tvec = o - v0;
-        const float u = dot(tvec, pvec) * inv;
-        if (u < 0.0f || u > 1.0f) continue;
-        const f3 qvec = cross(tvec, e1);
-        const float v = dot(d, qvec) * inv;
-        if (v < 0.0f || u + v > 1.0f) continue;
-        const float t = dot(e2, qvec) * inv;
-        if (!((t > tmin) && (t < tmax))) continue;
-        if ((flags & 1u) && alphaTestFails(S, prim, u, v)) continue;  // any-hit shader: IgnoreHit()
-        if (MODE == 2) {
-          best.prim = 0;
-          best.t = t;
-          return best;
-        }
-        if (t < best.t || (t == best.t && best.prim >= 0 && (int)prim < best.prim)) {
-          best.prim = (int)prim;
-          best.t = t;
-          best.u = u;
-          best.v = v;
-        }
-      }
-      if (sp == 0) break;
-      sp--;
-      cur = stk[sp * kWave];
-    }
-  }
-  return best;
-}
-
-BD void addCount(DevCounters* c, int idx, uint32_t n) {
-  if (n) atomicAdd(&c->v[idx], (unsigned long long)n);
-}
-// Sum over the active lanes of the wave, one atomic per wave (always-on ray tallies).
-BD void waveAddCount(DevCounters* c, int idx, uint32_t n) {
-  uint32_t v = n;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
-  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&c->v[idx], (unsigned long long)v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -555,16 +272,15 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
 }
 
 // ------------------------------------------------------------------------------------------------
-// extend: one bounce of one sub-path type for every queued path.  shootRay + RayClosestHit /
-// RayMiss (+ RayAnyHit inside traverse) — globalIlluminationRay.hlsli:1-45, updateRayData
-// RayPathData.hlsli:88-109.  A miss stores the reference's "ghost" vertex (quirk 2): colour 0 and
-// the previous payload geometry.
+// shade: second half of one bounce.  The persistent trace kernel has left a closest-hit record per
+// queued path; this dense kernel runs RayClosestHit / RayMiss (globalIlluminationRay.hlsli:14-45,
+// updateRayData RayPathData.hlsli:88-109) and compacts the survivors into the next queue.
+// A miss stores the reference's "ghost" vertex (quirk 2): colour 0, previous payload geometry.
 // ------------------------------------------------------------------------------------------------
-template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, PathBuf P, int path, int k, int maxK,
-                                                       const uint32_t* __restrict__ qin, const uint32_t* __restrict__ countIn,
-                                                       uint32_t* __restrict__ qout, uint32_t* __restrict__ countOut) {
-  __shared__ int s_stack[kStackEntries * kWave];
+template <bool GGX>
+__global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, PathBuf P, int path, int k, int maxK,
+                                                      const uint32_t* __restrict__ qin, const uint32_t* __restrict__ countIn,
+                                                      uint32_t* __restrict__ qout, uint32_t* __restrict__ countOut) {
   const uint32_t n = *countIn;
   if (blockIdx.x * kWave >= n) return;
   const uint32_t i = blockIdx.x * kWave + threadIdx.x;
@@ -573,17 +289,10 @@ __global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, P
   uint32_t p = 0;
   if (active) {
     p = qin[i];
-    const f3 o = ldPlane3(P, path, k, F_POS, p);
-    const float* rd = P.rayDir + (size_t)(path * 3) * P.Np + p;
-    const f3 d = mk(rd[0], rd[P.Np], rd[2 * (size_t)P.Np]);
-    uint32_t nNodes = 0, nTris = 0;
-    Hit h = traverse<0, COUNT>(S, o, d, F.p.minT, 1.0e38f, s_stack + threadIdx.x, nNodes, nTris);
-    if (COUNT) {
-      addCount(F.counters, C_NODE_CLOSEST, nNodes);
-      addCount(F.counters, C_TRI_CLOSEST, nTris);
-    }
-    if (h.prim >= 0) {
-      Shading sd = shadeHit<false>(S, (uint32_t)h.prim, h.u, h.v, o);  // V points at WorldRayOrigin()
+    const int prim = P.hitPrim[i];
+    if (prim >= 0) {
+      const f3 o = ldPlane3(P, path, k, F_POS, p);
+      Shading sd = shadeHit<false>(S, (uint32_t)prim, P.hitU[i], P.hitV[i], o);  // V points at WorldRayOrigin()
       const size_t pix = (size_t)F.y0 * F.W + p;
       const uint32_t seed = (path == PATH_EYE) ? initRand((uint32_t)pix, F.p.frameCount) : P.seedL[p];
       f3 L;
@@ -609,7 +318,7 @@ __global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, P
     } else {
       Vtx g = zeroVtx();
       if (path == PATH_EYE && k == 1) {
-        g.pos = o;  // payload still holds initPayload's values (RayPathData.hlsli:69-86)
+        g.pos = ldPlane3(P, path, k, F_POS, p);  // payload still holds initPayload's values (RayPathData.hlsli:69-86)
       } else {
         loadSurf(P, path, k, p, g);
         g.V = ldPlane3(P, path, k, F_V, p);
@@ -629,153 +338,47 @@ __global__ __launch_bounds__(kWave) void extend_kernel(SceneDev S, FrameDev F, P
 }
 
 // ------------------------------------------------------------------------------------------------
-// NEE: BDPTMain.rt.hlsl:161-167 with evalDirect (MaterialUtils.hlsli:93-103, 149-184, 288-307).
-// One rand per term, drawn also for vertices that do not exist (App. A item 8).  The shadow ray
-// is skipped when the visible-light value is already 0 after clampVec (identical output).
+// gen_shadow: every shadow ray of the frame, generated per valid pixel in the reference's order
+// and appended (wave-compacted) to one SoA ray queue together with the clamped contribution it
+// gates.  slotRay[slot][p] remembers which ray (if any) belongs to which term so that the gather
+// stage can add the terms in the reference's order.
+//   NEE        BDPTMain.rt.hlsl:161-167, evalDirect MaterialUtils.hlsli:93-103/149-184/288-307
+//   splat      BDPTMain.rt.hlsl:171-208, getLaunchIndexFromDirection BDPTUtils.hlsli:129-138
+//   connection BDPTMain.rt.hlsl:212-233, evalGWithoutV / getUnweightedContribution BDPTUtils.hlsli:172-224
+//              (uniform 1/totalLength weights; aL indexes the light path with cameraIndex-1, sic :198)
+// A term whose value is already exactly 0 after clampVec gets no ray: NEE terms then add 0 either
+// way; connection terms only matter through the per-write saturate, which the gather stage
+// reproduces with at most a few lazily traced rays.
 // ------------------------------------------------------------------------------------------------
-template <bool GGX, bool COUNT>
-BD void neeLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nRays, uint32_t& nNodes,
-                uint32_t& nTris) {
-  const uint32_t p = P.queue[0][i];
-  const size_t pix = (size_t)F.y0 * F.W + p;
-  float4* out4 = reinterpret_cast<float4*>(F.out);
-  float4 acc = out4[pix];
-  uint32_t seed = P.seedL[p];
-  const uint32_t D = F.p.maxDepth;
-  const int eyeLast = P.eyeLast[p];
-  const int lightsCount = (int)S.numLights;
-  f3 prevColor = mk(1.0f);  // cameraPath[0].color
-  for (uint32_t t = 0; t < D; t++) {
-    const float r = nextRand(seed);
-    f3 add = mk(0);
-    if ((int)(t + 1) <= eyeLast) {
-      int lightToSample = (int)(r * (float)lightsCount);
-      if (lightToSample > lightsCount - 1) lightToSample = lightsCount - 1;
-      const f3 pos = ldPlane3(P, PATH_EYE, (int)t + 1, F_POS, p);
-      const f3 N = ldPlane3(P, PATH_EYE, (int)t + 1, F_N, p);
-      const f3 dif = ldPlane3(P, PATH_EYE, (int)t + 1, F_DIF, p);
-      f3 V = mk(0), spec = mk(0);
-      float rough = 0.0f;
-      if (GGX) {
-        V = ldPlane3(P, PATH_EYE, (int)t + 1, F_V, p);
-        spec = ldPlane3(P, PATH_EYE, (int)t + 1, F_SPEC, p);
-        rough = ldPlane1(P, PATH_EYE, (int)t + 1, F_ROUGH, p);
-      }
-      f3 L, lightIntensity;
-      float distToLight;
-      getLightData(S.sc->lights[lightToSample], pos, L, lightIntensity, distToLight);
-      f3 direct = directIfVisible<GGX>((float)lightsCount, L, lightIntensity, N, V, dif, spec, rough);
-      f3 shade = prevColor * direct;
-      shade = clampVec(shade / (float)(t + 2), F.p.clampUpper);
-      if (!allZero(shade)) {
-        Hit h = traverse<2, COUNT>(S, pos, L, F.p.minT, distToLight, stk, nNodes, nTris);
-        nRays++;
-        if (h.prim < 0) add = shade;
-      }
-      prevColor = ldPlane3(P, PATH_EYE, (int)t + 1, F_COL, p);
-    } else {
-      prevColor = mk(0);
-    }
-    if (!(F.p.flags & BDPT_PARAM_NO_NEE)) {
-      acc.x = acc.x + add.x;
-      acc.y = acc.y + add.y;
-      acc.z = acc.z + add.z;
-      acc.w = acc.w + 1.0f;
-    }
+BD uint32_t emitRay(const PathBuf& P, bool active, f3 o, f3 d, float tmax, f3 contrib) {
+  const unsigned long long mask = __ballot(active);
+  uint32_t id = kNoRay;
+  if (mask == 0ull) return id;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  const uint32_t q = blockIdx.x % kNumSubQueues;
+  if (lane == leader) base = atomicAdd(&P.rayCount[q], (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, leader);
+  if (active) {
+    id = q * P.raySubCap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const size_t c = P.rayCap;
+    float* r = P.rayQ + id;
+    r[0] = o.x;
+    r[c] = o.y;
+    r[2 * c] = o.z;
+    r[3 * c] = d.x;
+    r[4 * c] = d.y;
+    r[5 * c] = d.z;
+    r[6 * c] = tmax;
+    float* q = P.rayContrib + id;
+    q[0] = contrib.x;
+    q[c] = contrib.y;
+    q[2 * c] = contrib.z;
   }
-  out4[pix] = acc;
-}
-template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  __shared__ int s_stack[kStackEntries * kWave];
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  uint32_t nRays = 0, nNodes = 0, nTris = 0;
-  if (i < n) neeLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nRays, nNodes, nTris);
-  waveAddCount(F.counters, C_RAYS_NEE, nRays);
-  waveAddCount(F.counters, C_PIX_VALID, i < n ? 1u : 0u);
-  if (COUNT) {
-    waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
-    waveAddCount(F.counters, C_TRI_SHADOW, nTris);
-  }
+  return id;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Light tracing: BDPTMain.rt.hlsl:171-208, getLaunchIndexFromDirection BDPTUtils.hlsli:129-138,
-// connectToCamera MaterialUtils.hlsli:10-13.  Splats go to the fixed-point buffer (quirk 6);
-// out-of-frame indices are discarded (quirk 8).
-// ------------------------------------------------------------------------------------------------
-template <bool GGX, bool COUNT>
-BD void splatLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nRays, uint32_t& nNodes,
-                  uint32_t& nTris, uint32_t& nSplat) {
-  const uint32_t p = P.queue[0][i];
-  const int real = P.lightReal[p];
-  const f3 camPos = ld3(F.cam.posW);
-  const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
-  const f3 cameraN = normalize(Wc);
-  for (int t = 0; t < real; t++) {
-    Vtx lv;
-    loadSurf(P, PATH_LIGHT, t + 1, p, lv);
-    const f3 dirToCamera = normalize(camPos - lv.pos);
-    const float disToCamera = length(camPos - lv.pos);
-    if (!(dot(cameraN, dirToCamera) < 0)) continue;
-    Hit h = traverse<2, COUNT>(S, lv.pos, dirToCamera, F.p.minT, disToCamera, stk, nNodes, nTris);
-    nRays++;
-    if (h.prim >= 0) continue;
-    // pixel index
-    float d1 = dot(dirToCamera, U) / dot(U, U);
-    float d2 = dot(dirToCamera, Vc) / dot(Vc, Vc);
-    float d3 = dot(dirToCamera, Wc) / dot(Wc, Wc);
-    float nx = d1 / d3, ny = -d2 / d3;
-    float px = nx * 0.5f + 0.5f, py = ny * 0.5f + 0.5f;
-    float fx = rintf(px * (float)F.W - F.p.pixelJitter[0]);
-    float fy = rintf(py * (float)F.H - F.p.pixelJitter[1]);
-    const bool inside = (fx >= 0.0f && fx < (float)F.W && fy >= 0.0f && fy < (float)F.H);
-    if (!inside) continue;
-    float theta1 = saturate(fabsf(dot(dirToCamera, cameraN)));
-    float theta2 = saturate(fabsf(dot(dirToCamera, lv.N)));
-    float invDisToCamera = 1.0f / disToCamera;
-    float G = theta1 * theta2 * invDisToCamera * invDisToCamera;
-    f3 vV = mk(0);
-    if (GGX) vV = ldPlane3(P, PATH_LIGHT, t + 1, F_V, p);
-    f3 fr = evalBRDF<GGX>(vV, normalize(camPos - lv.pos), lv.N, lv.N, lv.dif, lv.spec, lv.rough, lv.isSpec);
-    f3 prevColor = ldPlane3(P, PATH_LIGHT, t, F_COL, p);
-    f3 shade = (prevColor * fr) * G;
-    shade = clampVec(shade / (float)(t + 2), F.p.clampUpper);
-    if (isnan3(shade)) shade = mk(0);
-    unsigned long long* sp = F.splat + ((size_t)(int)fy * F.W + (size_t)(int)fx) * 4;
-    const unsigned long long qx = toFixed(shade.x), qy = toFixed(shade.y), qz = toFixed(shade.z);
-    if (qx) atomicAdd(&sp[0], qx);
-    if (qy) atomicAdd(&sp[1], qy);
-    if (qz) atomicAdd(&sp[2], qz);
-    atomicAdd(&sp[3], 1ull);
-    nSplat++;
-  }
-}
-template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  __shared__ int s_stack[kStackEntries * kWave];
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  uint32_t nRays = 0, nNodes = 0, nTris = 0, nSplat = 0;
-  if (i < n) splatLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nRays, nNodes, nTris, nSplat);
-  waveAddCount(F.counters, C_RAYS_SPLAT, nRays);
-  waveAddCount(F.counters, C_SPLATS, nSplat);
-  if (COUNT) {
-    waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
-    waveAddCount(F.counters, C_TRI_SHADOW, nTris);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Vertex connection: BDPTMain.rt.hlsl:212-233, evalGWithoutV / getUnweightedContribution
-// BDPTUtils.hlsli:172-224 (uniform 1/totalLength weights; aL indexes the light path with
-// cameraIndex-1, sic :198).  Pairs are visited in the reference's order because every write
-// saturates.  A pair whose contribution is exactly 0 only matters through that saturate, so its
-// shadow ray is traced only while the pixel has not been saturated yet.
-// ------------------------------------------------------------------------------------------------
 template <bool GGX>
 BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx& v) {
   if (k > last) {
@@ -796,95 +399,287 @@ BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx
   }
 }
 
+template <bool GGX>
+__global__ __launch_bounds__(kWave) void gen_shadow_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  const uint32_t n = P.qcount[0];
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  const bool act = i < n;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  const uint32_t p = act ? P.queue[0][i] : 0u;
+  const int D = (int)F.p.maxDepth;
+  const int eyeLast = act ? (int)P.eyeLast[p] : 0;
+  const int lightLast = act ? (int)P.lightLast[p] : -1;
+  const int real = act ? (int)P.lightReal[p] : 0;
+  const f3 camPos = ld3(F.cam.posW);
+  const int lightsCount = (int)S.numLights;
+  uint32_t nNee = 0, nSplat = 0, nConn = 0;
+
+  // ---- NEE ------------------------------------------------------------------------------------
+  {
+    uint32_t seed = act ? P.seedL[p] : 0u;
+    f3 prevColor = mk(1.0f);  // cameraPath[0].color
+    for (int t = 0; t < D; t++) {
+      const float r = nextRand(seed);  // drawn for every term, also for vertices that do not exist (App. A item 8)
+      bool emit = false;
+      f3 pos = mk(0), L = mk(0), shade = mk(0);
+      float distToLight = 0.0f;
+      if (act && (t + 1) <= eyeLast) {
+        int lightToSample = (int)(r * (float)lightsCount);
+        if (lightToSample > lightsCount - 1) lightToSample = lightsCount - 1;
+        pos = ldPlane3(P, PATH_EYE, t + 1, F_POS, p);
+        const f3 N = ldPlane3(P, PATH_EYE, t + 1, F_N, p);
+        const f3 dif = ldPlane3(P, PATH_EYE, t + 1, F_DIF, p);
+        f3 V = mk(0), spec = mk(0);
+        float rough = 0.0f;
+        if (GGX) {
+          V = ldPlane3(P, PATH_EYE, t + 1, F_V, p);
+          spec = ldPlane3(P, PATH_EYE, t + 1, F_SPEC, p);
+          rough = ldPlane1(P, PATH_EYE, t + 1, F_ROUGH, p);
+        }
+        f3 lightIntensity;
+        getLightData(S.sc->lights[lightToSample], pos, L, lightIntensity, distToLight);
+        f3 direct = directIfVisible<GGX>((float)lightsCount, L, lightIntensity, N, V, dif, spec, rough);
+        shade = clampVec((prevColor * direct) / (float)(t + 2), F.p.clampUpper);
+        emit = !allZero(shade);
+        prevColor = ldPlane3(P, PATH_EYE, t + 1, F_COL, p);
+      } else {
+        prevColor = mk(0);
+      }
+      const uint32_t id = emitRay(P, emit, pos, L, distToLight, shade);
+      if (act) P.slotRay[(size_t)t * P.Np + p] = id;
+      nNee += emit ? 1u : 0u;
+    }
+  }
+
+  // ---- light tracing (splats) -------------------------------------------------------------------
+  if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
+    const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
+    const f3 cameraN = normalize(Wc);
+    for (int t = 0; t < D; t++) {
+      bool emit = false;
+      f3 pos = mk(0), dirToCamera = mk(0), shade = mk(0);
+      float disToCamera = 0.0f;
+      uint32_t target = kNoRay;
+      if (act && t < real) {
+        Vtx lv;
+        loadSurf(P, PATH_LIGHT, t + 1, p, lv);
+        pos = lv.pos;
+        dirToCamera = normalize(camPos - lv.pos);
+        disToCamera = length(camPos - lv.pos);
+        if (dot(cameraN, dirToCamera) < 0) {
+          emit = true;  // the reference traces this ray whatever the value (its write saturates the target pixel)
+          float d1 = dot(dirToCamera, U) / dot(U, U);
+          float d2 = dot(dirToCamera, Vc) / dot(Vc, Vc);
+          float d3 = dot(dirToCamera, Wc) / dot(Wc, Wc);
+          float nx = d1 / d3, ny = -d2 / d3;
+          float px = nx * 0.5f + 0.5f, py = ny * 0.5f + 0.5f;
+          float fx = rintf(px * (float)F.W - F.p.pixelJitter[0]);
+          float fy = rintf(py * (float)F.H - F.p.pixelJitter[1]);
+          const bool inside = (fx >= 0.0f && fx < (float)F.W && fy >= 0.0f && fy < (float)F.H);
+          if (inside) {
+            target = (uint32_t)(int)fy * F.W + (uint32_t)(int)fx;
+            float theta1 = saturate(fabsf(dot(dirToCamera, cameraN)));
+            float theta2 = saturate(fabsf(dot(dirToCamera, lv.N)));
+            float invDisToCamera = 1.0f / disToCamera;
+            float G = theta1 * theta2 * invDisToCamera * invDisToCamera;
+            f3 vV = mk(0);
+            if (GGX) vV = ldPlane3(P, PATH_LIGHT, t + 1, F_V, p);
+            f3 fr = evalBRDF<GGX>(vV, normalize(camPos - lv.pos), lv.N, lv.N, lv.dif, lv.spec, lv.rough, lv.isSpec);
+            f3 prevColor = ldPlane3(P, PATH_LIGHT, t, F_COL, p);
+            shade = clampVec(((prevColor * fr) * G) / (float)(t + 2), F.p.clampUpper);
+            if (isnan3(shade)) shade = mk(0);
+          }
+        }
+      }
+      const uint32_t id = emitRay(P, emit, pos, dirToCamera, disToCamera, shade);
+      if (act) {
+        P.slotRay[(size_t)(D + t) * P.Np + p] = id;
+        P.splatPix[(size_t)t * P.Np + p] = target;
+      }
+      nSplat += emit ? 1u : 0u;
+    }
+  }
+
+  // ---- vertex connections -----------------------------------------------------------------------
+  if (!(F.p.flags & BDPT_PARAM_NO_CONNECT)) {
+    int slot = 2 * D;
+    for (int totalLength = 2; totalLength <= D; totalLength++) {
+      for (int cameraLength = 1; cameraLength <= D - 1; cameraLength++) {
+        if (cameraLength > totalLength) continue;  // undefined in the reference (uint underflow, quirk 3)
+        const int lightLength = totalLength - cameraLength;
+        bool emit = false;
+        f3 posA = mk(0), dirAB = mk(0), shade = mk(0);
+        float lengthAB = 0.0f;
+        if (act) {
+          Vtx ce, le;
+          loadConnVtx<GGX>(P, PATH_EYE, cameraLength, eyeLast, p, ce);
+          loadConnVtx<GGX>(P, PATH_LIGHT, lightLength, lightLast, p, le);
+          const f3 vecAB = le.pos - ce.pos;
+          const float invLengthAB = 1.0f / length(vecAB);
+          const f3 dirG = vecAB * invLengthAB;
+          const float cosA = fabsf(dot(ce.N, dirG));
+          const float cosB = fabsf(dot(le.N, dirG));
+          const float G = cosA * cosB * invLengthAB * invLengthAB;
+          f3 c = mk(0);
+          if (lightLength != 0) {
+            const f3 connectDir = normalize(ce.pos - le.pos);
+            const f3 lprev = (lightLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength - 1, F_POS, p) : mk(0);
+            f3 wo = normalize(lprev - le.pos);
+            f3 fsL = evalBRDF<GGX>(connectDir, wo, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
+            if (allZero(fsL)) {
+              c = fsL;
+            } else {
+              f3 cprevPos, aE;
+              if (cameraLength - 1 == 0) {
+                cprevPos = camPos;
+                aE = mk(1.0f);
+              } else if (cameraLength - 1 <= eyeLast) {
+                cprevPos = ldPlane3(P, PATH_EYE, cameraLength - 1, F_POS, p);
+                aE = ldPlane3(P, PATH_EYE, cameraLength - 1, F_COL, p);
+              } else {
+                cprevPos = mk(0);
+                aE = mk(0);
+              }
+              wo = normalize(cprevPos - ce.pos);
+              f3 fsE = evalBRDF<GGX>(-connectDir, wo, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
+              if (allZero(fsE)) {
+                c = fsE;
+              } else {
+                const f3 aL = (cameraLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, cameraLength - 1, F_COL, p) : mk(0);
+                f3 cst = (fsL * G) * fsE;
+                c = (aL * cst) * aE;
+              }
+            }
+          }
+          shade = clampVec(c / (float)totalLength, F.p.clampUpper);
+          if (isnan3(shade)) shade = mk(0);
+          if (!allZero(shade)) {
+            emit = true;
+            posA = ce.pos;
+            lengthAB = length(le.pos - ce.pos);
+            dirAB = (le.pos - ce.pos) / lengthAB;
+          }
+        }
+        const uint32_t id = emitRay(P, emit, posA, dirAB, lengthAB, shade);
+        if (act) P.slotRay[(size_t)slot * P.Np + p] = id;
+        nConn += emit ? 1u : 0u;
+        slot++;
+      }
+    }
+  }
+  waveAddCount(F.counters, C_RAYS_NEE, nNee);
+  waveAddCount(F.counters, C_RAYS_SPLAT, nSplat);
+  waveAddCount(F.counters, C_RAYS_CONNECT, nConn);
+  waveAddCount(F.counters, C_PIX_VALID, act ? 1u : 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather: per valid pixel, add the terms in the reference's order using the visibility the trace
+// kernel wrote; NEE terms add without saturate (:166), connection terms saturate per write (:230).
+// If no non-zero connection turned out visible, the zero-valued pairs are traced here, in order,
+// until one is visible: its write would have saturated the pixel (rgb clamp + alpha = 1).  Visible
+// splats are added to the fixed-point splat buffer (quirk 6).
+// ------------------------------------------------------------------------------------------------
 template <bool GGX, bool COUNT>
-BD void connectLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nRays, uint32_t& nNodes,
-                    uint32_t& nTris) {
+BD void gatherLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nLazy, uint32_t& nNodes,
+                   uint32_t& nTris, uint32_t& nSplat) {
   const uint32_t p = P.queue[0][i];
   const size_t pix = (size_t)F.y0 * F.W + p;
   float4* out4 = reinterpret_cast<float4*>(F.out);
   float4 acc = out4[pix];
   const int D = (int)F.p.maxDepth;
-  const int eyeLast = P.eyeLast[p], lightLast = P.lightLast[p];
-  const f3 camPos = ld3(F.cam.posW);
-  bool sat = false;
-  for (int totalLength = 2; totalLength <= D; totalLength++) {
-    for (int cameraLength = 1; cameraLength <= D - 1; cameraLength++) {
-      if (cameraLength > totalLength) continue;  // undefined in the reference (uint underflow, quirk 3)
-      const int lightLength = totalLength - cameraLength;
-      Vtx ce, le;
-      loadConnVtx<GGX>(P, PATH_EYE, cameraLength, eyeLast, p, ce);
-      loadConnVtx<GGX>(P, PATH_LIGHT, lightLength, lightLast, p, le);
-      // evalGWithoutV
-      const f3 vecAB = le.pos - ce.pos;
-      const float invLengthAB = 1.0f / length(vecAB);
-      const f3 dirG = vecAB * invLengthAB;
-      const float cosA = fabsf(dot(ce.N, dirG));
-      const float cosB = fabsf(dot(le.N, dirG));
-      const float G = cosA * cosB * invLengthAB * invLengthAB;
-      // getUnweightedContribution
-      f3 c = mk(0);
-      if (lightLength != 0) {
-        const f3 connectDir = normalize(ce.pos - le.pos);
-        const f3 lprev = (lightLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength - 1, F_POS, p) : mk(0);
-        f3 wo = normalize(lprev - le.pos);
-        f3 fsL = evalBRDF<GGX>(connectDir, wo, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
-        if (allZero(fsL)) {
-          c = fsL;
-        } else {
-          f3 cprevPos, aE;
-          if (cameraLength - 1 == 0) {
-            cprevPos = camPos;
-            aE = mk(1.0f);
-          } else if (cameraLength - 1 <= eyeLast) {
-            cprevPos = ldPlane3(P, PATH_EYE, cameraLength - 1, F_POS, p);
-            aE = ldPlane3(P, PATH_EYE, cameraLength - 1, F_COL, p);
-          } else {
-            cprevPos = mk(0);
-            aE = mk(0);
-          }
-          wo = normalize(cprevPos - ce.pos);
-          f3 fsE = evalBRDF<GGX>(-connectDir, wo, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
-          if (allZero(fsE)) {
-            c = fsE;
-          } else {
-            const f3 aL = (cameraLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, cameraLength - 1, F_COL, p) : mk(0);
-            f3 cst = (fsL * G) * fsE;
-            c = (aL * cst) * aE;
-          }
-        }
+  const size_t cap = P.rayCap;
+  if (!(F.p.flags & BDPT_PARAM_NO_NEE)) {
+    for (int t = 0; t < D; t++) {
+      const uint32_t id = P.slotRay[(size_t)t * P.Np + p];
+      if (id != kNoRay && P.rayVis[id]) {
+        acc.x = acc.x + P.rayContrib[id];
+        acc.y = acc.y + P.rayContrib[cap + id];
+        acc.z = acc.z + P.rayContrib[2 * cap + id];
+      } else {
+        acc.x = acc.x + 0.0f;
+        acc.y = acc.y + 0.0f;
+        acc.z = acc.z + 0.0f;
       }
-      f3 shade = clampVec(c / (float)totalLength, F.p.clampUpper);
-      if (isnan3(shade)) shade = mk(0);
-      if (allZero(shade) && sat) continue;
-      const float lengthAB = length(le.pos - ce.pos);
-      const f3 dirAB = (le.pos - ce.pos) / lengthAB;
-      Hit h = traverse<2, COUNT>(S, ce.pos, dirAB, F.p.minT, lengthAB, stk, nNodes, nTris);
-      nRays++;
-      if (h.prim < 0) {
-        acc.x = saturate(acc.x + shade.x);
-        acc.y = saturate(acc.y + shade.y);
-        acc.z = saturate(acc.z + shade.z);
+      acc.w = acc.w + 1.0f;
+    }
+  }
+  if (!(F.p.flags & BDPT_PARAM_NO_CONNECT)) {
+    const int nPairs = (int)numConnectPairs((uint32_t)D);
+    bool sat = false;
+    for (int s = 0; s < nPairs; s++) {
+      const uint32_t id = P.slotRay[(size_t)(2 * D + s) * P.Np + p];
+      if (id != kNoRay && P.rayVis[id]) {
+        acc.x = saturate(acc.x + P.rayContrib[id]);
+        acc.y = saturate(acc.y + P.rayContrib[cap + id]);
+        acc.z = saturate(acc.z + P.rayContrib[2 * cap + id]);
         acc.w = saturate(acc.w + 1.0f);
         sat = true;
       }
     }
+    if (!sat && nPairs > 0) {
+      const int eyeLast = P.eyeLast[p], lightLast = P.lightLast[p];
+      int slot = 2 * D;
+      for (int totalLength = 2; totalLength <= D && !sat; totalLength++) {
+        for (int cameraLength = 1; cameraLength <= D - 1 && !sat; cameraLength++) {
+          if (cameraLength > totalLength) continue;
+          const uint32_t id = P.slotRay[(size_t)slot * P.Np + p];
+          slot++;
+          if (id != kNoRay) continue;  // had a ray and it was occluded
+          const int lightLength = totalLength - cameraLength;
+          const f3 posA = (cameraLength <= eyeLast) ? ldPlane3(P, PATH_EYE, cameraLength, F_POS, p) : mk(0);
+          const f3 posB = (lightLength <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength, F_POS, p) : mk(0);
+          const float lengthAB = length(posB - posA);
+          const f3 dirAB = (posB - posA) / lengthAB;
+          Hit h = traverse<2, COUNT>(S, posA, dirAB, F.p.minT, lengthAB, stk, nNodes, nTris);
+          nLazy++;
+          if (h.prim < 0) sat = true;
+        }
+      }
+      if (sat) {
+        acc.x = saturate(acc.x + 0.0f);
+        acc.y = saturate(acc.y + 0.0f);
+        acc.z = saturate(acc.z + 0.0f);
+        acc.w = saturate(acc.w + 1.0f);
+      }
+    }
   }
   out4[pix] = acc;
+  if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
+    for (int t = 0; t < D; t++) {
+      const uint32_t id = P.slotRay[(size_t)(D + t) * P.Np + p];
+      if (id == kNoRay || !P.rayVis[id]) continue;
+      const uint32_t target = P.splatPix[(size_t)t * P.Np + p];
+      if (target == kNoRay) continue;  // outside the frame (quirk 8)
+      unsigned long long* sp = F.splat + (size_t)target * 4;
+      const unsigned long long qx = toFixed(P.rayContrib[id]), qy = toFixed(P.rayContrib[cap + id]),
+                               qz = toFixed(P.rayContrib[2 * cap + id]);
+      if (qx) atomicAdd(&sp[0], qx);
+      if (qy) atomicAdd(&sp[1], qy);
+      if (qz) atomicAdd(&sp[2], qz);
+      atomicAdd(&sp[3], 1ull);
+      nSplat++;
+    }
+  }
 }
+
 template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
+__global__ __launch_bounds__(kWave) void gather_kernel(SceneDev S, FrameDev F, PathBuf P) {
   __shared__ int s_stack[kStackEntries * kWave];
   const uint32_t n = P.qcount[0];
   if (blockIdx.x * kWave >= n) return;
   const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  uint32_t nRays = 0, nNodes = 0, nTris = 0;
-  if (i < n) connectLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nRays, nNodes, nTris);
-  waveAddCount(F.counters, C_RAYS_CONNECT, nRays);
+  uint32_t nLazy = 0, nNodes = 0, nTris = 0, nSplat = 0;
+  if (i < n) gatherLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nLazy, nNodes, nTris, nSplat);
+  waveAddCount(F.counters, C_RAYS_CONNECT, nLazy);
+  waveAddCount(F.counters, C_RAYS_LAZY, nLazy);
+  waveAddCount(F.counters, C_SPLATS, nSplat);
   if (COUNT) {
     waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
     waveAddCount(F.counters, C_TRI_SHADOW, nTris);
   }
 }
+
 
 // out = saturate(out + splat) where at least one splat landed
 __global__ void resolve_kernel(const unsigned long long* __restrict__ splat, uint32_t splatRow0, float4* __restrict__ out, uint32_t W,
@@ -979,10 +774,20 @@ __global__ void test_bsdf_kernel(const float* in, uint32_t n, bool fromLobe, flo
   o[11] = o[12] = o[13] = o[14] = o[15] = 0.0f;
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t blocksFor(uint64_t n) { return (uint32_t)((n + kWave - 1) / kWave); }
+
+// Persistent grids: as many one-wave workgroups as can be resident (LDS 8 KiB/wave, VGPRs).
+template <class K>
+static uint32_t persistentGrid(K kernel, int numCUs) {
+  int perCU = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kWave, 0) != hipSuccess || perCU <= 0) perCU = 8;
+  if (perCU > 20) perCU = 20;
+  return (uint32_t)(perCU * numCUs);
+}
 
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st) {
   const uint32_t Np = (G.y1 - G.y0) * G.W;
@@ -1001,36 +806,72 @@ void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hip
     hipLaunchKernelGGL(init_paths_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
 }
 
-#define BDPT_DISPATCH(KERNEL, GRID, ...)                                                         \
-  do {                                                                                           \
-    const bool ggx_ = (F.p.matIndex == 0), cnt_ = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;                       \
-    if (ggx_ && cnt_)                                                                            \
-      hipLaunchKernelGGL((KERNEL<true, true>), dim3(GRID), dim3(kWave), 0, st, __VA_ARGS__);     \
-    else if (ggx_)                                                                               \
-      hipLaunchKernelGGL((KERNEL<true, false>), dim3(GRID), dim3(kWave), 0, st, __VA_ARGS__);    \
-    else if (cnt_)                                                                               \
-      hipLaunchKernelGGL((KERNEL<false, true>), dim3(GRID), dim3(kWave), 0, st, __VA_ARGS__);    \
-    else                                                                                         \
-      hipLaunchKernelGGL((KERNEL<false, false>), dim3(GRID), dim3(kWave), 0, st, __VA_ARGS__);   \
-  } while (0)
-
 void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
-                  const uint32_t* countIn, uint32_t* qout, uint32_t* countOut, hipStream_t st) {
+                  const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st) {
   if (!P.Np) return;
-  BDPT_DISPATCH(extend_kernel, blocksFor(P.Np), S, F, P, path, k, maxK, qin, countIn, qout, countOut);
+  const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
+  RayQueue Q{nullptr, 0, 0, 1, countIn, head};
+  ClosestIn CI{qin, P.v + ((size_t)(path * (int)P.D1 + k) * NF + (size_t)F_POS) * P.Np, P.rayDir + (size_t)(path * 3) * P.Np, P.Np,
+               F.p.minT};
+  ShadowOut SO{nullptr};
+  ClosestOut CO{P.hitPrim, P.hitT, P.hitU, P.hitV};
+  static uint32_t grid0 = 0, grid1 = 0;
+  if (cnt) {
+    if (!grid1) grid1 = persistentGrid(trace_kernel<0, true>, numCUs);
+    const uint32_t g = std::min(grid1, blocksFor(P.Np));
+    hipLaunchKernelGGL((trace_kernel<0, true>), dim3(g), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, 0.0f);
+  } else {
+    if (!grid0) grid0 = persistentGrid(trace_kernel<0, false>, numCUs);
+    const uint32_t g = std::min(grid0, blocksFor(P.Np));
+    hipLaunchKernelGGL((trace_kernel<0, false>), dim3(g), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, 0.0f);
+  }
+  if (F.p.matIndex == 0)
+    hipLaunchKernelGGL(shade_kernel<true>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
+                       countOut);
+  else
+    hipLaunchKernelGGL(shade_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
+                       countOut);
 }
-void launchNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+
+void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
-  BDPT_DISPATCH(nee_kernel, blocksFor(P.Np), S, F, P);
+  if (F.p.matIndex == 0)
+    hipLaunchKernelGGL(gen_shadow_kernel<true>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
+  else
+    hipLaunchKernelGGL(gen_shadow_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
 }
-void launchSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+
+void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st) {
   if (!P.Np) return;
-  BDPT_DISPATCH(splat_kernel, blocksFor(P.Np), S, F, P);
+  const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
+  RayQueue Q{P.rayQ, P.rayCap, P.raySubCap, kNumSubQueues, P.rayCount, P.rayHead};
+  ClosestIn CI{nullptr, nullptr, nullptr, 0, 0.0f};
+  ShadowOut SO{P.rayVis};
+  ClosestOut CO{nullptr, nullptr, nullptr, nullptr};
+  static uint32_t grid0 = 0, grid1 = 0;
+  if (cnt) {
+    if (!grid1) grid1 = persistentGrid(trace_kernel<2, true>, numCUs);
+    hipLaunchKernelGGL((trace_kernel<2, true>), dim3(grid1), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, F.p.minT);
+  } else {
+    if (!grid0) grid0 = persistentGrid(trace_kernel<2, false>, numCUs);
+    hipLaunchKernelGGL((trace_kernel<2, false>), dim3(grid0), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, F.p.minT);
+  }
 }
-void launchConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+
+void launchGather(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
-  BDPT_DISPATCH(connect_kernel, blocksFor(P.Np), S, F, P);
+  const bool ggx = (F.p.matIndex == 0), cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
+  const dim3 g(blocksFor(P.Np)), b(kWave);
+  if (ggx && cnt)
+    hipLaunchKernelGGL((gather_kernel<true, true>), g, b, 0, st, S, F, P);
+  else if (ggx)
+    hipLaunchKernelGGL((gather_kernel<true, false>), g, b, 0, st, S, F, P);
+  else if (cnt)
+    hipLaunchKernelGGL((gather_kernel<false, true>), g, b, 0, st, S, F, P);
+  else
+    hipLaunchKernelGGL((gather_kernel<false, false>), g, b, 0, st, S, F, P);
 }
+
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
                    hipStream_t st) {
   const uint64_t n = (uint64_t)(y1 - y0) * W;

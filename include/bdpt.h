@@ -220,6 +220,7 @@ typedef struct bdpt_counters {
   uint64_t triTestsShadow;
   uint64_t pixelsValid;       /* G-buffer pixels with geometry */
   uint64_t splatsLanded;
+  uint64_t raysConnectLazy;   /* subset of raysConnect traced by the gather stage for zero-valued pairs */
 } bdpt_counters;
 
 typedef struct bdpt_bvh_info {

@@ -19,7 +19,7 @@ using namespace bdpt;
 namespace {
 constexpr int kMaxStages = 64;
 // path-queue counters, their fetch cursors, then the shadow sub-queue counters and cursors
-constexpr size_t kCursorWords = 4 * BDPT_MAX_DEPTH + 8 + 2 * kNumSubQueues;
+constexpr size_t kCursorWords = 4 * BDPT_MAX_DEPTH + 8 + 2 * kNumSubQueues + kLazyRounds + 2;
 }
 
 struct bdpt_ctx {
@@ -312,6 +312,7 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   P.qhead = P.qcount + 2 * BDPT_MAX_DEPTH + 4;
   P.rayCount = P.qcount + 4 * BDPT_MAX_DEPTH + 8;
   P.rayHead = P.rayCount + kNumSubQueues;
+  P.lazyCount = P.rayHead + kNumSubQueues;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrim, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, np))) return rc;
@@ -335,6 +336,9 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     if ((rc = devAlloc(c, c->frameAllocs, &P.rayVis, (size_t)cap))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.slotRay, (size_t)slots * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.splatPix, (size_t)D * np))) return rc;
+    const uint32_t batch = (numConnectPairs(D) + kLazyRounds - 1) / kLazyRounds;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.lazyCursor, np))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.lazyRay, (size_t)std::max<uint32_t>(batch, 1) * np))) return rc;
   }
   if ((rc = devAlloc(c, c->frameAllocs, &c->ownSplat, (size_t)width * height * 4))) return rc;
   c->splat = c->ownSplat;
@@ -453,8 +457,22 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   stageMark(c, st, "gen_shadow");
   launchTraceShadow(c->S, F, P, c->numCUs, st);
   stageMark(c, st, "trace_shadow");
-  launchGather(c->S, F, P, st);
+  launchGather(F, P, P.queue[1], &P.lazyCount[0], st);
   stageMark(c, st, "gather");
+  if (!(p->flags & BDPT_PARAM_NO_CONNECT) && D >= 2) {
+    // zero-valued connection pairs of the pixels no visible connection has saturated yet
+    const int nPairs = (int)numConnectPairs((uint32_t)D);
+    const int batch = (nPairs + kLazyRounds - 1) / kLazyRounds;
+    for (int r = 0; r < kLazyRounds; r++) {
+      uint32_t* list = P.queue[1 + (r & 1)];
+      uint32_t* next = P.queue[1 + ((r + 1) & 1)];
+      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kNumSubQueues * sizeof(uint32_t), st));
+      launchLazyGen(F, P, list, &P.lazyCount[r], batch, st);
+      launchTraceShadow(c->S, F, P, c->numCUs, st);
+      launchLazyCheck(F, P, list, &P.lazyCount[r], batch, next, &P.lazyCount[r + 1], st);
+    }
+    stageMark(c, st, "lazy_rounds");
+  }
   if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
     launchResolve(c->splat, 0, out, c->W, c->tile.y0, c->tile.y1, st);
     stageMark(c, st, "resolve");

@@ -87,6 +87,9 @@ struct PathBuf {
   uint32_t raySubCap;    // capacity of one sub-queue; ray id = subQueue*raySubCap + offset
   uint32_t* slotRay;     // planes: slot*Np + p -> ray id or kNoRay.  slots: [0,D) NEE, [D,2D) splat, [2D,..) pairs
   uint32_t* splatPix;    // planes: t*Np + p -> full-frame pixel index of splat t
+  uint8_t* lazyCursor;   // next connection-pair ordinal a pending pixel has not examined yet
+  uint32_t* lazyRay;     // planes: b*Np + p -> ray id of the b-th lazy ray of the current round
+  uint32_t* lazyCount;   // pending-list sizes, one per round
   uint32_t rayCap;
   uint32_t Np, D1;
 };
@@ -117,7 +120,11 @@ void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int pa
                   const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st);
 void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st);
-void launchGather(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st);
+void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st);
+void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
+                     uint32_t* nextList, uint32_t* nextCount, hipStream_t st);
+constexpr int kLazyRounds = 8;  // rounds per frame; batch = ceil(pairs / rounds)
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
                    hipStream_t st);
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);

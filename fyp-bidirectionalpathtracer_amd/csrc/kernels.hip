@@ -576,14 +576,12 @@ __global__ __launch_bounds__(kWave) void gen_shadow_kernel(SceneDev S, FrameDev 
 // ------------------------------------------------------------------------------------------------
 // gather: per valid pixel, add the terms in the reference's order using the visibility the trace
 // kernel wrote; NEE terms add without saturate (:166), connection terms saturate per write (:230).
-// If no non-zero connection turned out visible, the zero-valued pairs are traced here, in order,
-// until one is visible: its write would have saturated the pixel (rgb clamp + alpha = 1).  Visible
-// splats are added to the fixed-point splat buffer (quirk 6).
+// If no non-zero connection turned out visible the pixel is handed to the lazy rounds: the
+// zero-valued pairs still matter, because the first visible one would have saturated the pixel
+// (rgb clamp + alpha = 1).  Visible splats are added to the fixed-point splat buffer (quirk 6).
 // ------------------------------------------------------------------------------------------------
-template <bool GGX, bool COUNT>
-BD void gatherLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint32_t i, int* stk, uint32_t& nLazy, uint32_t& nNodes,
-                   uint32_t& nTris, uint32_t& nSplat) {
-  const uint32_t p = P.queue[0][i];
+BD bool gatherLane(const FrameDev& F, const PathBuf& P, uint32_t p, uint32_t& nSplat) {
+  bool pending = false;
   const size_t pix = (size_t)F.y0 * F.W + p;
   float4* out4 = reinterpret_cast<float4*>(F.out);
   float4 acc = out4[pix];
@@ -617,32 +615,7 @@ BD void gatherLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint3
         sat = true;
       }
     }
-    if (!sat && nPairs > 0) {
-      const int eyeLast = P.eyeLast[p], lightLast = P.lightLast[p];
-      int slot = 2 * D;
-      for (int totalLength = 2; totalLength <= D && !sat; totalLength++) {
-        for (int cameraLength = 1; cameraLength <= D - 1 && !sat; cameraLength++) {
-          if (cameraLength > totalLength) continue;
-          const uint32_t id = P.slotRay[(size_t)slot * P.Np + p];
-          slot++;
-          if (id != kNoRay) continue;  // had a ray and it was occluded
-          const int lightLength = totalLength - cameraLength;
-          const f3 posA = (cameraLength <= eyeLast) ? ldPlane3(P, PATH_EYE, cameraLength, F_POS, p) : mk(0);
-          const f3 posB = (lightLength <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength, F_POS, p) : mk(0);
-          const float lengthAB = length(posB - posA);
-          const f3 dirAB = (posB - posA) / lengthAB;
-          Hit h = traverse<2, COUNT>(S, posA, dirAB, F.p.minT, lengthAB, stk, nNodes, nTris);
-          nLazy++;
-          if (h.prim < 0) sat = true;
-        }
-      }
-      if (sat) {
-        acc.x = saturate(acc.x + 0.0f);
-        acc.y = saturate(acc.y + 0.0f);
-        acc.z = saturate(acc.z + 0.0f);
-        acc.w = saturate(acc.w + 1.0f);
-      }
-    }
+    pending = (!sat && nPairs > 0);  // settled by the lazy rounds below
   }
   out4[pix] = acc;
   if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
@@ -661,25 +634,110 @@ BD void gatherLane(const SceneDev& S, const FrameDev& F, const PathBuf& P, uint3
       nSplat++;
     }
   }
+  return pending;
 }
 
-template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void gather_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  __shared__ int s_stack[kStackEntries * kWave];
+__global__ __launch_bounds__(kWave) void gather_kernel(FrameDev F, PathBuf P, uint32_t* __restrict__ lazyList,
+                                                       uint32_t* __restrict__ lazyCount) {
   const uint32_t n = P.qcount[0];
   if (blockIdx.x * kWave >= n) return;
   const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  uint32_t nLazy = 0, nNodes = 0, nTris = 0, nSplat = 0;
-  if (i < n) gatherLane<GGX, COUNT>(S, F, P, i, s_stack + threadIdx.x, nLazy, nNodes, nTris, nSplat);
-  waveAddCount(F.counters, C_RAYS_CONNECT, nLazy);
-  waveAddCount(F.counters, C_RAYS_LAZY, nLazy);
-  waveAddCount(F.counters, C_SPLATS, nSplat);
-  if (COUNT) {
-    waveAddCount(F.counters, C_NODE_SHADOW, nNodes);
-    waveAddCount(F.counters, C_TRI_SHADOW, nTris);
+  uint32_t nSplat = 0, p = 0;
+  bool pending = false;
+  if (i < n) {
+    p = P.queue[0][i];
+    pending = gatherLane(F, P, p, nSplat);
+    if (pending) P.lazyCursor[p] = 0;
   }
+  waveAddCount(F.counters, C_SPLATS, nSplat);
+  wavePush(pending, p, lazyList, lazyCount);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lazy rounds.  A pending pixel has no visible non-zero connection; the reference would still have
+// traced its zero-valued pairs (BDPTMain.rt.hlsl:223) and the first visible one saturates the pixel
+// (:230).  Only the OR of their visibilities matters, so each round queues the next `batch`
+// zero-valued pairs of every still-pending pixel, traces them in the persistent kernel, and
+// settles the pixels that found a visible one.
+// ------------------------------------------------------------------------------------------------
+BD void pairFromOrdinal(int D, int ord, int& totalLength, int& cameraLength) {
+  int t = 2;
+  for (; t <= D; t++) {
+    const int cnt = (t < D - 1) ? t : (D - 1);
+    if (ord < cnt) break;
+    ord -= cnt;
+  }
+  totalLength = t;
+  cameraLength = ord + 1;
+}
+
+__global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
+                                                         const uint32_t* __restrict__ listCount, int batch) {
+  const uint32_t n = *listCount;
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  const bool act = i < n;
+  const uint32_t p = act ? list[i] : 0u;
+  const int D = (int)F.p.maxDepth;
+  const int nPairs = (int)numConnectPairs((uint32_t)D);
+  int ord = act ? (int)P.lazyCursor[p] : nPairs;
+  const int eyeLast = act ? (int)P.eyeLast[p] : 0, lightLast = act ? (int)P.lightLast[p] : -1;
+  uint32_t nRays = 0;
+  for (int b = 0; b < batch; b++) {
+    while (ord < nPairs && P.slotRay[(size_t)(2 * D + ord) * P.Np + p] != kNoRay) ord++;  // had a ray: it was occluded
+    const bool emit = act && ord < nPairs;
+    f3 posA = mk(0), dirAB = mk(0);
+    float lengthAB = 0.0f;
+    if (emit) {
+      int totalLength, cameraLength;
+      pairFromOrdinal(D, ord, totalLength, cameraLength);
+      const int lightLength = totalLength - cameraLength;
+      posA = (cameraLength <= eyeLast) ? ldPlane3(P, PATH_EYE, cameraLength, F_POS, p) : mk(0);
+      const f3 posB = (lightLength <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength, F_POS, p) : mk(0);
+      lengthAB = length(posB - posA);
+      dirAB = (posB - posA) / lengthAB;
+      ord++;
+    }
+    const uint32_t id = emitRay(P, emit, posA, dirAB, lengthAB, mk(0));
+    if (act) P.lazyRay[(size_t)b * P.Np + p] = id;
+    nRays += emit ? 1u : 0u;
+  }
+  if (act) P.lazyCursor[p] = (uint8_t)ord;
+  waveAddCount(F.counters, C_RAYS_CONNECT, nRays);
+  waveAddCount(F.counters, C_RAYS_LAZY, nRays);
+}
+
+__global__ __launch_bounds__(kWave) void lazy_check_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
+                                                           const uint32_t* __restrict__ listCount, int batch,
+                                                           uint32_t* __restrict__ nextList, uint32_t* __restrict__ nextCount) {
+  const uint32_t n = *listCount;
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  bool again = false;
+  uint32_t p = 0;
+  if (i < n) {
+    p = list[i];
+    bool vis = false;
+    for (int b = 0; b < batch; b++) {
+      const uint32_t id = P.lazyRay[(size_t)b * P.Np + p];
+      if (id != kNoRay && P.rayVis[id]) vis = true;
+    }
+    if (vis) {
+      const size_t pix = (size_t)F.y0 * F.W + p;
+      float4* out4 = reinterpret_cast<float4*>(F.out);
+      float4 acc = out4[pix];
+      acc.x = saturate(acc.x + 0.0f);
+      acc.y = saturate(acc.y + 0.0f);
+      acc.z = saturate(acc.z + 0.0f);
+      acc.w = saturate(acc.w + 1.0f);
+      out4[pix] = acc;
+    } else {
+      const int nPairs = (int)numConnectPairs(F.p.maxDepth);
+      again = (int)P.lazyCursor[p] < nPairs;
+    }
+  }
+  wavePush(again, p, nextList, nextCount);
+}
 
 // out = saturate(out + splat) where at least one splat landed
 __global__ void resolve_kernel(const unsigned long long* __restrict__ splat, uint32_t splatRow0, float4* __restrict__ out, uint32_t W,
@@ -858,18 +916,18 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
   }
 }
 
-void launchGather(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st) {
   if (!P.Np) return;
-  const bool ggx = (F.p.matIndex == 0), cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
-  const dim3 g(blocksFor(P.Np)), b(kWave);
-  if (ggx && cnt)
-    hipLaunchKernelGGL((gather_kernel<true, true>), g, b, 0, st, S, F, P);
-  else if (ggx)
-    hipLaunchKernelGGL((gather_kernel<true, false>), g, b, 0, st, S, F, P);
-  else if (cnt)
-    hipLaunchKernelGGL((gather_kernel<false, true>), g, b, 0, st, S, F, P);
-  else
-    hipLaunchKernelGGL((gather_kernel<false, false>), g, b, 0, st, S, F, P);
+  hipLaunchKernelGGL(gather_kernel, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, F, P, lazyList, lazyCount);
+}
+void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st) {
+  if (!P.Np) return;
+  hipLaunchKernelGGL(lazy_gen_kernel, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, F, P, list, listCount, batch);
+}
+void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
+                     uint32_t* nextList, uint32_t* nextCount, hipStream_t st) {
+  if (!P.Np) return;
+  hipLaunchKernelGGL(lazy_check_kernel, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, F, P, list, listCount, batch, nextList, nextCount);
 }
 
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,

@@ -52,6 +52,9 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
   const float4* np = S.nodes + (size_t)T.cur * 4;
   const float4 q0 = np[0], q1 = np[1], q2 = np[2];
   const int4 q3 = reinterpret_cast<const int4*>(np)[3];
+  // (plane - o) * idir, not fma(plane, idir, -o*idir): for axis-parallel rays (idir = inf) the fused
+  // form yields inf - inf = NaN, the NaN-ignoring min/max then drop that axis, and rays such as
+  // (0,0,0) -> (0,y,0) would visit every box of the scene.
   const f3 o = T.o, idir = T.idir;
   float ax0 = (q0.x - o.x) * idir.x, ax1 = (q0.w - o.x) * idir.x;
   float ay0 = (q0.y - o.y) * idir.y, ay1 = (q1.x - o.y) * idir.y;

@@ -8,7 +8,10 @@
 namespace bdpt {
 
 constexpr int kWave = 64;          // gfx950 wavefront
-constexpr int kStackEntries = 32;  // per-lane traversal stack in LDS (kBvhMaxDepth = 30)
+#ifndef KSTACK
+#define KSTACK 32
+#endif
+constexpr int kStackEntries = KSTACK;  // per-lane traversal stack in LDS, 8 KiB per wave (kBvhMaxDepth = 30)
 constexpr int kShadeRecF4 = 7;     // float4s per triangle shading record (112 B)
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // Hot single-word atomics top out near 90 M/s on this chip (MI355X_MICROARCH.md "dequeue"), so

@@ -836,6 +836,9 @@ __global__ void test_bsdf_kernel(const float* in, uint32_t n, bool fromLobe, flo
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+#ifndef PERCU
+#define PERCU 20
+#endif
 static inline uint32_t blocksFor(uint64_t n) { return (uint32_t)((n + kWave - 1) / kWave); }
 
 // Persistent grids: as many one-wave workgroups as can be resident (LDS 8 KiB/wave, VGPRs).
@@ -843,7 +846,7 @@ template <class K>
 static uint32_t persistentGrid(K kernel, int numCUs) {
   int perCU = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kWave, 0) != hipSuccess || perCU <= 0) perCU = 8;
-  if (perCU > 20) perCU = 20;
+  if (perCU > PERCU) perCU = PERCU;
   return (uint32_t)(perCU * numCUs);
 }
 

@@ -82,8 +82,8 @@ def main():
     scene = pkg.Scene.atrium(1, args.triangles) if args.scene == "atrium" else pkg.Scene.cornell()
 
     # tile = contiguous band of rows; bands padded to equal height so reduce-scatter chunks are equal
-    rows = (H + world - 1) // world
-    y0, y1 = min(rank * rows, H), min((rank + 1) * rows, H)
+    rows = pkg.tiling.band_rows(H, world)
+    y0, y1 = pkg.tiling.band(H, world, rank)
     pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, tile=(y0, y1), accum_limit=10000)
     ctx = pipe.ctx
     info = ctx.bvh_info()
@@ -99,7 +99,7 @@ def main():
             pipe.render_frame(accumulate=True, extra_flags=flags)
         else:
             pipe.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE)
-            dist.reduce_scatter_tensor(splat_mine, splat_full, op=dist.ReduceOp.SUM)
+            pkg.tiling.exchange_splats(dist, splat_full, splat_mine)
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             ctx.resolve(C.c_void_p(splat_mine.data_ptr()), y0, C.c_void_p(pipe.output.data_ptr()), st)
             n = pipe.accum_count

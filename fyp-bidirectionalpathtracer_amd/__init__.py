@@ -9,10 +9,10 @@ There is no CPU fallback anywhere in this package.
 """
 import ctypes as C
 
-from . import abi
+from . import abi, tiling
 from .abi import (Camera, Counters, GBuffer, GBufferParams, Params, SceneDesc, Tile, load_library)
 
-__all__ = ["abi", "Scene", "Context", "FramePipeline", "load_library"]
+__all__ = ["abi", "tiling", "Scene", "Context", "FramePipeline", "load_library"]
 
 # Channel names of the reference's ResourceManager (BDPTPass.cpp:27-29, LightProbeGBufferPass.cpp:46-51)
 GBUFFER_CHANNELS = ("WorldPosition", "WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams",

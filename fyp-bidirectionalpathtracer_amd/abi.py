@@ -101,6 +101,7 @@ PROTOTYPES = {
     "bdpt_set_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "bdpt_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(BvhInfo)]),
     "bdpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
+    "bdpt_bvh_build_check": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BvhInfo), C.c_char_p, C.c_uint32]),
     "bdpt_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.POINTER(Camera)]),
     "bdpt_msaa_jitter": (None, [C.c_uint32, C.POINTER(C.c_float)]),

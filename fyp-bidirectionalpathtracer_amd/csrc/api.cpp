@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -256,6 +257,106 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.sc, &sc, 1))) return rc;
   c->S.numLights = d->numLights;
   c->haveScene = true;
+  return BDPT_OK;
+}
+
+int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg, uint32_t msgCap) {
+  auto say = [&](const std::string& m) {
+    if (msg && msgCap) {
+      std::snprintf(msg, msgCap, "%s", m.c_str());
+    }
+    return BDPT_E_INVALID;
+  };
+  if (!d || !out || !d->positions || !d->indices) return say("null scene");
+  Bvh bvh;
+  buildBvh(d->positions, d->indices, d->numTriangles, nullptr, bvh);
+  out->numNodes = (uint32_t)bvh.nodes.size();
+  out->numTriangles = d->numTriangles;
+  out->maxDepth = bvh.maxDepth;
+  out->nodeBytes = sizeof(BvhNode);
+  out->triBytes = sizeof(BvhTri);
+  out->sahCost = bvh.sahCost;
+  if (bvh.maxDepth > (uint32_t)kBvhMaxDepth) return say("depth exceeds kBvhMaxDepth");
+  if (bvh.tris.size() != d->numTriangles) return say("triangle list size");
+  std::vector<uint8_t> seen(d->numTriangles, 0);
+  for (const BvhTri& t : bvh.tris) {
+    if (t.prim >= d->numTriangles || seen[t.prim]) return say("primitive missing or duplicated in the leaf order");
+    seen[t.prim] = 1;
+  }
+  if (d->numTriangles == 0) return BDPT_OK;
+  // walk: returns the exact bounds of a subtree and checks them against the stored (padded) box
+  std::vector<uint8_t> covered(d->numTriangles, 0);
+  struct Bounds {
+    float lo[3], hi[3];
+  };
+  bool ok = true;
+  std::string why;
+  std::function<Bounds(int32_t, uint32_t)> walk = [&](int32_t ref, uint32_t depth) -> Bounds {
+    Bounds b;
+    for (int k = 0; k < 3; k++) {
+      b.lo[k] = 1e30f;
+      b.hi[k] = -1e30f;
+    }
+    if (depth > (uint32_t)kBvhMaxDepth + 1) {
+      ok = false;
+      why = "walk deeper than kBvhMaxDepth";
+      return b;
+    }
+    if (ref < 0) {
+      const uint32_t enc = (uint32_t)(-1 - ref), first = enc >> 3, cnt = (enc & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; i++) {
+        if (first + i >= bvh.tris.size() || covered[first + i]) {
+          ok = false;
+          why = "leaf range out of bounds or shared";
+          return b;
+        }
+        covered[first + i] = 1;
+        const BvhTri& t = bvh.tris[first + i];
+        for (int k = 0; k < 3; k++) {
+          const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];
+          b.lo[k] = std::min(b.lo[k], std::min(p0, std::min(p1, p2)));
+          b.hi[k] = std::max(b.hi[k], std::max(p0, std::max(p1, p2)));
+        }
+      }
+      return b;
+    }
+    if ((size_t)ref >= bvh.nodes.size()) {
+      ok = false;
+      why = "child index out of range";
+      return b;
+    }
+    const BvhNode& n = bvh.nodes[(size_t)ref];
+    const float lo0[3] = {n.lo0[0], n.lo0[1], n.lo0[2]}, hi0[3] = {n.hi0x, n.hi0yz[0], n.hi0yz[1]};
+    const float lo1[3] = {n.lo1xy[0], n.lo1xy[1], n.lo1z}, hi1[3] = {n.hi1[0], n.hi1[1], n.hi1[2]};
+    const bool has0 = lo0[0] <= hi0[0], has1 = lo1[0] <= hi1[0];
+    if (has0) {
+      Bounds c = walk(n.child0, depth + 1);
+      for (int k = 0; k < 3; k++) {
+        if (c.lo[k] < lo0[k] || c.hi[k] > hi0[k]) {
+          ok = false;
+          why = "child 0 box does not contain its subtree";
+        }
+        b.lo[k] = std::min(b.lo[k], c.lo[k]);
+        b.hi[k] = std::max(b.hi[k], c.hi[k]);
+      }
+    }
+    if (has1) {
+      Bounds c = walk(n.child1, depth + 1);
+      for (int k = 0; k < 3; k++) {
+        if (c.lo[k] < lo1[k] || c.hi[k] > hi1[k]) {
+          ok = false;
+          why = "child 1 box does not contain its subtree";
+        }
+        b.lo[k] = std::min(b.lo[k], c.lo[k]);
+        b.hi[k] = std::max(b.hi[k], c.hi[k]);
+      }
+    }
+    return b;
+  };
+  walk(0, 0);
+  if (!ok) return say(why);
+  for (uint32_t i = 0; i < d->numTriangles; i++)
+    if (!covered[i]) return say("a leaf-order triangle is not referenced by any leaf");
   return BDPT_OK;
 }
 

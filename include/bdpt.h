@@ -242,6 +242,12 @@ int bdpt_set_scene(bdpt_ctx* ctx, const bdpt_scene_desc* scene);
 int bdpt_get_bvh_info(const bdpt_ctx* ctx, bdpt_bvh_info* out);
 int bdpt_set_camera(bdpt_ctx* ctx, const bdpt_camera* cam);
 
+/* Host-only (no GPU, no context): run the acceleration-structure builder on a scene and check
+ * its invariants — every triangle in exactly one leaf, every child box contains its subtree,
+ * depth within the traversal stack.  Returns BDPT_OK and fills *out, or BDPT_E_INVALID with the
+ * first violated invariant in msg (msgCap bytes, may be NULL). */
+int bdpt_bvh_build_check(const bdpt_scene_desc* scene, bdpt_bvh_info* out, char* msg, uint32_t msgCap);
+
 /* Camera::calculateCameraParameters (Graphics/Camera/Camera.cpp:129-136) with
  * fovY = focalLengthToFovY (Utils/Math/FalcorMath.h:148-151).  Host-only helper. */
 int bdpt_camera_look_at(const float pos[3], const float target[3], const float up[3], float focalLengthMm,

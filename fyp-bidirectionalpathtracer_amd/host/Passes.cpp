@@ -1,0 +1,532 @@
+// Passes.cpp — host mirror of the reference's pass framework and passes over the C ABI.
+#include "Passes.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace bdpt {
+
+// ------------------------------------------------------------------------------------------------
+// HostTypes
+// ------------------------------------------------------------------------------------------------
+static uint16_t floatToHalf(float f) {  // round to nearest even, as the device does for the G-buffer
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | (ax > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (ax < 0x33000001u) return (uint16_t)sign;
+  int e = (int)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+  int shift = (e < -14) ? (13 + (-14 - e)) : 13;
+  uint32_t he = (e < -14) ? 0u : (uint32_t)(e + 15);
+  uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  return (uint16_t)(sign | ((he == 0) ? q : (((he - 1) << 10) + q)));
+}
+static float halfToFloat(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+  if (e == 0) {
+    float v = (float)m * 5.9604644775390625e-08f;
+    std::memcpy(&x, &v, 4);
+    x |= sign;
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+Texture::SharedPtr Texture::create2D(uint32_t w, uint32_t h, ResourceFormat fmt) {
+  SharedPtr t(new Texture());
+  t->mW = w;
+  t->mH = h;
+  t->mFormat = fmt;
+  if (hipMalloc(&t->mData, std::max<size_t>(t->getSizeInBytes(), 16)) != hipSuccess) return nullptr;
+  (void)hipMemset(t->mData, 0, t->getSizeInBytes());
+  return t;
+}
+Texture::~Texture() {
+  if (mData) (void)hipFree(mData);
+}
+void Texture::clear(const vec4& c, hipStream_t stream) {
+  if (c.x == 0 && c.y == 0 && c.z == 0 && c.w == 0) {
+    (void)hipMemsetAsync(mData, 0, getSizeInBytes(), stream);
+    return;
+  }
+  const size_t n = (size_t)mW * mH;
+  if (mFormat == ResourceFormat::RGBA32Float) {
+    std::vector<float> host(n * 4);
+    for (size_t i = 0; i < n; i++) {
+      host[i * 4] = c.x;
+      host[i * 4 + 1] = c.y;
+      host[i * 4 + 2] = c.z;
+      host[i * 4 + 3] = c.w;
+    }
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(mData, host.data(), host.size() * 4, hipMemcpyHostToDevice);
+  } else {
+    std::vector<uint16_t> host(n * 4);
+    const uint16_t q[4] = {floatToHalf(c.x), floatToHalf(c.y), floatToHalf(c.z), floatToHalf(c.w)};
+    for (size_t i = 0; i < n * 4; i++) host[i] = q[i & 3];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(mData, host.data(), host.size() * 2, hipMemcpyHostToDevice);
+  }
+}
+std::vector<float> Texture::download(hipStream_t stream) const {
+  (void)hipStreamSynchronize(stream);
+  const size_t n = (size_t)mW * mH * 4;
+  std::vector<float> out(n);
+  if (mFormat == ResourceFormat::RGBA32Float) {
+    (void)hipMemcpy(out.data(), mData, n * 4, hipMemcpyDeviceToHost);
+  } else {
+    std::vector<uint16_t> raw(n);
+    (void)hipMemcpy(raw.data(), mData, n * 2, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < n; i++) out[i] = halfToFloat(raw[i]);
+  }
+  return out;
+}
+
+bool Gui::addIntVar(const char* name, int32_t& v, int lo, int hi) {
+  log.push_back(std::string("int:") + name);
+  auto it = overrides.find(name);
+  if (it == overrides.end()) return false;
+  int32_t nv = (int32_t)it->second;
+  nv = nv < lo ? lo : (nv > hi ? hi : nv);
+  bool changed = nv != v;
+  v = nv;
+  return changed;
+}
+bool Gui::addFloatVar(const char* name, float& v, float lo, float hi, float, bool) {
+  log.push_back(std::string("float:") + name);
+  auto it = overrides.find(name);
+  if (it == overrides.end()) return false;
+  float nv = (float)it->second;
+  nv = nv < lo ? lo : (nv > hi ? hi : nv);
+  bool changed = nv != v;
+  v = nv;
+  return changed;
+}
+bool Gui::addCheckBox(const char* name, bool& v, bool) {
+  log.push_back(std::string("check:") + name);
+  auto it = overrides.find(name);
+  if (it == overrides.end()) return false;
+  bool nv = it->second != 0.0;
+  bool changed = nv != v;
+  v = nv;
+  return changed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ResourceManager (SharedUtils/ResourceManager.cpp:22-241)
+// ------------------------------------------------------------------------------------------------
+const std::string ResourceManager::kOutputChannel = "PipelineOutput";
+const std::string ResourceManager::kEnvironmentMap = "EnvironmentMap";
+const BindFlags ResourceManager::kDefaultFlags = BindFlags::ShaderResource | BindFlags::UnorderedAccess | BindFlags::RenderTarget;
+
+int32_t ResourceManager::getTextureIndex(const std::string& channelName) const {
+  for (size_t i = 0; i < mTextureNames.size(); i++)
+    if (mTextureNames[i] == channelName) return (int32_t)i;
+  return -1;
+}
+std::string ResourceManager::getTextureName(int32_t i) { return (i < 0 || i >= (int32_t)mTextureNames.size()) ? "" : mTextureNames[(size_t)i]; }
+
+int32_t ResourceManager::requestTextureResource(const std::string& channelName, ResourceFormat channelFormat, BindFlags usageFlags,
+                                                int32_t channelWidth, int32_t channelHeight) {
+  int32_t existingIndex = getTextureIndex(channelName);
+  if (existingIndex >= 0) {
+    // conflicting needs: the first requester's format / size stands (ResourceManager.cpp:218-221)
+    if (channelFormat != mTextureFormat[(size_t)existingIndex]) return -1;
+    if (mTextureSizes[(size_t)existingIndex] != ivec2{channelWidth, channelHeight}) return -1;
+    mTextureFlags[(size_t)existingIndex] |= usageFlags;
+    return existingIndex;
+  }
+  existingIndex = int32_t(mTextures.size());
+  mTextures.push_back(nullptr);  // created in initializeResources()
+  mTextureSizes.push_back(ivec2{channelWidth, channelHeight});
+  mTextureNames.push_back(channelName);
+  mTextureFlags.push_back(usageFlags);
+  mTextureFormat.push_back(channelFormat);
+  mUpdatedFlag = true;
+  return existingIndex;
+}
+void ResourceManager::requestTextureResources(const std::vector<std::string>& names, ResourceFormat f, BindFlags fl, int32_t w, int32_t h) {
+  for (const std::string& n : names) requestTextureResource(n, f, fl, w, h);
+}
+int32_t ResourceManager::manageTextureResource(const std::string& channelName, Texture::SharedPtr tex) {
+  if (!tex) return -1;
+  int32_t idx = getTextureIndex(channelName);
+  if (idx < 0) {
+    idx = int32_t(mTextures.size());
+    mTextures.push_back(tex);
+    mTextureNames.push_back(channelName);
+    mTextureSizes.push_back(ivec2{(int)tex->getWidth(), (int)tex->getHeight()});
+    mTextureFlags.push_back(kDefaultFlags);
+    mTextureFormat.push_back(tex->getFormat());
+  } else {
+    mTextures[(size_t)idx] = tex;
+    mTextureSizes[(size_t)idx] = ivec2{(int)tex->getWidth(), (int)tex->getHeight()};
+    mTextureFormat[(size_t)idx] = tex->getFormat();
+  }
+  mUpdatedFlag = true;
+  return idx;
+}
+Texture::SharedPtr ResourceManager::getTexture(int32_t i) { return (i < 0 || i >= (int32_t)mTextures.size()) ? nullptr : mTextures[(size_t)i]; }
+Texture::SharedPtr ResourceManager::getTexture(const std::string& n) { return getTexture(getTextureIndex(n)); }
+Texture::SharedPtr ResourceManager::getClearedTexture(const std::string& n, const vec4& c) { return getClearedTexture(getTextureIndex(n), c); }
+Texture::SharedPtr ResourceManager::getClearedTexture(int32_t i, const vec4& c) {
+  Texture::SharedPtr t = getTexture(i);
+  if (!t) return nullptr;
+  t->clear(c, mpContext->getStream());
+  return t;
+}
+void ResourceManager::clearTexture(Texture::SharedPtr& tex, const vec4& c) {
+  if (tex) tex->clear(c, mpContext->getStream());
+}
+bool ResourceManager::updateEnvironmentMap(const std::string& filename) {
+  if (filename != "" && filename != "Black") return false;  // image files: out of scope (no loader, HDR blob absent)
+  Texture::SharedPtr tmpEnv = Texture::create2D(128, 128, ResourceFormat::RGBA32Float);
+  if (!tmpEnv) return false;
+  tmpEnv->clear(filename == "" ? vec4{0.5f, 0.5f, 0.8f, 1.0f} : vec4{0.0f, 0.0f, 0.0f, 1.0f}, mpContext->getStream());
+  manageTextureResource(kEnvironmentMap, tmpEnv);
+  mEnvMapFilename = filename;
+  return true;
+}
+uvec2 ResourceManager::getEnvironmentMapSize() const {
+  int32_t i = getTextureIndex(kEnvironmentMap);
+  if (i < 0) return uvec2{0, 0};
+  return uvec2{(uint32_t)mTextureSizes[(size_t)i].x, (uint32_t)mTextureSizes[(size_t)i].y};
+}
+void ResourceManager::initializeResources() {
+  for (size_t i = 0; i < mTextures.size(); i++) {
+    uint32_t w = mTextureSizes[i].x <= 0 ? mWidth : (uint32_t)mTextureSizes[i].x;
+    uint32_t h = mTextureSizes[i].y <= 0 ? mHeight : (uint32_t)mTextureSizes[i].y;
+    if (!mTextures[i]) mTextures[i] = Texture::create2D(w, h, mTextureFormat[i]);
+  }
+  mIsInitialized = true;
+  mUpdatedFlag = true;
+}
+void ResourceManager::resize(uint32_t width, uint32_t height) {
+  if (width == mWidth && height == mHeight && mIsInitialized) return;
+  mWidth = width;
+  mHeight = height;
+  if (mWidth == 0 || mHeight == 0) return;
+  if (!mIsInitialized) initializeResources();
+  for (size_t i = 0; i < mTextures.size(); i++) {
+    if (mTextureSizes[i] != ivec2{-1, -1}) continue;
+    if (mTextures[i] && mTextures[i]->getWidth() == mWidth && mTextures[i]->getHeight() == mHeight) continue;
+    mTextures[i] = Texture::create2D(mWidth, mHeight, mTextureFormat[i]);
+  }
+  mUpdatedFlag = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RenderPass trampolines (SharedUtils/RenderPass.cpp:26-62)
+// ------------------------------------------------------------------------------------------------
+bool RenderPass::onInitialize(RenderContext* ctx, ResourceManager::SharedPtr rm) {
+  mIsInitialized = initialize(ctx, rm);
+  return mIsInitialized;
+}
+void RenderPass::onExecute(RenderContext* ctx) {
+  mRefreshFlag = false;
+  execute(ctx);
+}
+void RenderPass::onShutdown() {
+  if (mIsInitialized) shutdown();
+  mIsInitialized = false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RayLaunch: one bdpt_ctx per device, shared by the passes
+// ------------------------------------------------------------------------------------------------
+RayLaunch::SharedPtr RayLaunch::create(RenderContext* ctx) {
+  static std::map<int, std::weak_ptr<RayLaunch>> perDevice;
+  const int dev = ctx ? ctx->getDevice() : 0;
+  if (auto sp = perDevice[dev].lock()) return sp;
+  SharedPtr r(new RayLaunch());
+  if (bdpt_create(dev, &r->mCtx) != BDPT_OK) {
+    std::fprintf(stderr, "[RayLaunch] bdpt_create(%d) failed: no usable HIP device\n", dev);
+    return nullptr;
+  }
+  perDevice[dev] = r;
+  return r;
+}
+RayLaunch::~RayLaunch() {
+  if (mCtx) bdpt_destroy(mCtx);
+}
+const char* RayLaunch::lastError() const { return bdpt_last_error(mCtx); }
+void RayLaunch::setScene(Scene::SharedPtr pScene) {
+  if (!pScene || !mCtx) return;
+  if (pScene == mpScene && mSceneSet) return;
+  mpScene = pScene;
+  pScene->addDefaultLightIfNone();  // SceneLoaderWrapper.cpp:71-78
+  bdpt_scene_desc d;
+  pScene->getDesc(&d);
+  mSceneSet = bdpt_set_scene(mCtx, &d) == BDPT_OK;
+  if (!mSceneSet) std::fprintf(stderr, "[RayLaunch] bdpt_set_scene failed: %s\n", lastError());
+}
+bool RayLaunch::ensureSize(uint32_t w, uint32_t h) {
+  if (!mCtx) return false;
+  if (w == mW && h == mH && mSizedDepth == mMaxDepth) return true;
+  bdpt_tile tile{0, h};
+  if (bdpt_resize(mCtx, w, h, tile, mMaxDepth) != BDPT_OK) {
+    std::fprintf(stderr, "[RayLaunch] bdpt_resize failed: %s\n", lastError());
+    return false;
+  }
+  mW = w;
+  mH = h;
+  mSizedDepth = mMaxDepth;
+  return true;
+}
+
+static bool fillGBuffer(ResourceManager& rm, bdpt_gbuffer& gb) {
+  Texture::SharedPtr p = rm.getTexture("WorldPosition"), n = rm.getTexture("WorldNormal"), d = rm.getTexture("MaterialDiffuse"),
+                     s = rm.getTexture("MaterialSpecRough"), x = rm.getTexture("MaterialExtraParams"), e = rm.getTexture("Emissive");
+  if (!p || !n || !d || !s || !x || !e) return false;
+  // formats fixed by the first requester (LightProbeGBufferPass.cpp:46-51): position 32F, the rest 16F
+  if (p->getFormat() != ResourceFormat::RGBA32Float) return false;
+  for (Texture::SharedPtr t : {n, d, s, x, e})
+    if (t->getFormat() != ResourceFormat::RGBA16Float) return false;
+  gb.worldPosition = (float*)p->getDevicePointer();
+  gb.worldNormal = (uint16_t*)n->getDevicePointer();
+  gb.materialDiffuse = (uint16_t*)d->getDevicePointer();
+  gb.materialSpecRough = (uint16_t*)s->getDevicePointer();
+  gb.materialExtraParams = (uint16_t*)x->getDevicePointer();
+  gb.emissive = (uint16_t*)e->getDevicePointer();
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LightProbeGBufferPass (CommonPasses/LightProbeGBufferPass.cpp:41-161)
+// ------------------------------------------------------------------------------------------------
+bool LightProbeGBufferPass::initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) {
+  mpResManager = pResManager;
+  mpResManager->requestTextureResource("WorldPosition");
+  mpResManager->requestTextureResource("WorldNormal", ResourceFormat::RGBA16Float);
+  mpResManager->requestTextureResource("MaterialDiffuse", ResourceFormat::RGBA16Float);
+  mpResManager->requestTextureResource("MaterialSpecRough", ResourceFormat::RGBA16Float);
+  mpResManager->requestTextureResource("MaterialExtraParams", ResourceFormat::RGBA16Float);
+  mpResManager->requestTextureResource("Emissive", ResourceFormat::RGBA16Float);
+  mpRays = RayLaunch::create(pRenderContext);
+  if (!mpRays) return false;
+  if (mpScene) mpRays->setScene(mpScene);
+  setGuiSize(ivec2{250, 220});
+  return true;
+}
+void LightProbeGBufferPass::initScene(RenderContext*, Scene::SharedPtr pScene) {
+  mpScene = pScene;
+  if (mpRays) mpRays->setScene(mpScene);
+}
+void LightProbeGBufferPass::renderGui(Gui* pGui) {
+  int dirty = 0;
+  dirty |= (int)pGui->addCheckBox(mUseThinLens ? "Using thin lens model" : "Using pinhole camera model", mUseThinLens);
+  if (mUseThinLens) {
+    dirty |= (int)pGui->addFloatVar("f stop", mFStop, 1.0f, 128.0f, 0.01f, true);
+    dirty |= (int)pGui->addFloatVar("f plane", mFocalLength, 0.01f, 3.4e38f, 0.01f, true);
+  }
+  dirty |= (int)pGui->addCheckBox(mUseJitter ? "Using camera jitter" : "No camera jitter", mUseJitter);
+  if (dirty) setRefreshFlag();
+}
+void LightProbeGBufferPass::execute(RenderContext* pRenderContext) {
+  if (!mpRays || !mpRays->readyToRender()) return;
+  const vec4 zero{0, 0, 0, 0};
+  Texture::SharedPtr wsPos = mpResManager->getClearedTexture("WorldPosition", zero);
+  mpResManager->getClearedTexture("WorldNormal", zero);
+  mpResManager->getClearedTexture("MaterialDiffuse", zero);
+  mpResManager->getClearedTexture("MaterialSpecRough", zero);
+  mpResManager->getClearedTexture("MaterialExtraParams", zero);
+  mpResManager->getClearedTexture("Emissive", zero);
+  bdpt_gbuffer gb;
+  if (!wsPos || !fillGBuffer(*mpResManager, gb)) return;
+  if (!mpRays->ensureSize(wsPos->getWidth(), wsPos->getHeight())) return;
+  Camera::SharedPtr cam = mpScene->getActiveCamera();
+  cam->setAspectRatio((float)wsPos->getWidth() / (float)wsPos->getHeight());  // SceneLoaderWrapper.cpp:98
+  bdpt_set_camera(mpRays->ctx(), &cam->getData());
+
+  mLensRadius = mFocalLength / (2.0f * mFStop);
+  bdpt_gbuffer_params gp;
+  std::memset(&gp, 0, sizeof(gp));
+  Texture::SharedPtr env = mpResManager->getTexture(ResourceManager::kEnvironmentMap);
+  gp.envMap = env ? (const float*)env->getDevicePointer() : nullptr;
+  gp.envWidth = env ? env->getWidth() : 0;
+  gp.envHeight = env ? env->getHeight() : 0;
+  gp.envColor[0] = 0.5f;
+  gp.envColor[1] = 0.5f;
+  gp.envColor[2] = 0.8f;
+  gp.envColor[3] = 1.0f;
+  gp.useThinLens = mUseThinLens ? 1u : 0u;
+  gp.frameCount = mFrameCount;
+  gp.lensRadius = mLensRadius;
+  gp.focalLen = mFocalLength;
+  if (mUseJitter) {
+    bdpt_msaa_jitter(mFrameCount, gp.pixelJitter);  // kMSAA[(mFrameCount after ++) % 8], LightProbeGBufferPass.cpp:140-147
+    cam->setJitter((gp.pixelJitter[0] - 0.5f) / (float)wsPos->getWidth(), (gp.pixelJitter[1] - 0.5f) / (float)wsPos->getHeight());
+  } else {
+    gp.pixelJitter[0] = gp.pixelJitter[1] = 0.5f;
+    cam->setJitter(0, 0);
+  }
+  mFrameCount++;
+  if (bdpt_gbuffer_execute(mpRays->ctx(), &gp, &gb, pRenderContext->getStream()) != BDPT_OK)
+    std::fprintf(stderr, "[LightProbeGBufferPass] %s\n", mpRays->lastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// BDPTPass (BidirectionalPathtracing/Passes/BDPTPass.cpp:23-107)
+// ------------------------------------------------------------------------------------------------
+bool BDPTPass::initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) {
+  mpResManager = pResManager;
+  // default-format requests lose against the G-buffer pass's RGBA16F ones and return -1, as in the reference
+  mpResManager->requestTextureResources({"WorldPosition", "WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams", "Emissive"});
+  mpResManager->requestTextureResource(mOutputTextureName);
+  mpResManager->requestTextureResource(ResourceManager::kEnvironmentMap);
+  mpResManager->setDefaultSceneName("Data/pink_room/pink_room.fscene");
+  mpRays = RayLaunch::create(pRenderContext);
+  if (!mpRays) return false;
+  mpRays->setMaxRecursionDepth(uint32_t(mMaxPossibleRayDepth));
+  if (mpScene) mpRays->setScene(mpScene);
+  return true;
+}
+void BDPTPass::initScene(RenderContext*, Scene::SharedPtr pScene) {
+  mpScene = pScene;
+  if (mpRays) mpRays->setScene(mpScene);
+}
+void BDPTPass::renderGui(Gui* pGui) {
+  int dirty = 0;
+  dirty |= (int)pGui->addIntVar("Max Ray Depth", mUserSpecifiedRayDepth, 0, mMaxPossibleRayDepth);
+  dirty |= (int)pGui->addIntVar("Material", mMaterialIndex, 0, mNumOfMaterials - 1);
+  dirty |= (int)pGui->addFloatVar("Clamping Upper Bound", mClampUpper, 0.001f, 1.0f);
+  dirty |= (int)pGui->addFloatVar("Refractive Index (only for dielectric material)", mRefractiveIndex, 0.1f, 5.0f);
+  if (dirty) setRefreshFlag();
+}
+void BDPTPass::execute(RenderContext* pRenderContext) {
+  Texture::SharedPtr pDstTex = mpResManager->getTexture(mOutputTextureName);  // cleared by bdpt_execute itself
+  if (!pDstTex || !mpRays || !mpRays->readyToRender()) return;                 // silent no-op, BDPTPass.cpp:76
+  bdpt_gbuffer gb;
+  if (!fillGBuffer(*mpResManager, gb)) return;
+  if (!mpRays->ensureSize(pDstTex->getWidth(), pDstTex->getHeight())) return;
+  bdpt_params p;
+  std::memset(&p, 0, sizeof(p));
+  p.minT = mpResManager->getMinTDist();
+  p.frameCount = mFrameCount;
+  p.maxDepth = (uint32_t)mUserSpecifiedRayDepth;
+  p.emitMult = 1.0f;
+  p.matIndex = (uint32_t)mMaterialIndex;
+  p.clampUpper = mClampUpper;
+  p.refractiveIndex = mRefractiveIndex;
+  p.flags = mParamFlags;
+  bdpt_msaa_jitter(mFrameCount, p.pixelJitter);  // kMSAA[(mFrameCount after ++) % 8], BDPTPass.cpp:81,97-101
+  mFrameCount++;
+  Camera::SharedPtr cam = mpScene->getActiveCamera();
+  cam->setJitter((p.pixelJitter[0] - 0.5f) / (float)pDstTex->getWidth(), (p.pixelJitter[1] - 0.5f) / (float)pDstTex->getHeight());
+  bdpt_set_camera(mpRays->ctx(), &cam->getData());
+  if (bdpt_execute(mpRays->ctx(), &p, &gb, (float*)pDstTex->getDevicePointer(), pRenderContext->getStream()) != BDPT_OK)
+    std::fprintf(stderr, "[BDPTPass] %s\n", mpRays->lastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// SimpleAccumulationPass (CommonPasses/SimpleAccumulationPass.cpp:24-140)
+// ------------------------------------------------------------------------------------------------
+bool SimpleAccumulationPass::initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) {
+  if (!pResManager) return false;
+  mpResManager = pResManager;
+  mpResManager->requestTextureResource(mAccumChannel);
+  mpRays = RayLaunch::create(pRenderContext);
+  setGuiSize(ivec2{250, 135});
+  return mpRays != nullptr;
+}
+void SimpleAccumulationPass::initScene(RenderContext*, Scene::SharedPtr pScene) {
+  mAccumCount = 0;
+  mpScene = pScene;
+  if (mpScene && mpScene->getActiveCamera()) {
+    mpScene->getActiveCamera()->getData();
+    mLastCameraVersion = mpScene->getActiveCamera()->getViewVersion();
+  }
+}
+void SimpleAccumulationPass::resize(uint32_t width, uint32_t height) {
+  mpLastFrame = Texture::create2D(width, height, ResourceFormat::RGBA32Float);
+  mAccumCount = 0;
+}
+void SimpleAccumulationPass::renderGui(Gui* pGui) {
+  pGui->addText((std::string("Accumulating buffer:   ") + mAccumChannel).c_str());
+  if (pGui->addCheckBox(mDoAccumulation ? "Accumulating samples temporally" : "No temporal accumulation", mDoAccumulation)) {
+    mAccumCount = 0;
+    setRefreshFlag();
+  }
+  (void)pGui->addIntVar("Max frames to accumulate", mCountLimit, 1, mMaxCountLimit);
+  pGui->addText((std::string("Frames accumulated: ") + std::to_string(mAccumCount)).c_str());
+}
+bool SimpleAccumulationPass::hasCameraMoved() {
+  if (!mpScene || !mpScene->getActiveCamera()) return false;
+  mpScene->getActiveCamera()->getData();  // refresh the basis if a setter marked it dirty
+  return mLastCameraVersion != mpScene->getActiveCamera()->getViewVersion();
+}
+void SimpleAccumulationPass::execute(RenderContext* pRenderContext) {
+  Texture::SharedPtr inputTexture = mpResManager->getTexture(mAccumChannel);
+  if (!inputTexture || !mDoAccumulation || !mpLastFrame || !mpRays) return;
+  if (hasCameraMoved()) {
+    mAccumCount = 0;
+    mLastCameraVersion = mpScene->getActiveCamera()->getViewVersion();
+  }
+  const uint32_t gAccumCount = (int32_t)mAccumCount < mCountLimit ? mAccumCount++ : (uint32_t)mCountLimit;
+  bdpt_accumulate(mpRays->ctx(), (float*)mpLastFrame->getDevicePointer(), (float*)inputTexture->getDevicePointer(), gAccumCount,
+                  (uint32_t)mCountLimit, (uint64_t)inputTexture->getWidth() * inputTexture->getHeight(), pRenderContext->getStream());
+}
+void SimpleAccumulationPass::stateRefreshed() { mAccumCount = 0; }
+
+// ------------------------------------------------------------------------------------------------
+// RenderingPipeline (headless subset of SharedUtils/RenderingPipeline.cpp)
+// ------------------------------------------------------------------------------------------------
+RenderingPipeline::RenderingPipeline(uint32_t width, uint32_t height, int device) : mContext(device, nullptr), mWidth(width), mHeight(height) {
+  (void)hipSetDevice(device);
+  mpResourceManager = ResourceManager::create(width, height, &mContext);
+}
+RenderingPipeline::~RenderingPipeline() {
+  for (auto& p : mActivePasses)
+    if (p) p->onShutdown();
+  mActivePasses.clear();
+}
+void RenderingPipeline::setPass(uint32_t passNum, RenderPass::SharedPtr pTargetPass) {
+  if (mActivePasses.size() <= passNum) mActivePasses.resize(passNum + 1);
+  mActivePasses[passNum] = pTargetPass;
+}
+bool RenderingPipeline::initialize(Scene::SharedPtr pScene) {
+  mpScene = pScene;
+  mpResourceManager->requestTextureResource(ResourceManager::kOutputChannel);
+  mpResourceManager->updateEnvironmentMap("");  // the HDR probe blob is absent: default constant environment
+  for (auto& p : mActivePasses) {
+    if (!p) continue;
+    if (!p->onInitialize(&mContext, mpResourceManager)) p = nullptr;  // a failing pass is dropped (RenderingPipeline.cpp:58-59)
+  }
+  mpResourceManager->initializeResources();
+  bool any = false;
+  for (auto& p : mActivePasses) {
+    if (!p) continue;
+    any = true;
+    p->onResize(mWidth, mHeight);
+    if (pScene) p->onInitScene(&mContext, pScene);
+  }
+  return any;
+}
+void RenderingPipeline::applyGui(Gui* pGui) {
+  for (auto& p : mActivePasses)
+    if (p) p->onRenderGui(pGui);
+}
+void RenderingPipeline::renderFrame() {
+  bool refresh = false;
+  for (auto& p : mActivePasses) refresh |= (p && p->isRefreshFlagSet());
+  if (refresh)
+    for (auto& p : mActivePasses)
+      if (p) p->onStateRefresh();  // RenderingPipeline.cpp:635-663
+  for (auto& p : mActivePasses)
+    if (p) p->onExecute(&mContext);
+}
+std::vector<float> RenderingPipeline::readOutput() {
+  Texture::SharedPtr t = mpResourceManager->getTexture(ResourceManager::kOutputChannel);
+  return t ? t->download(mContext.getStream()) : std::vector<float>();
+}
+
+}  // namespace bdpt

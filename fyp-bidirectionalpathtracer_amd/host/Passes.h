@@ -1,0 +1,145 @@
+// Passes.h — the three passes of the reference pipeline that sit on the hot path, with the
+// reference's class names, factories and GUI-exposed state:
+//   LightProbeGBufferPass   CommonPasses/LightProbeGBufferPass.{h,cpp}
+//   BDPTPass                BidirectionalPathtracing/Passes/BDPTPass.{h,cpp}
+//   SimpleAccumulationPass  CommonPasses/SimpleAccumulationPass.{h,cpp}
+// plus RayLaunch, the thin launch wrapper they hold (SharedUtils/RayLaunch.h:85-135): here it owns
+// one bdpt_ctx and forwards to the C ABI of include/bdpt.h instead of building a DXR state object.
+#pragma once
+#include "../../include/bdpt.h"
+#include "RenderPass.h"
+
+namespace bdpt {
+
+// One bdpt_ctx shared by the passes of a pipeline (they trace the same scene on the same device).
+class RayLaunch {
+ public:
+  using SharedPtr = std::shared_ptr<RayLaunch>;
+  // All passes created for one device share the same launcher (and so the same BVH).
+  static SharedPtr create(RenderContext* ctx);
+  ~RayLaunch();
+  void setScene(Scene::SharedPtr pScene);           // RayLaunch::setScene -> bdpt_set_scene (BVH build)
+  void setMaxRecursionDepth(uint32_t d) { mMaxDepth = d; }
+  bool readyToRender() const { return mCtx && mSceneSet; }
+  // (re)size the per-pixel path state; called by execute when the screen size changed
+  bool ensureSize(uint32_t w, uint32_t h);
+  bdpt_ctx* ctx() const { return mCtx; }
+  Scene::SharedPtr scene() const { return mpScene; }
+  const char* lastError() const;
+
+ private:
+  RayLaunch() = default;
+  bdpt_ctx* mCtx = nullptr;
+  Scene::SharedPtr mpScene;
+  bool mSceneSet = false;
+  uint32_t mW = 0, mH = 0, mMaxDepth = 8, mSizedDepth = 0;
+};
+
+class LightProbeGBufferPass : public RenderPass {
+ public:
+  using SharedPtr = std::shared_ptr<LightProbeGBufferPass>;
+  static SharedPtr create() { return SharedPtr(new LightProbeGBufferPass()); }
+
+ protected:
+  LightProbeGBufferPass() : RenderPass("G-Buf With Light Probe", "G-Buffer With Light Probe Options") {}
+  bool initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) override;
+  void execute(RenderContext* pRenderContext) override;
+  void renderGui(Gui* pGui) override;
+  void initScene(RenderContext* pRenderContext, Scene::SharedPtr pScene) override;
+  bool requiresScene() override { return true; }
+  bool usesRayTracing() override { return true; }
+  bool usesEnvironmentMap() override { return true; }
+
+  RayLaunch::SharedPtr mpRays;
+  Scene::SharedPtr mpScene;
+  bool mUseThinLens = false;
+  float mFStop = 32.0f, mFocalLength = 1.0f, mLensRadius = 0.0f;
+  bool mUseJitter = true, mUseRandomJitter = false;  // random jitter (std::mt19937 seeded by time) is not reproduced
+  uint32_t mFrameCount = 0xdeadbeefu;
+};
+
+class BDPTPass : public RenderPass {
+ public:
+  using SharedPtr = std::shared_ptr<BDPTPass>;
+  static SharedPtr create(const std::string& outChannel) { return SharedPtr(new BDPTPass(outChannel)); }
+  // build-only switches (BDPT_PARAM_*), default 0 = reference behaviour
+  void setParamFlags(uint32_t f) { mParamFlags = f; }
+
+ protected:
+  BDPTPass(const std::string& outChannel) : RenderPass("Bidirectional Pathtracer", "BDPT Options"), mOutputTextureName(outChannel) {}
+  bool initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) override;
+  void initScene(RenderContext* pRenderContext, Scene::SharedPtr pScene) override;
+  void execute(RenderContext* pRenderContext) override;
+  void renderGui(Gui* pGui) override;
+  bool requiresScene() override { return true; }
+  bool usesRayTracing() override { return true; }
+
+  RayLaunch::SharedPtr mpRays;
+  Scene::SharedPtr mpScene;
+  int32_t mUserSpecifiedRayDepth = 3;
+  const int32_t mMaxPossibleRayDepth = 8;
+  int32_t mMaterialIndex = 0;
+  const int32_t mNumOfMaterials = 2;
+  float mClampUpper = 0.9f;
+  float mRefractiveIndex = 1.0f;
+  std::string mOutputTextureName;
+  uint32_t mFrameCount = 0x1337u;
+  uint32_t mParamFlags = 0;
+};
+
+class SimpleAccumulationPass : public RenderPass {
+ public:
+  using SharedPtr = std::shared_ptr<SimpleAccumulationPass>;
+  static SharedPtr create(const std::string& bufferToAccumulate) { return SharedPtr(new SimpleAccumulationPass(bufferToAccumulate)); }
+  uint32_t getAccumCount() const { return mAccumCount; }
+
+ protected:
+  SimpleAccumulationPass(const std::string& bufferToAccumulate) : RenderPass("Accumulation Pass", "Accumulation Options") {
+    mAccumChannel = bufferToAccumulate;
+  }
+  bool initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) override;
+  void initScene(RenderContext* pRenderContext, Scene::SharedPtr pScene) override;
+  void execute(RenderContext* pRenderContext) override;
+  void renderGui(Gui* pGui) override;
+  void resize(uint32_t width, uint32_t height) override;
+  void stateRefreshed() override;
+  bool appliesPostprocess() override { return true; }
+  bool hasAnimation() override { return false; }
+  bool hasCameraMoved();
+
+  std::string mAccumChannel;
+  RayLaunch::SharedPtr mpRays;  // only for the context that runs bdpt_accumulate
+  Texture::SharedPtr mpLastFrame;
+  Scene::SharedPtr mpScene;
+  uint64_t mLastCameraVersion = 0;
+  bool mDoAccumulation = true;
+  uint32_t mAccumCount = 0;
+  int32_t mCountLimit = 100;
+  const int32_t mMaxCountLimit = 10000;
+};
+
+// Headless counterpart of SharedUtils/RenderingPipeline (setPass + per-frame loop,
+// RenderingPipeline.cpp:421-471, 611-695); the window, GUI rendering and final blit are out of scope.
+class RenderingPipeline {
+ public:
+  RenderingPipeline(uint32_t width, uint32_t height, int device = 0);
+  ~RenderingPipeline();
+  void setPass(uint32_t passNum, RenderPass::SharedPtr pTargetPass);
+  // onLoad (initialize every pass, drop those that fail), onFirstRun (scene), onResize
+  bool initialize(Scene::SharedPtr pScene);
+  void renderFrame();                 // onFrameRender: refresh notifications, then every pass in order
+  void applyGui(Gui* pGui);           // renderGui of every pass (scripted widget values)
+  ResourceManager::SharedPtr getResourceManager() { return mpResourceManager; }
+  RenderContext* getRenderContext() { return &mContext; }
+  std::vector<float> readOutput();    // "PipelineOutput" as RGBA32F
+  size_t getPassCount() const { return mActivePasses.size(); }
+
+ private:
+  RenderContext mContext;
+  uint32_t mWidth, mHeight;
+  ResourceManager::SharedPtr mpResourceManager;
+  std::vector<RenderPass::SharedPtr> mActivePasses;
+  Scene::SharedPtr mpScene;
+};
+
+}  // namespace bdpt

@@ -30,7 +30,7 @@ class Camera {
   void setUpVector(float3 u) { mUp = u; mDirty = true; }
   void setFocalLength(float mm) { mFocalLength = mm; mDirty = true; }
   void setFrameHeight(float mm) { mFrameHeight = mm; mDirty = true; }
-  void setAspectRatio(float a) { mAspect = a; mDirty = true; }
+  void setAspectRatio(float a) { if (a != mAspect) { mAspect = a; mDirty = true; } }
   void setFocalDistance(float d) { mFocalDistance = d; mDirty = true; }
   void setJitter(float jx, float jy) { mJitterX = jx; mJitterY = jy; }
   float3 getPosition() const { return mPos; }

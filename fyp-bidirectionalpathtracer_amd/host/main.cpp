@@ -1,0 +1,84 @@
+// main.cpp — headless counterpart of BidirectionalPathtracing/Main.cpp:9-29: the same pipeline
+// (G-buffer pass -> BDPT pass -> accumulation pass; the BMFR denoiser is off by default in the
+// reference and out of scope here), run for a number of frames, output written as a PFM image.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "Passes.h"
+
+using namespace bdpt;
+
+static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t w, uint32_t h) {
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return;
+  std::fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
+  for (int y = (int)h - 1; y >= 0; y--)  // PFM rows go bottom to top
+    for (uint32_t x = 0; x < w; x++) std::fwrite(&rgba[((size_t)y * w + x) * 4], 4, 3, f);
+  std::fclose(f);
+}
+
+int main(int argc, char** argv) {
+  std::string scene = "cornell", out = "bdpt_out.pfm", raw;
+  uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
+  int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100;
+  for (int i = 1; i < argc; i++) {
+    auto next = [&](const char* name) -> const char* {
+      if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
+      return nullptr;
+    };
+    if (const char* v = next("--scene")) scene = v;
+    else if (const char* v = next("--width")) W = (uint32_t)std::atoi(v);
+    else if (const char* v = next("--height")) H = (uint32_t)std::atoi(v);
+    else if (const char* v = next("--frames")) frames = std::atoi(v);
+    else if (const char* v = next("--depth")) depth = std::atoi(v);
+    else if (const char* v = next("--mat")) mat = std::atoi(v);
+    else if (const char* v = next("--device")) device = std::atoi(v);
+    else if (const char* v = next("--accum-limit")) accumLimit = std::atoi(v);
+    else if (const char* v = next("--out")) out = v;
+    else if (const char* v = next("--raw")) raw = v;
+    else {
+      std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium] [--width W] [--height H] [--frames N] [--depth D] "
+                           "[--mat 0|1] [--accum-limit N] [--out file.pfm] [--raw file.f32]\n");
+      return 2;
+    }
+  }
+  Scene::SharedPtr pScene = scene == "atrium" ? Scene::createAtrium(1, 262144) : Scene::createCornellBox();
+
+  // Create our rendering pipeline and add the passes, as Main.cpp:12-18 does
+  RenderingPipeline* pipeline = new RenderingPipeline(W, H, device);
+  pipeline->setPass(0, LightProbeGBufferPass::create());
+  pipeline->setPass(1, BDPTPass::create(ResourceManager::kOutputChannel));
+  pipeline->setPass(2, SimpleAccumulationPass::create(ResourceManager::kOutputChannel));
+  if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 3) {
+    std::fprintf(stderr, "pipeline initialisation failed (no GPU?)\n");
+    return 1;
+  }
+  Gui gui;  // what a user would have set in the GUI windows
+  gui.overrides["Max Ray Depth"] = depth;
+  gui.overrides["Material"] = mat;
+  gui.overrides["Max frames to accumulate"] = accumLimit;
+  pipeline->applyGui(&gui);
+
+  auto t0 = std::chrono::steady_clock::now();
+  for (int f = 0; f < frames; f++) pipeline->renderFrame();
+  pipeline->getRenderContext()->flush(true);
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<float> img = pipeline->readOutput();
+  double mean = 0;
+  for (size_t i = 0; i < img.size(); i += 4) mean += img[i] + img[i + 1] + img[i + 2];
+  std::printf("%s %ux%u depth %d mat %d: %d frames in %.2f ms (%.2f ms/frame), mean radiance %.6f\n", scene.c_str(), W, H, depth, mat,
+              frames, ms, ms / frames, mean / (3.0 * (double)(img.size() / 4)));
+  writePfm(out.c_str(), img, W, H);
+  if (!raw.empty()) {
+    FILE* f = std::fopen(raw.c_str(), "wb");
+    if (f) {
+      std::fwrite(img.data(), 4, img.size(), f);
+      std::fclose(f);
+    }
+  }
+  delete pipeline;
+  return 0;
+}

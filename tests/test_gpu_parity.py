@@ -142,3 +142,165 @@ def test_cornell_frame_bit_exact(pkg, ob, mat, depth, size):
         orc.close()
     pipe.close()
     scene.close()
+
+
+def test_cpp_host_pipeline_matches_python_pipeline(pkg, ob, tmp_path):
+    """The C++ host mirror (RenderingPipeline + LightProbeGBufferPass + BDPTPass + SimpleAccumulationPass,
+    host/bdpt_render) must produce the same accumulated image as the same frame sequence driven
+    from Python, and the first frame must equal the oracle's."""
+    import os
+    import subprocess
+    import torch
+    import __graft_entry__ as ge
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe), "host/bdpt_render not built (run __graft_entry__.build())"
+    raw = tmp_path / "out.f32"
+    size, frames = 48, 3
+    r = subprocess.run([exe, "--scene", "cornell", "--width", str(size), "--height", str(size), "--frames", str(frames),
+                        "--depth", "3", "--mat", "0", "--out", str(tmp_path / "o.pfm"), "--raw", str(raw)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cpp = np.fromfile(raw, np.float32).reshape(size, size, 4)
+    scene = pkg.Scene.cornell()
+    pipe = pkg.FramePipeline(scene, size, size, max_depth=3, mat_index=0, accum_limit=100)
+    first = None
+    for k in range(frames):
+        gp, p = pipe.render_frame(accumulate=True)
+        if k == 0:
+            torch.cuda.synchronize()
+            first = (gp, p)
+    torch.cuda.synchronize()
+    py = pipe.output.cpu().numpy()
+    assert np.array_equal(cpp.view(np.uint32), py.view(np.uint32)), np.abs(cpp - py).max()
+    # and a 1-frame C++ run against the oracle
+    r = subprocess.run([exe, "--scene", "cornell", "--width", str(size), "--height", str(size), "--frames", "1",
+                        "--depth", "3", "--mat", "0", "--out", str(tmp_path / "o.pfm"), "--raw", str(raw)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cpp1 = np.fromfile(raw, np.float32).reshape(size, size, 4)
+    orc, _ = _oracle_frame(pkg, ob, scene, pipe, first[0], first[1])
+    orc.resolve()
+    assert np.array_equal(cpp1.view(np.uint32), orc.image().view(np.uint32))
+    orc.close()
+    pipe.close()
+
+
+def test_accumulate_matches_oracle(pkg, ob, gpu_ctx):
+    import torch
+    rng = np.random.default_rng(3)
+    n = 4096
+    frames = rng.uniform(0, 2, (6, n, 4)).astype(np.float32)
+    last_g = torch.zeros(n, 4, device="cuda")
+    last_o = np.zeros((n, 4), np.float32)
+    lib = ob.load_oracle(pkg.abi)
+    for k in range(6):
+        cur_g = torch.from_numpy(frames[k]).cuda()
+        cur_o = frames[k].copy()
+        cnt = min(k, 4)
+        gpu_ctx.accumulate(C.c_void_p(last_g.data_ptr()), C.c_void_p(cur_g.data_ptr()), cnt, 4, n)
+        torch.cuda.synchronize()
+        lib.oracle_accumulate(last_o.ctypes.data, cur_o.ctypes.data, cnt, 4, n)
+        assert np.array_equal(cur_g.cpu().numpy().view(np.uint32), cur_o.view(np.uint32))
+        assert np.array_equal(last_g.cpu().numpy().view(np.uint32), last_o.view(np.uint32))
+
+
+def test_partial_stage_images_and_depths(pkg, ob):
+    """Stage-wise parity (NEE only / splat only / connect only) and depths beyond the reference's cap of 8."""
+    import torch
+    scene = pkg.Scene.cornell()
+    a = pkg.abi
+    for depth, mat, flags in ((3, 0, a.PARAM_NO_SPLAT | a.PARAM_NO_CONNECT), (3, 0, a.PARAM_NO_NEE | a.PARAM_NO_CONNECT),
+                              (4, 0, a.PARAM_NO_NEE | a.PARAM_NO_SPLAT), (5, 0, a.PARAM_SPECULAR_FROM_LOBE), (12, 1, 0),
+                              (16, 0, 0)):
+        pipe = pkg.FramePipeline(scene, 32, 24, max_depth=depth, mat_index=mat, flags=flags)
+        gp, p = pipe.render_frame()
+        torch.cuda.synchronize()
+        orc, cnt = _oracle_frame(pkg, ob, scene, pipe, gp, p)
+        orc.resolve()
+        gpu = pipe.output.cpu().numpy()
+        assert np.array_equal(gpu.view(np.uint32), orc.image().view(np.uint32)), (depth, mat, flags)
+        orc.close()
+        pipe.close()
+    scene.close()
+
+
+def test_tiled_execution_equals_full_frame(pkg, ob):
+    """Two contexts rendering two row bands with deferred resolve + summed splat buffers reproduce the
+    single-context frame bit for bit (the N>1 path of bench.py on one GPU)."""
+    import torch
+    scene = pkg.Scene.cornell()
+    W, H = 48, 40
+    full = pkg.FramePipeline(scene, W, H, max_depth=4, mat_index=0)
+    full.render_frame()
+    torch.cuda.synchronize()
+    ref = full.output.cpu().numpy()
+    bands = [(0, 17), (17, 40)]
+    pipes = [pkg.FramePipeline(scene, W, H, max_depth=4, mat_index=0, tile=b) for b in bands]
+    splats = []
+    for pp in pipes:
+        buf = torch.zeros(W * H * 4, dtype=torch.int64, device="cuda")
+        pp.ctx.set_splat_buffer(C.c_void_p(buf.data_ptr()), buf.numel())
+        pp.render_frame(extra_flags=pkg.abi.PARAM_DEFER_RESOLVE)
+        splats.append(buf)
+    torch.cuda.synchronize()
+    total = splats[0] + splats[1]
+    img = np.zeros_like(ref)
+    for pp, (y0, y1) in zip(pipes, bands):
+        pp.ctx.resolve(C.c_void_p(total.data_ptr()), 0, C.c_void_p(pp.output.data_ptr()))
+        torch.cuda.synchronize()
+        img[y0:y1] = pp.output.cpu().numpy()[y0:y1]
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    for pp in pipes + [full]:
+        pp.close()
+
+
+def test_atrium_frame_matches_oracle(pkg, ob):
+    """Textured GGX scene (sRGB textures, roughness/metal map, normal map, alpha mask, SpecGloss, spot light)."""
+    import torch
+    scene = pkg.Scene.atrium(1, 30000)
+    pipe = pkg.FramePipeline(scene, 96, 54, max_depth=5, mat_index=0)
+    gp, p = pipe.render_frame()
+    torch.cuda.synchronize()
+    orc, cnt = _oracle_frame(pkg, ob, scene, pipe, gp, p)
+    names = {"WorldPosition": "worldPosition", "WorldNormal": "worldNormal", "MaterialDiffuse": "materialDiffuse",
+             "MaterialSpecRough": "materialSpecRough", "MaterialExtraParams": "materialExtra", "Emissive": "emissive"}
+    for ch, on in names.items():
+        g = pipe.channels[ch].float().cpu().numpy().reshape(-1, 4)
+        assert np.array_equal(g.view(np.uint32), orc.chan[on].view(np.uint32)), ch
+    orc.resolve()
+    gpu = pipe.output.cpu().numpy()
+    ref = orc.image()
+    assert _rmse(gpu, ref) <= RMSE_TOL
+    assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), f"{(gpu != ref).any(axis=-1).sum()} pixels differ"
+    # the GPU path skips rays whose outcome cannot change the image; it never traces more than the reference
+    c = pipe.ctx.counters().as_dict()
+    o = cnt.as_dict()
+    assert c["raysEyeExtend"] == o["raysEyeExtend"] and c["raysLightExtend"] == o["raysLightExtend"]
+    assert c["raysSplat"] == o["raysSplat"] and c["raysNee"] <= o["raysNee"] and c["raysConnect"] <= o["raysConnect"]
+    assert c["pixelsValid"] == o["pixelsValid"] and c["splatsLanded"] == o["splatsLanded"]
+    orc.close()
+    pipe.close()
+    scene.close()
+
+
+def test_error_conventions(pkg, gpu_ctx):
+    scene = pkg.Scene.cornell()
+    ctx = pkg.Context(0)
+    p = pkg.abi.Params()
+    gb = pkg.abi.GBuffer()
+    with pytest.raises(pkg.BdptError, match="scene, camera and size"):
+        ctx.execute(p, gb, C.c_void_p(16))
+    ctx.set_scene(scene.desc)
+    ctx.set_camera(scene.camera(1.0))
+    with pytest.raises(pkg.BdptError, match="BDPT_MAX_DEPTH"):
+        ctx.resize(16, 16, 0, 16, 17)
+    with pytest.raises(pkg.BdptError, match="bad frame or tile"):
+        ctx.resize(16, 16, 8, 4, 3)
+    ctx.resize(16, 16, 0, 16, 3)
+    p.maxDepth = 4
+    with pytest.raises(pkg.BdptError):
+        ctx.execute(p, gb, C.c_void_p(16))
+    bad = pkg.abi.SceneDesc()
+    with pytest.raises(pkg.BdptError):
+        ctx.set_scene(bad)
+    ctx.close()

@@ -185,8 +185,8 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   }
   Bvh bvh;
   buildBvh(d->positions, d->indices, d->numTriangles, triFlags.data(), bvh);
-  if (bvh.maxDepth > (uint32_t)kBvhMaxDepth) {
-    fail(c, "bvh deeper than the traversal stack");
+  if (bvh.maxStack > (uint32_t)kBvhMaxStack) {
+    fail(c, "bvh needs a deeper traversal stack than the device provides");
     return BDPT_E_LIMIT;
   }
   c->bvhInfo.numNodes = (uint32_t)bvh.nodes.size();
@@ -276,7 +276,7 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   out->nodeBytes = sizeof(BvhNode);
   out->triBytes = sizeof(BvhTri);
   out->sahCost = bvh.sahCost;
-  if (bvh.maxDepth > (uint32_t)kBvhMaxDepth) return say("depth exceeds kBvhMaxDepth");
+  if (bvh.maxStack > (uint32_t)kBvhMaxStack) return say("worst-case stack exceeds kBvhMaxStack");
   if (bvh.tris.size() != d->numTriangles) return say("triangle list size");
   std::vector<uint8_t> seen(d->numTriangles, 0);
   for (const BvhTri& t : bvh.tris) {
@@ -284,22 +284,22 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
     seen[t.prim] = 1;
   }
   if (d->numTriangles == 0) return BDPT_OK;
-  // walk: returns the exact bounds of a subtree and checks them against the stored (padded) box
+  // walk: returns the exact bounds of a subtree and checks them against the decoded (quantised) box
   std::vector<uint8_t> covered(d->numTriangles, 0);
   struct Bounds {
     float lo[3], hi[3];
   };
   bool ok = true;
   std::string why;
-  std::function<Bounds(int32_t, uint32_t)> walk = [&](int32_t ref, uint32_t depth) -> Bounds {
+  std::function<Bounds(int32_t, uint32_t, uint32_t)> walk = [&](int32_t ref, uint32_t depth, uint32_t stackAbove) -> Bounds {
     Bounds b;
     for (int k = 0; k < 3; k++) {
       b.lo[k] = 1e30f;
       b.hi[k] = -1e30f;
     }
-    if (depth > (uint32_t)kBvhMaxDepth + 1) {
+    if (depth > 64) {
       ok = false;
-      why = "walk deeper than kBvhMaxDepth";
+      why = "walk deeper than 64 levels";
       return b;
     }
     if (ref < 0) {
@@ -326,34 +326,33 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
       return b;
     }
     const BvhNode& n = bvh.nodes[(size_t)ref];
-    const float lo0[3] = {n.lo0[0], n.lo0[1], n.lo0[2]}, hi0[3] = {n.hi0x, n.hi0yz[0], n.hi0yz[1]};
-    const float lo1[3] = {n.lo1xy[0], n.lo1xy[1], n.lo1z}, hi1[3] = {n.hi1[0], n.hi1[1], n.hi1[2]};
-    const bool has0 = lo0[0] <= hi0[0], has1 = lo1[0] <= hi1[0];
-    if (has0) {
-      Bounds c = walk(n.child0, depth + 1);
-      for (int k = 0; k < 3; k++) {
-        if (c.lo[k] < lo0[k] || c.hi[k] > hi0[k]) {
-          ok = false;
-          why = "child 0 box does not contain its subtree";
-        }
-        b.lo[k] = std::min(b.lo[k], c.lo[k]);
-        b.hi[k] = std::max(b.hi[k], c.hi[k]);
-      }
+    if (n.numChildren < 1 || n.numChildren > 4 || stackAbove + n.numChildren - 1 > (uint32_t)kBvhMaxStack) {
+      ok = false;
+      why = "bad child count or stack bound";
+      return b;
     }
-    if (has1) {
-      Bounds c = walk(n.child1, depth + 1);
+    for (int c = 0; c < 4; c++) {
+      if (c >= n.numChildren) {
+        for (int k = 0; k < 3; k++)
+          if (!(n.lo[k][c] == 255 && n.hi[k][c] == 0)) {
+            ok = false;
+            why = "unused child slot is not inverted";
+          }
+        continue;
+      }
+      Bounds cb = walk(n.child[c], depth + 1, stackAbove + n.numChildren - 1);
       for (int k = 0; k < 3; k++) {
-        if (c.lo[k] < lo1[k] || c.hi[k] > hi1[k]) {
+        if (cb.lo[k] < bvhDecodePlane(n, k, n.lo[k][c]) || cb.hi[k] > bvhDecodePlane(n, k, n.hi[k][c])) {
           ok = false;
-          why = "child 1 box does not contain its subtree";
+          why = "decoded child box does not contain its subtree";
         }
-        b.lo[k] = std::min(b.lo[k], c.lo[k]);
-        b.hi[k] = std::max(b.hi[k], c.hi[k]);
+        b.lo[k] = std::min(b.lo[k], cb.lo[k]);
+        b.hi[k] = std::max(b.hi[k], cb.hi[k]);
       }
     }
     return b;
   };
-  walk(0, 0);
+  walk(0, 0, 0);
   if (!ok) return say(why);
   for (uint32_t i = 0; i < d->numTriangles; i++)
     if (!covered[i]) return say("a leaf-order triangle is not referenced by any leaf");

@@ -8,16 +8,22 @@
 
 namespace bdpt {
 
-// 64-byte two-child node: both children's boxes + two child references.
+// 64-byte four-child node with child boxes quantised to 8 bits per plane relative to the node's
+// own box: plane = origin[axis] + q * 2^(exp[axis]-127).  Quantisation rounds outward, so a
+// decoded child box always contains the (already padded) exact one.  One node = four 16-byte
+// loads per lane, the same as a two-child fp32 node, for half the dependent fetches per ray.
 //   ref >= 0 : interior node index
 //   ref <  0 : leaf, -1 - ((firstTriangle << 3) | (count - 1)), count in 1..8
-// An absent child has an inverted box (lo > hi) and is never entered.
+// Unused child slots have lo = 255, hi = 0 on every axis (never entered: the slab test picks
+// near/far planes by ray direction sign, so an inverted box has tnear > tfar).
 struct alignas(16) BvhNode {
-  float lo0[3], hi0x;  // child 0: lo.xyz, hi.x
-  float hi0yz[2], lo1xy[2];
-  float lo1z, hi1[3];
-  int32_t child0, child1;
-  int32_t pad[2];
+  float origin[3];
+  uint8_t exp[3];
+  uint8_t numChildren;
+  uint8_t lo[3][4];  // [axis][child]
+  uint8_t hi[3][4];
+  uint32_t pad[2];
+  int32_t child[4];
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 bytes");
 
@@ -32,17 +38,28 @@ struct alignas(16) BvhTri {
 };
 static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
 
-constexpr int kBvhMaxDepth = 30;  // traversal stack holds 32 entries per lane
+constexpr int kBvhMaxStack = 31;  // worst-case traversal stack entries (device stack holds 32 per lane)
 constexpr uint32_t kTriNonOpaque = 1u, kTriDoubleSided = 2u;
 
 struct Bvh {
   std::vector<BvhNode> nodes;
   std::vector<BvhTri> tris;  // in leaf order
-  uint32_t maxDepth = 0;
+  uint32_t maxDepth = 0;     // depth of the four-wide tree
+  uint32_t maxStack = 0;     // worst-case number of simultaneously stacked references
   float sahCost = 0.0f;
 };
 
 // positions: 3 floats per vertex; indices: 3 per triangle; triFlags: per triangle (may be null).
 void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTriangles, const uint32_t* triFlags, Bvh& out);
+
+// Decode one quantised plane exactly as the device does.
+inline float bvhDecodePlane(const BvhNode& n, int axis, uint8_t q) {
+  union {
+    uint32_t u;
+    float f;
+  } s;
+  s.u = (uint32_t)n.exp[axis] << 23;
+  return n.origin[axis] + (float)q * s.f;
+}
 
 }  // namespace bdpt

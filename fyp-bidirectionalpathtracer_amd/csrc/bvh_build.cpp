@@ -43,6 +43,7 @@ struct TmpNode {
 constexpr int kBins = 16;
 constexpr uint32_t kLeafMax = 4;
 constexpr float kCostTraverse = 1.0f, kCostTri = 1.0f;
+constexpr int kBinaryMaxDepth = 48;  // depth budget of the intermediate binary tree
 
 inline uint32_t ceilLog2(uint32_t x) {
   uint32_t l = 0;
@@ -128,12 +129,11 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
       cb.grow(&cent[(size_t)t * 3]);
     }
     tmp[ni].box = nb;
-    out.maxDepth = std::max(out.maxDepth, depth);
     if (count <= kLeafMax) continue;
 
     // Depth budget: once the remaining levels are only just enough for a balanced split of
     // `count` triangles into leaves, stop trusting SAH and split at the median.
-    bool forceMedian = depth + ceilLog2((count + kLeafMax - 1) / kLeafMax) + 1 >= (uint32_t)kBvhMaxDepth;
+    bool forceMedian = depth + ceilLog2((count + kLeafMax - 1) / kLeafMax) + 1 >= (uint32_t)kBinaryMaxDepth;
 
     int bestAxis = -1, bestSplit = -1;
     float bestCost = 1e30f;
@@ -226,88 +226,149 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
   out.tris.resize(n);
   for (uint32_t i = 0; i < n; i++) out.tris[i] = recs[order[i]];
 
-  // Flatten: interior nodes in depth-first order (top of the tree first), each carrying its
-  // children's padded boxes.
+  // ---- collapse the binary tree into four-wide nodes and quantise the child boxes ----------------
   auto leafRef = [](uint32_t first, uint32_t count) -> int32_t { return -1 - (int32_t)((first << 3) | (count - 1)); };
-  auto writeChild = [&](BvhNode& nd, int which, const TmpNode* c, int32_t ref) {
-    float lo[3], hi[3];
-    if (c) {
-      for (int k = 0; k < 3; k++) {
-        lo[k] = c->box.lo[k] - pad;
-        hi[k] = c->box.hi[k] + pad;
-      }
-    } else {
-      lo[0] = lo[1] = lo[2] = 1e30f;
-      hi[0] = hi[1] = hi[2] = -1e30f;
-    }
-    if (which == 0) {
-      nd.lo0[0] = lo[0];
-      nd.lo0[1] = lo[1];
-      nd.lo0[2] = lo[2];
-      nd.hi0x = hi[0];
-      nd.hi0yz[0] = hi[1];
-      nd.hi0yz[1] = hi[2];
-      nd.child0 = ref;
-    } else {
-      nd.lo1xy[0] = lo[0];
-      nd.lo1xy[1] = lo[1];
-      nd.lo1z = lo[2];
-      nd.hi1[0] = hi[0];
-      nd.hi1[1] = hi[1];
-      nd.hi1[2] = hi[2];
-      nd.child1 = ref;
-    }
+  struct Wide {
+    uint32_t src;            // tmp index of the subtree root this node covers
+    uint32_t kids[4];        // tmp indices of the (up to 4) children
+    int nk;
+    uint32_t depth;
   };
   if (n == 0) {
     BvhNode nd;
     std::memset(&nd, 0, sizeof(nd));
-    writeChild(nd, 0, nullptr, -1);
-    writeChild(nd, 1, nullptr, -1);
+    for (int a = 0; a < 3; a++)
+      for (int c = 0; c < 4; c++) {
+        nd.lo[a][c] = 255;
+        nd.hi[a][c] = 0;
+      }
+    for (int c = 0; c < 4; c++) nd.child[c] = -1;
+    nd.exp[0] = nd.exp[1] = nd.exp[2] = 127;
     out.nodes.push_back(nd);
     return;
   }
-  if (tmp[0].left < 0) {  // whole scene is one leaf: wrap it in a root
-    BvhNode nd;
-    std::memset(&nd, 0, sizeof(nd));
-    writeChild(nd, 0, &tmp[0], leafRef(tmp[0].first, tmp[0].count));
-    writeChild(nd, 1, nullptr, -1);
-    out.nodes.push_back(nd);
-    out.sahCost = kCostTri * (float)n;
-    return;
-  }
-  // assign flat indices to interior tmp nodes in DFS preorder
-  std::vector<int32_t> flatIndex(tmp.size(), -1);
-  std::vector<uint32_t> stack;
-  stack.push_back(0);
-  uint32_t numInner = 0;
-  std::vector<uint32_t> preorder;
-  while (!stack.empty()) {
-    uint32_t t = stack.back();
-    stack.pop_back();
-    if (tmp[t].left < 0) continue;
-    flatIndex[t] = (int32_t)numInner++;
-    preorder.push_back(t);
-    stack.push_back((uint32_t)tmp[t].right);
-    stack.push_back((uint32_t)tmp[t].left);
-  }
-  out.nodes.resize(numInner);
-  float rootArea = tmp[0].box.area();
-  double cost = 0.0;
-  for (uint32_t t : preorder) {
-    BvhNode nd;
-    std::memset(&nd, 0, sizeof(nd));
-    const TmpNode& l = tmp[(size_t)tmp[t].left];
-    const TmpNode& r = tmp[(size_t)tmp[t].right];
-    writeChild(nd, 0, &l, l.left < 0 ? leafRef(l.first, l.count) : flatIndex[(size_t)tmp[t].left]);
-    writeChild(nd, 1, &r, r.left < 0 ? leafRef(r.first, r.count) : flatIndex[(size_t)tmp[t].right]);
-    out.nodes[(size_t)flatIndex[t]] = nd;
-    if (rootArea > 0) {
-      cost += kCostTraverse * tmp[t].box.area() / rootArea;
-      if (l.left < 0) cost += kCostTri * l.count * l.box.area() / rootArea;
-      if (r.left < 0) cost += kCostTri * r.count * r.box.area() / rootArea;
+  // Binary height of every subtree: the stack need of a subtree left two-wide is its height, so a
+  // node at stack level u may widen to k children only while u + (k-1) + max child height stays
+  // within the device stack.  Shallow subtrees (most of the nodes) become four-wide; only the few
+  // deep, skinny paths of a SAH tree keep two-wide nodes.
+  std::vector<uint16_t> height(tmp.size(), 0);
+  for (size_t t = tmp.size(); t-- > 0;)  // children are always created after their parent
+    if (tmp[t].left >= 0) height[t] = (uint16_t)(1 + std::max(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]));
+  std::vector<Wide> wide;
+  std::vector<std::pair<int32_t, int32_t>> slots;  // per wide node: where its index must be written
+  uint32_t wDepth = 0, wStack = 0;
+  {
+    struct Job {
+      uint32_t src, depth, stackAbove;
+      int32_t slotNode, slotIdx;
+    };
+    std::vector<Job> jobs;
+    jobs.push_back(Job{0, 0, 0, -1, -1});
+    while (!jobs.empty()) {
+      Job j = jobs.back();
+      jobs.pop_back();
+      Wide w;
+      w.src = j.src;
+      w.depth = j.depth;
+      w.nk = 0;
+      if (tmp[j.src].left < 0) {  // root is a single leaf
+        w.kids[w.nk++] = j.src;
+      } else {
+        w.kids[w.nk++] = (uint32_t)tmp[j.src].left;
+        w.kids[w.nk++] = (uint32_t)tmp[j.src].right;
+        while (w.nk < 4) {
+          int best = -1;
+          float bestArea = -1.0f;
+          for (int k = 0; k < w.nk; k++)
+            if (tmp[w.kids[k]].left >= 0) {
+              float ar = tmp[w.kids[k]].box.area();
+              if (ar > bestArea) {
+                bestArea = ar;
+                best = k;
+              }
+            }
+          if (best < 0) break;
+          // stack need if we widen: j.stackAbove + nk (= (nk+1)-1) + tallest remaining child
+          const uint32_t t = w.kids[best];
+          uint32_t tallest = std::max<uint32_t>(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]);
+          for (int k = 0; k < w.nk; k++)
+            if (k != best) tallest = std::max<uint32_t>(tallest, height[w.kids[k]]);
+          if (j.stackAbove + (uint32_t)w.nk + tallest > (uint32_t)kBvhMaxStack) break;
+          w.kids[best] = (uint32_t)tmp[t].left;
+          w.kids[w.nk++] = (uint32_t)tmp[t].right;
+        }
+      }
+      const uint32_t self = (uint32_t)wide.size();
+      wide.push_back(w);
+      slots.push_back({j.slotNode, j.slotIdx});
+      wDepth = std::max(wDepth, j.depth);
+      const uint32_t need = j.stackAbove + (uint32_t)(w.nk - 1);
+      wStack = std::max(wStack, need);
+      for (int k = w.nk - 1; k >= 0; k--)
+        if (tmp[w.kids[k]].left >= 0) jobs.push_back(Job{w.kids[k], j.depth + 1, need, (int32_t)self, k});
     }
   }
-  out.sahCost = (float)cost;
+  out.maxDepth = wDepth;
+  out.maxStack = wStack;
+  out.nodes.resize(wide.size());
+  const float rootArea = tmp[0].box.area();
+  double cost = 0.0;
+  for (size_t wi = 0; wi < wide.size(); wi++) {
+    const Wide& w = wide[wi];
+    BvhNode nd;
+    std::memset(&nd, 0, sizeof(nd));
+    // node box = union of the padded child boxes
+    float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+    float clo[4][3], chi[4][3];
+    for (int k = 0; k < w.nk; k++)
+      for (int a = 0; a < 3; a++) {
+        clo[k][a] = tmp[w.kids[k]].box.lo[a] - pad;
+        chi[k][a] = tmp[w.kids[k]].box.hi[a] + pad;
+        blo[a] = std::min(blo[a], clo[k][a]);
+        bhi[a] = std::max(bhi[a], chi[k][a]);
+      }
+    for (int a = 0; a < 3; a++) {
+      nd.origin[a] = blo[a];
+      // smallest power of two s with 254*s >= extent (one code of headroom for outward rounding)
+      const float ext = std::max(bhi[a] - blo[a], 1e-30f);
+      int e = 0;
+      (void)std::frexp(ext / 254.0f, &e);  // ext/254 = m * 2^e, m in [0.5,1) -> s = 2^e >= ext/254
+      int biased = e + 127;
+      if (biased < 1) biased = 1;
+      if (biased > 254) biased = 254;
+      nd.exp[a] = (uint8_t)biased;
+      for (int k = 0; k < 4; k++) {
+        if (k >= w.nk) {
+          nd.lo[a][k] = 255;
+          nd.hi[a][k] = 0;
+          continue;
+        }
+        union {
+          uint32_t u;
+          float f;
+        } sc;
+        sc.u = (uint32_t)biased << 23;
+        int ql = (int)std::floor((clo[k][a] - blo[a]) / sc.f);
+        ql = std::min(std::max(ql, 0), 255);
+        while (ql > 0 && blo[a] + (float)ql * sc.f > clo[k][a]) ql--;
+        int qh = (int)std::ceil((chi[k][a] - blo[a]) / sc.f);
+        qh = std::min(std::max(qh, 0), 255);
+        while (qh < 255 && blo[a] + (float)qh * sc.f < chi[k][a]) qh++;
+        nd.lo[a][k] = (uint8_t)ql;
+        nd.hi[a][k] = (uint8_t)qh;
+      }
+    }
+    nd.numChildren = (uint8_t)w.nk;
+    for (int k = 0; k < 4; k++) nd.child[k] = -1;
+    for (int k = 0; k < w.nk; k++) {
+      const TmpNode& c = tmp[w.kids[k]];
+      if (c.left < 0) nd.child[k] = leafRef(c.first, c.count);  // interior refs are patched below
+      if (rootArea > 0) cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
+    }
+    out.nodes[wi] = nd;
+  }
+  for (size_t wi = 1; wi < wide.size(); wi++) out.nodes[(size_t)slots[wi].first].child[slots[wi].second] = (int32_t)wi;
+  out.sahCost = (float)cost + kCostTraverse;
 }
 
 }  // namespace bdpt

@@ -21,24 +21,35 @@ struct Hit {
 constexpr int kDone = (int)0x80000000;  // traversal cursor value: stack exhausted
 
 struct TravState {
-  f3 o, d, idir;
+  f3 o, d, idir;  // idir clamped to +-1e30 so slab arithmetic never produces inf - inf
+  uint32_t neg;   // bit a set when d[a] < 0: near plane of axis a is the box's hi plane
   float tmin, tmax;
   int cur, sp;
   Hit best;
 };
 
+BD float clampedRcp(float d) {
+  float r = 1.0f / d;
+  if (!(fabsf(r) <= 1.0e30f)) r = copysignf(1.0e30f, d);
+  return r;
+}
+
 BD void travInit(TravState& T, f3 o, f3 d, float tmin, float tmax) {
   T.o = o;
   T.d = d;
-  T.idir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  T.idir = mk(clampedRcp(d.x), clampedRcp(d.y), clampedRcp(d.z));
+  T.neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
   T.tmin = tmin;
   T.tmax = tmax;
-  T.cur = 0;
   T.sp = 0;
   T.best.prim = -1;
   T.best.t = tmax;
   T.best.u = 0.0f;
   T.best.v = 0.0f;
+  // A ray with a NaN anywhere, or with an empty (tmin, tmax) interval, cannot satisfy
+  // tmin < t < tmax for any triangle (the brute-force scan agrees): it misses without traversal.
+  const bool finite = (o.x == o.x) && (o.y == o.y) && (o.z == o.z) && (d.x == d.x) && (d.y == d.y) && (d.z == d.z);
+  T.cur = (finite && (tmax > tmin)) ? 0 : kDone;
 }
 
 BD int travPop(TravState& T, const int* stk) {
@@ -47,37 +58,87 @@ BD int travPop(TravState& T, const int* stk) {
   return stk[T.sp * kWave];
 }
 
-// One interior-node visit: test both children, descend into the nearer, push the farther.
+BD void travPush(TravState& T, int* stk, int ref) {
+  stk[T.sp * kWave] = ref;
+  T.sp++;
+}
+
+BD float ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  // v_cvt_f32_ubyteN
+
+// One visit of a four-wide node with 8-bit quantised child boxes (bvh.h): plane = origin + q*scale,
+// so t = fma(q, scale*idir, (origin - o)*idir) — one convert and one fma per plane.  Near/far plane
+// bytes are picked per axis by the ray's direction sign (one select per axis for all four children).
+// ORDERED (closest hit): children are entered nearest first; otherwise in slot order.
+template <bool ORDERED>
 BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
-  const float4* np = S.nodes + (size_t)T.cur * 4;
-  const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-  const int4 q3 = reinterpret_cast<const int4*>(np)[3];
-  // (plane - o) * idir, not fma(plane, idir, -o*idir): for axis-parallel rays (idir = inf) the fused
-  // form yields inf - inf = NaN, the NaN-ignoring min/max then drop that axis, and rays such as
-  // (0,0,0) -> (0,y,0) would visit every box of the scene.
-  const f3 o = T.o, idir = T.idir;
-  float ax0 = (q0.x - o.x) * idir.x, ax1 = (q0.w - o.x) * idir.x;
-  float ay0 = (q0.y - o.y) * idir.y, ay1 = (q1.x - o.y) * idir.y;
-  float az0 = (q0.z - o.z) * idir.z, az1 = (q1.y - o.z) * idir.z;
-  float tn0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), T.tmin));
-  float tf0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), T.best.t));
-  float bx0 = (q1.z - o.x) * idir.x, bx1 = (q2.y - o.x) * idir.x;
-  float by0 = (q1.w - o.y) * idir.y, by1 = (q2.z - o.y) * idir.y;
-  float bz0 = (q2.x - o.z) * idir.z, bz1 = (q2.w - o.z) * idir.z;
-  float tn1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), T.tmin));
-  float tf1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), T.best.t));
-  const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-  if (h0 && h1) {
-    const bool swap = tn1 < tn0;
-    stk[T.sp * kWave] = swap ? q3.x : q3.y;
-    T.sp++;
-    T.cur = swap ? q3.y : q3.x;
-  } else if (h0) {
-    T.cur = q3.x;
-  } else if (h1) {
-    T.cur = q3.y;
+  const uint4* np = reinterpret_cast<const uint4*>(S.nodes) + (size_t)T.cur * 4;
+  const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+  const uint4 q3 = np[3];
+  const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23),
+              sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+  const float ax = sx * T.idir.x, ay = sy * T.idir.y, az = sz * T.idir.z;
+  const float bx = (__uint_as_float(q0.x) - T.o.x) * T.idir.x, by = (__uint_as_float(q0.y) - T.o.y) * T.idir.y,
+              bz = (__uint_as_float(q0.z) - T.o.z) * T.idir.z;
+  const bool nx = (T.neg & 1u) != 0, ny = (T.neg & 2u) != 0, nz = (T.neg & 4u) != 0;
+  const uint32_t nearX = nx ? q1.w : q1.x, farX = nx ? q1.x : q1.w;
+  const uint32_t nearY = ny ? q2.x : q1.y, farY = ny ? q1.y : q2.x;
+  const uint32_t nearZ = nz ? q2.y : q1.z, farZ = nz ? q1.z : q2.y;
+  float tn[4];
+  bool hit[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const float tnx = fmaf(ubyte(nearX, c), ax, bx), tfx = fmaf(ubyte(farX, c), ax, bx);
+    const float tny = fmaf(ubyte(nearY, c), ay, by), tfy = fmaf(ubyte(farY, c), ay, by);
+    const float tnz = fmaf(ubyte(nearZ, c), az, bz), tfz = fmaf(ubyte(farZ, c), az, bz);
+    const float n = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, T.tmin));
+    const float f = fminf(fminf(tfx, tfy), fminf(tfz, T.best.t));
+    hit[c] = n <= f;
+    tn[c] = n;
+  }
+  int r0 = (int)q3.x, r1 = (int)q3.y, r2 = (int)q3.z, r3 = (int)q3.w;
+  if (ORDERED) {
+    float t0 = hit[0] ? tn[0] : 3.0e38f, t1 = hit[1] ? tn[1] : 3.0e38f, t2 = hit[2] ? tn[2] : 3.0e38f, t3 = hit[3] ? tn[3] : 3.0e38f;
+    r0 = hit[0] ? r0 : kDone;
+    r1 = hit[1] ? r1 : kDone;
+    r2 = hit[2] ? r2 : kDone;
+    r3 = hit[3] ? r3 : kDone;
+#define BDPT_CSWAP(ta, ra, tb, rb) \
+  {                                \
+    const bool sw = tb < ta;       \
+    const float tt = sw ? tb : ta; \
+    const int rr = sw ? rb : ra;   \
+    tb = sw ? ta : tb;             \
+    rb = sw ? ra : rb;             \
+    ta = tt;                       \
+    ra = rr;                       \
+  }
+    BDPT_CSWAP(t0, r0, t1, r1)
+    BDPT_CSWAP(t2, r2, t3, r3)
+    BDPT_CSWAP(t0, r0, t2, r2)
+    BDPT_CSWAP(t1, r1, t3, r3)
+    BDPT_CSWAP(t1, r1, t2, r2)
+#undef BDPT_CSWAP
+    // misses sorted to the back (t = 3e38, ref = kDone): push far to near, enter the nearest
+    if (r3 != kDone) travPush(T, stk, r3);
+    if (r2 != kDone) travPush(T, stk, r2);
+    if (r1 != kDone) travPush(T, stk, r1);
+    T.cur = (r0 != kDone) ? r0 : travPop(T, stk);
   } else {
-    T.cur = travPop(T, stk);
+    int next = kDone;
+    if (hit[3]) next = r3;
+    if (hit[2]) {
+      if (next != kDone) travPush(T, stk, next);
+      next = r2;
+    }
+    if (hit[1]) {
+      if (next != kDone) travPush(T, stk, next);
+      next = r1;
+    }
+    if (hit[0]) {
+      if (next != kDone) travPush(T, stk, next);
+      next = r0;
+    }
+    T.cur = (next != kDone) ? next : travPop(T, stk);
   }
 }
 
@@ -132,7 +193,7 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
   while (T.cur != kDone) {
     while (T.cur >= 0) {
       if (COUNT) nNodes++;
-      nodeStep(S, T, stk);
+      nodeStep<MODE != 2>(S, T, stk);
     }
     if (T.cur == kDone) break;
     if (leafStep<MODE, COUNT>(S, T, nTris)) break;
@@ -248,7 +309,7 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep(S, T, stk);
+        nodeStep<MODE != 2>(S, T, stk);
       }
       bool finished = (T.cur == kDone);
       if (!finished) {

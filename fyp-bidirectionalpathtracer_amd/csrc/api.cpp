@@ -20,7 +20,9 @@ using namespace bdpt;
 namespace {
 constexpr int kMaxStages = 64;
 // path-queue counters, their fetch cursors, then the shadow sub-queue counters and cursors
-constexpr size_t kCursorWords = 4 * BDPT_MAX_DEPTH + 8 + 2 * kNumSubQueues + kLazyRounds + 2;
+// (each shadow sub-queue cursor on its own 128-byte line: atomics to one line serialise)
+constexpr size_t kQueueWords = 4 * BDPT_MAX_DEPTH + 8 + kLazyRounds + 2;
+constexpr size_t kCursorWords = ((kQueueWords + 31) / 32) * 32 + 2 * kNumSubQueues * kCursorStride;
 }
 
 struct bdpt_ctx {
@@ -410,9 +412,9 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)kCursorWords))) return rc;
   P.qhead = P.qcount + 2 * BDPT_MAX_DEPTH + 4;
-  P.rayCount = P.qcount + 4 * BDPT_MAX_DEPTH + 8;
-  P.rayHead = P.rayCount + kNumSubQueues;
-  P.lazyCount = P.rayHead + kNumSubQueues;
+  P.lazyCount = P.qcount + 4 * BDPT_MAX_DEPTH + 8;
+  P.rayCount = P.qcount + ((kQueueWords + 31) / 32) * 32;
+  P.rayHead = P.rayCount + kNumSubQueues * kCursorStride;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrim, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, np))) return rc;
@@ -566,7 +568,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     for (int r = 0; r < kLazyRounds; r++) {
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
-      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kNumSubQueues * sizeof(uint32_t), st));
+      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kNumSubQueues * kCursorStride * sizeof(uint32_t), st));
       launchLazyGen(F, P, list, &P.lazyCount[r], batch, st);
       launchTraceShadow(c->S, F, P, c->numCUs, st);
       launchLazyCheck(F, P, list, &P.lazyCount[r], batch, next, &P.lazyCount[r + 1], st);

@@ -268,10 +268,10 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
     const int idle = __popcll(idleMask);
     if (!exhausted && idle >= kRefillIdle) {
       while (chunkPos >= chunkEnd && !exhausted) {  // wave-uniform loop: take a new chunk
-        const uint32_t nq = Q.count[q];
+        const uint32_t nq = Q.count[q * kCursorStride];
         uint32_t base = nq;
-        if (__hip_atomic_load(&Q.head[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
-          if (lane == 0) base = atomicAdd(&Q.head[q], kFetchChunk);
+        if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
+          if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], kFetchChunk);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         }
         if (base < nq) {

@@ -19,6 +19,7 @@ constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // take kFetchChunk rays per atomic, and the statistics counters are sharded per workgroup.
 constexpr uint32_t kNumSubQueues = 32;
 constexpr uint32_t kFetchChunk = 256;
+constexpr uint32_t kCursorStride = 32;  // uint32 words between two sub-queue cursors: one 128-byte line each
 constexpr uint32_t kCounterShards = 64;
 
 // Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45, minus pdfForward which only

@@ -6,7 +6,7 @@
 //   per bounce of each sub-path:
 //     trace_kernel<0>   persistent closest-hit traversal        globalIlluminationRay.hlsli:1-12 (TraceRay)
 //     shade_kernel      hit/miss shading + queue compaction     globalIlluminationRay.hlsli:14-45
-//   gen_shadow_kernel   NEE / splat / connection terms -> rays  BDPTMain.rt.hlsl:161-233
+//   gen_{nee,splat,connect}_kernel  terms -> shadow-ray queue   BDPTMain.rt.hlsl:161-233
 //   trace_kernel<2>     persistent any-hit traversal            standardShadowRay.hlsli:7-49
 //   gather_kernel       ordered sums, splat atomics             BDPTMain.rt.hlsl:166, 199, 230
 //   resolve_kernel      fold the splat buffer in                (build definition)
@@ -358,7 +358,7 @@ BD uint32_t emitRay(const PathBuf& P, bool active, f3 o, f3 d, float tmax, f3 co
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
   const uint32_t q = blockIdx.x % kNumSubQueues;
-  if (lane == leader) base = atomicAdd(&P.rayCount[q], (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(&P.rayCount[q * kCursorStride], (uint32_t)__popcll(mask));
   base = (uint32_t)__shfl((int)base, leader);
   if (active) {
     id = q * P.raySubCap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -399,8 +399,10 @@ BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx
   }
 }
 
+// Three kernels (NEE, splat, connection) instead of one: each stays under 64 VGPRs, so twice as
+// many waves are resident to hide the latency of the vertex-plane loads.
 template <bool GGX>
-__global__ __launch_bounds__(kWave) void gen_shadow_kernel(SceneDev S, FrameDev F, PathBuf P) {
+__global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
   const uint32_t n = P.qcount[0];
   if (blockIdx.x * kWave >= n) return;
   const uint32_t i = blockIdx.x * kWave + threadIdx.x;
@@ -408,12 +410,8 @@ __global__ __launch_bounds__(kWave) void gen_shadow_kernel(SceneDev S, FrameDev 
   const uint32_t p = act ? P.queue[0][i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0;
-  const int lightLast = act ? (int)P.lightLast[p] : -1;
-  const int real = act ? (int)P.lightReal[p] : 0;
-  const f3 camPos = ld3(F.cam.posW);
   const int lightsCount = (int)S.numLights;
-  uint32_t nNee = 0, nSplat = 0, nConn = 0;
-
+  uint32_t nNee = 0;
   // ---- NEE ------------------------------------------------------------------------------------
   {
     uint32_t seed = act ? P.seedL[p] : 0u;
@@ -451,6 +449,21 @@ __global__ __launch_bounds__(kWave) void gen_shadow_kernel(SceneDev S, FrameDev 
     }
   }
 
+  waveAddCount(F.counters, C_RAYS_NEE, nNee);
+  waveAddCount(F.counters, C_PIX_VALID, act ? 1u : 0u);
+}
+
+template <bool GGX>
+__global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  const uint32_t n = P.qcount[0];
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  const bool act = i < n;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  const uint32_t p = act ? P.queue[0][i] : 0u;
+  const int D = (int)F.p.maxDepth;
+  const int real = act ? (int)P.lightReal[p] : 0;
+  const f3 camPos = ld3(F.cam.posW);
+  uint32_t nSplat = 0;
   // ---- light tracing (splats) -------------------------------------------------------------------
   if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
     const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
@@ -500,77 +513,88 @@ __global__ __launch_bounds__(kWave) void gen_shadow_kernel(SceneDev S, FrameDev 
     }
   }
 
-  // ---- vertex connections -----------------------------------------------------------------------
-  if (!(F.p.flags & BDPT_PARAM_NO_CONNECT)) {
-    int slot = 2 * D;
-    for (int totalLength = 2; totalLength <= D; totalLength++) {
-      for (int cameraLength = 1; cameraLength <= D - 1; cameraLength++) {
-        if (cameraLength > totalLength) continue;  // undefined in the reference (uint underflow, quirk 3)
-        const int lightLength = totalLength - cameraLength;
-        bool emit = false;
-        f3 posA = mk(0), dirAB = mk(0), shade = mk(0);
-        float lengthAB = 0.0f;
-        if (act) {
-          Vtx ce, le;
-          loadConnVtx<GGX>(P, PATH_EYE, cameraLength, eyeLast, p, ce);
-          loadConnVtx<GGX>(P, PATH_LIGHT, lightLength, lightLast, p, le);
-          const f3 vecAB = le.pos - ce.pos;
-          const float invLengthAB = 1.0f / length(vecAB);
-          const f3 dirG = vecAB * invLengthAB;
-          const float cosA = fabsf(dot(ce.N, dirG));
-          const float cosB = fabsf(dot(le.N, dirG));
-          const float G = cosA * cosB * invLengthAB * invLengthAB;
-          f3 c = mk(0);
-          if (lightLength != 0) {
-            const f3 connectDir = normalize(ce.pos - le.pos);
-            const f3 lprev = (lightLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength - 1, F_POS, p) : mk(0);
-            f3 wo = normalize(lprev - le.pos);
-            f3 fsL = evalBRDF<GGX>(connectDir, wo, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
-            if (allZero(fsL)) {
-              c = fsL;
-            } else {
-              f3 cprevPos, aE;
-              if (cameraLength - 1 == 0) {
-                cprevPos = camPos;
-                aE = mk(1.0f);
-              } else if (cameraLength - 1 <= eyeLast) {
-                cprevPos = ldPlane3(P, PATH_EYE, cameraLength - 1, F_POS, p);
-                aE = ldPlane3(P, PATH_EYE, cameraLength - 1, F_COL, p);
-              } else {
-                cprevPos = mk(0);
-                aE = mk(0);
-              }
-              wo = normalize(cprevPos - ce.pos);
-              f3 fsE = evalBRDF<GGX>(-connectDir, wo, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
-              if (allZero(fsE)) {
-                c = fsE;
-              } else {
-                const f3 aL = (cameraLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, cameraLength - 1, F_COL, p) : mk(0);
-                f3 cst = (fsL * G) * fsE;
-                c = (aL * cst) * aE;
-              }
-            }
-          }
-          shade = clampVec(c / (float)totalLength, F.p.clampUpper);
-          if (isnan3(shade)) shade = mk(0);
-          if (!allZero(shade)) {
-            emit = true;
-            posA = ce.pos;
-            lengthAB = length(le.pos - ce.pos);
-            dirAB = (le.pos - ce.pos) / lengthAB;
+  waveAddCount(F.counters, C_RAYS_SPLAT, nSplat);
+}
+
+// Connection pairs are generated camera-vertex-major (the eye end vertex, its predecessor and the
+// two throughputs indexed by cameraLength are loaded once per cameraLength); the slot index keeps the
+// reference's (totalLength, cameraLength) numbering, which is all the gather stage needs.
+template <bool GGX>
+__global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  const uint32_t n = P.qcount[0];
+  if (blockIdx.x * kWave >= n) return;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  const bool act = i < n;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  const uint32_t p = act ? P.queue[0][i] : 0u;
+  const int D = (int)F.p.maxDepth;
+  const int eyeLast = act ? (int)P.eyeLast[p] : 0;
+  const int lightLast = act ? (int)P.lightLast[p] : -1;
+  const f3 camPos = ld3(F.cam.posW);
+  uint32_t nConn = 0;
+  for (int cameraLength = 1; cameraLength <= D - 1; cameraLength++) {
+    Vtx ce = zeroVtx();
+    f3 aE = mk(0), aL = mk(0), woE = mk(0);
+    if (act) {
+      loadConnVtx<GGX>(P, PATH_EYE, cameraLength, eyeLast, p, ce);
+      f3 cprevPos;
+      if (cameraLength - 1 == 0) {
+        cprevPos = camPos;
+        aE = mk(1.0f);
+      } else if (cameraLength - 1 <= eyeLast) {
+        cprevPos = ldPlane3(P, PATH_EYE, cameraLength - 1, F_POS, p);
+        aE = ldPlane3(P, PATH_EYE, cameraLength - 1, F_COL, p);
+      } else {
+        cprevPos = mk(0);
+        aE = mk(0);
+      }
+      woE = normalize(cprevPos - ce.pos);
+      aL = (cameraLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, cameraLength - 1, F_COL, p) : mk(0);  // sic, BDPTUtils.hlsli:198
+    }
+    for (int lightLength = (cameraLength == 1) ? 1 : 0; cameraLength + lightLength <= D; lightLength++) {
+      const int totalLength = cameraLength + lightLength;  // 2..D; pairs of smaller totals come first: (t-1)t/2 - 1 of them
+      const int slot = 2 * D + ((totalLength - 1) * totalLength) / 2 - 1 + (cameraLength - 1);
+      bool emit = false;
+      f3 dirAB = mk(0), shade = mk(0);
+      float lengthAB = 0.0f;
+      if (act && lightLength != 0) {
+        Vtx le;
+        loadConnVtx<GGX>(P, PATH_LIGHT, lightLength, lightLast, p, le);
+        const f3 vecAB = le.pos - ce.pos;
+        const float invLengthAB = 1.0f / length(vecAB);
+        const f3 dirG = vecAB * invLengthAB;
+        const float cosA = fabsf(dot(ce.N, dirG));
+        const float cosB = fabsf(dot(le.N, dirG));
+        const float G = cosA * cosB * invLengthAB * invLengthAB;
+        const f3 connectDir = normalize(ce.pos - le.pos);
+        const f3 lprev = (lightLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength - 1, F_POS, p) : mk(0);
+        const f3 woL = normalize(lprev - le.pos);
+        f3 c;
+        const f3 fsL = evalBRDF<GGX>(connectDir, woL, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
+        if (allZero(fsL)) {
+          c = fsL;
+        } else {
+          const f3 fsE = evalBRDF<GGX>(-connectDir, woE, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
+          if (allZero(fsE)) {
+            c = fsE;
+          } else {
+            const f3 cst = (fsL * G) * fsE;
+            c = (aL * cst) * aE;
           }
         }
-        const uint32_t id = emitRay(P, emit, posA, dirAB, lengthAB, shade);
-        if (act) P.slotRay[(size_t)slot * P.Np + p] = id;
-        nConn += emit ? 1u : 0u;
-        slot++;
+        shade = clampVec(c / (float)totalLength, F.p.clampUpper);
+        if (isnan3(shade)) shade = mk(0);
+        if (!allZero(shade)) {
+          emit = true;
+          lengthAB = length(le.pos - ce.pos);
+          dirAB = (le.pos - ce.pos) / lengthAB;
+        }
       }
+      const uint32_t id = emitRay(P, emit, ce.pos, dirAB, lengthAB, shade);
+      if (act) P.slotRay[(size_t)slot * P.Np + p] = id;
+      nConn += emit ? 1u : 0u;
     }
   }
-  waveAddCount(F.counters, C_RAYS_NEE, nNee);
-  waveAddCount(F.counters, C_RAYS_SPLAT, nSplat);
   waveAddCount(F.counters, C_RAYS_CONNECT, nConn);
-  waveAddCount(F.counters, C_PIX_VALID, act ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -896,10 +920,24 @@ void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int pa
 
 void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
-  if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(gen_shadow_kernel<true>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
+  const dim3 g(blocksFor(P.Np)), b(kWave);
+  const bool ggx = F.p.matIndex == 0;
+  if (ggx)
+    hipLaunchKernelGGL(gen_nee_kernel<true>, g, b, 0, st, S, F, P);
   else
-    hipLaunchKernelGGL(gen_shadow_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
+    hipLaunchKernelGGL(gen_nee_kernel<false>, g, b, 0, st, S, F, P);
+  if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
+    if (ggx)
+      hipLaunchKernelGGL(gen_splat_kernel<true>, g, b, 0, st, S, F, P);
+    else
+      hipLaunchKernelGGL(gen_splat_kernel<false>, g, b, 0, st, S, F, P);
+  }
+  if (!(F.p.flags & BDPT_PARAM_NO_CONNECT)) {
+    if (ggx)
+      hipLaunchKernelGGL(gen_connect_kernel<true>, g, b, 0, st, S, F, P);
+    else
+      hipLaunchKernelGGL(gen_connect_kernel<false>, g, b, 0, st, S, F, P);
+  }
 }
 
 void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st) {

@@ -20,9 +20,11 @@ using namespace bdpt;
 namespace {
 constexpr int kMaxStages = 64;
 // path-queue counters, their fetch cursors, then the shadow sub-queue counters and cursors
-// (each shadow sub-queue cursor on its own 128-byte line: atomics to one line serialise)
-constexpr size_t kQueueWords = 4 * BDPT_MAX_DEPTH + 8 + kLazyRounds + 2;
-constexpr size_t kCursorWords = ((kQueueWords + 31) / 32) * 32 + 2 * kNumSubQueues * kCursorStride;
+// (every cursor is sharded: kNumSubQueues words, each on its own 128-byte line — atomics to one line serialise)
+constexpr size_t kCountBlocks = 2 * BDPT_MAX_DEPTH + 2;  // valid list + one per extension step
+constexpr size_t kHeadBlocks = 2 * BDPT_MAX_DEPTH + 2;
+constexpr size_t kLazyBlocks = kLazyRounds + 2;
+constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks + 2) * kCursorBlock;
 }
 
 struct bdpt_ctx {
@@ -408,17 +410,20 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   if ((rc = devAlloc(c, c->frameAllocs, &P.eyeLast, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightLast, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightReal, np))) return rc;
+  // a path queue = kNumSubQueues lists; workgroup b appends to list b % kNumSubQueues
+  P.pathSubCap = (uint32_t)((((np + kWave - 1) / kWave + kNumSubQueues - 1) / kNumSubQueues) * kWave);
+  const size_t qcap = (size_t)P.pathSubCap * kNumSubQueues;
   for (int q = 0; q < 3; q++)
-    if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], np))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], qcap))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)kCursorWords))) return rc;
-  P.qhead = P.qcount + 2 * BDPT_MAX_DEPTH + 4;
-  P.lazyCount = P.qcount + 4 * BDPT_MAX_DEPTH + 8;
-  P.rayCount = P.qcount + ((kQueueWords + 31) / 32) * 32;
-  P.rayHead = P.rayCount + kNumSubQueues * kCursorStride;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrim, np))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, np))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, np))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitV, np))) return rc;
+  P.qhead = P.qcount + kCountBlocks * kCursorBlock;
+  P.lazyCount = P.qhead + kHeadBlocks * kCursorBlock;
+  P.rayCount = P.lazyCount + kLazyBlocks * kCursorBlock;
+  P.rayHead = P.rayCount + kCursorBlock;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrim, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitV, qcap))) return rc;
   {
     // one shadow ray per NEE term, per splat term and per defined connection pair, at most
     const uint32_t D = std::max<uint32_t>(maxDepth, 1);
@@ -527,15 +532,16 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   stageMark(c, st, "init_paths");
 
   // eye walk: vertices 2..D (BDPTMain.rt.hlsl:106-112)
-  int qc = 1;  // next free queue counter
+  int qc = 1;  // next free cursor block
   {
     const uint32_t* qin = P.queue[0];
-    const uint32_t* cin = &P.qcount[0];
+    const uint32_t* cin = P.qcount;
     int ping = 1;
     for (int k = 1; k <= D - 1; k++) {
-      launchExtend(c->S, F, P, PATH_EYE, k, D, qin, cin, &P.qhead[qc], P.queue[ping], &P.qcount[qc], c->numCUs, st);
+      launchExtend(c->S, F, P, PATH_EYE, k, D, qin, cin, P.qhead + (size_t)qc * kCursorBlock, P.queue[ping],
+                   P.qcount + (size_t)qc * kCursorBlock, c->numCUs, st);
       qin = P.queue[ping];
-      cin = &P.qcount[qc];
+      cin = P.qcount + (size_t)qc * kCursorBlock;
       qc++;
       ping = 3 - ping;
     }
@@ -544,12 +550,13 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   // light walk: vertices 1..D (BDPTMain.rt.hlsl:138-145)
   {
     const uint32_t* qin = P.queue[0];
-    const uint32_t* cin = &P.qcount[0];
+    const uint32_t* cin = P.qcount;
     int ping = 1;
     for (int k = 0; k <= D - 1; k++) {
-      launchExtend(c->S, F, P, PATH_LIGHT, k, D, qin, cin, &P.qhead[qc], P.queue[ping], &P.qcount[qc], c->numCUs, st);
+      launchExtend(c->S, F, P, PATH_LIGHT, k, D, qin, cin, P.qhead + (size_t)qc * kCursorBlock, P.queue[ping],
+                   P.qcount + (size_t)qc * kCursorBlock, c->numCUs, st);
       qin = P.queue[ping];
-      cin = &P.qcount[qc];
+      cin = P.qcount + (size_t)qc * kCursorBlock;
       qc++;
       ping = 3 - ping;
     }
@@ -559,7 +566,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   stageMark(c, st, "gen_shadow");
   launchTraceShadow(c->S, F, P, c->numCUs, st);
   stageMark(c, st, "trace_shadow");
-  launchGather(F, P, P.queue[1], &P.lazyCount[0], st);
+  launchGather(F, P, P.queue[1], P.lazyCount, st);
   stageMark(c, st, "gather");
   if (!(p->flags & BDPT_PARAM_NO_CONNECT) && D >= 2) {
     // zero-valued connection pairs of the pixels no visible connection has saturated yet
@@ -568,10 +575,10 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     for (int r = 0; r < kLazyRounds; r++) {
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
-      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kNumSubQueues * kCursorStride * sizeof(uint32_t), st));
-      launchLazyGen(F, P, list, &P.lazyCount[r], batch, st);
+      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));
+      launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
       launchTraceShadow(c->S, F, P, c->numCUs, st);
-      launchLazyCheck(F, P, list, &P.lazyCount[r], batch, next, &P.lazyCount[r + 1], st);
+      launchLazyCheck(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, next, P.lazyCount + (size_t)(r + 1) * kCursorBlock, st);
     }
     stageMark(c, st, "lazy_rounds");
   }

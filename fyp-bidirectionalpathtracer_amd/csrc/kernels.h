@@ -19,7 +19,8 @@ constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // take kFetchChunk rays per atomic, and the statistics counters are sharded per workgroup.
 constexpr uint32_t kNumSubQueues = 32;
 constexpr uint32_t kFetchChunk = 256;
-constexpr uint32_t kCursorStride = 32;  // uint32 words between two sub-queue cursors: one 128-byte line each
+constexpr uint32_t kCursorStride = 32;
+constexpr uint32_t kCursorBlock = kNumSubQueues * kCursorStride;  // words of one sharded cursor  // uint32 words between two sub-queue cursors: one 128-byte line each
 constexpr uint32_t kCounterShards = 64;
 
 // Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45, minus pdfForward which only
@@ -74,9 +75,11 @@ struct PathBuf {
   uint8_t* eyeLast;    // last stored eye vertex (ghost included); 0 = pixel has no geometry
   uint8_t* lightLast;  // last stored light vertex (ghost included)
   uint8_t* lightReal;  // number of light vertices produced by hits (takeContribution, BDPTMain.rt.hlsl:144)
-  uint32_t* queue[3];  // [0] valid pixels; [1],[2] ping-pong extension queues
-  uint32_t* qcount;    // [0] valid count, [1..] one counter per extension step
-  uint32_t* qhead;     // fetch cursors of the persistent trace kernel, one per launch
+  uint32_t* queue[3];  // sharded path queues (kernels.hip "Path queues"): [0] valid pixels; [1],[2] ping-pong
+  uint32_t pathSubCap; // capacity of one list of a path queue (multiple of 64)
+  // cursor blocks: each is kNumSubQueues cursors, one per 128-byte line (kCursorBlock words)
+  uint32_t* qcount;    // block 0 = valid-pixel list lengths; block 1+s = lengths after extension step s
+  uint32_t* qhead;     // block s = fetch cursors of the persistent trace of extension step s
   // closest-hit records by queue position
   int* hitPrim;
   float* hitT;
@@ -93,7 +96,7 @@ struct PathBuf {
   uint32_t* splatPix;    // planes: t*Np + p -> full-frame pixel index of splat t
   uint8_t* lazyCursor;   // next connection-pair ordinal a pending pixel has not examined yet
   uint32_t* lazyRay;     // planes: b*Np + p -> ray id of the b-th lazy ray of the current round
-  uint32_t* lazyCount;   // pending-list sizes, one per round
+  uint32_t* lazyCount;   // cursor blocks: pending-list lengths, one block per round
   uint32_t rayCap;
   uint32_t Np, D1;
 };

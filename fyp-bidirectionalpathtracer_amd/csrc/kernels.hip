@@ -31,18 +31,33 @@ namespace bdpt {
 #define BD __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------------------
-// queue compaction: append `value` of every lane with `active` to queue[]; one atomic per wave
+// Path queues.  A queue is kNumSubQueues dense lists (workgroup b appends to and, in the dense
+// kernels, reads list b % kNumSubQueues) with one cursor per list on its own 128-byte line, because
+// every wave of a launch hitting one atomic word caps the chip near 90 M appends/s.
+//   item of list q at offset i lives at items[q*subCap + i]; count[q*kCursorStride] = list length
 // ------------------------------------------------------------------------------------------------
-BD void wavePush(bool active, uint32_t value, uint32_t* queue, uint32_t* counter) {
+BD void wavePush(bool active, uint32_t value, uint32_t* items, uint32_t* count, uint32_t subCap) {
   unsigned long long mask = __ballot(active);
   if (mask == 0ull) return;
   const int lane = (int)(threadIdx.x & 63u);
   const int leader = __ffsll((long long)mask) - 1;
+  const uint32_t q = blockIdx.x % kNumSubQueues;
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(&count[q * kCursorStride], (uint32_t)__popcll(mask));
   base = (uint32_t)__shfl((int)base, leader);
   const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  if (active) queue[base + prefix] = value;
+  if (active) items[q * subCap + base + prefix] = value;
+}
+// Dense consumer: workgroup b handles entries [64*(b / NQ), +64) of list b % NQ.  Returns false for
+// the whole wave when the chunk lies beyond the list (wave-uniform), else sets act / idx per lane.
+BD bool queueChunk(const uint32_t* count, uint32_t subCap, bool& act, uint32_t& idx) {
+  const uint32_t q = blockIdx.x % kNumSubQueues, c0 = (blockIdx.x / kNumSubQueues) * kWave;
+  const uint32_t n = count[q * kCursorStride];
+  if (c0 >= n) return false;
+  const uint32_t i = c0 + threadIdx.x;
+  act = i < n;
+  idx = q * subCap + i;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
       out4[pix] = em ? make_float4(0.0f + er, 0.0f + eg, 0.0f + eb, 0.0f + ea) : make_float4(0, 0, 0, 0);
     }
   }
-  wavePush(geom, p, P.queue[0], &P.qcount[0]);
+  wavePush(geom, p, P.queue[0], P.qcount, P.pathSubCap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,10 +296,9 @@ template <bool GGX>
 __global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, PathBuf P, int path, int k, int maxK,
                                                       const uint32_t* __restrict__ qin, const uint32_t* __restrict__ countIn,
                                                       uint32_t* __restrict__ qout, uint32_t* __restrict__ countOut) {
-  const uint32_t n = *countIn;
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  const bool active = i < n;
+  bool active = false;
+  uint32_t i = 0;
+  if (!queueChunk(countIn, P.pathSubCap, active, i)) return;
   bool survive = false;
   uint32_t p = 0;
   if (active) {
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, Pa
     }
   }
   waveAddCount(F.counters, path == PATH_EYE ? C_RAYS_EYE : C_RAYS_LIGHT, active ? 1u : 0u);
-  wavePush(survive, p, qout, countOut);
+  wavePush(survive, p, qout, countOut, P.pathSubCap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,10 +417,9 @@ BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx
 // many waves are resident to hide the latency of the vertex-plane loads.
 template <bool GGX>
 __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  const bool act = i < n;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  bool act = false;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  uint32_t i = 0;
+  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
   const uint32_t p = act ? P.queue[0][i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0;
@@ -455,10 +468,9 @@ __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, 
 
 template <bool GGX>
 __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  const bool act = i < n;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  bool act = false;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  uint32_t i = 0;
+  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
   const uint32_t p = act ? P.queue[0][i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int real = act ? (int)P.lightReal[p] : 0;
@@ -521,10 +533,9 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
 // reference's (totalLength, cameraLength) numbering, which is all the gather stage needs.
 template <bool GGX>
 __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  const bool act = i < n;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  bool act = false;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  uint32_t i = 0;
+  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
   const uint32_t p = act ? P.queue[0][i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0;
@@ -663,18 +674,18 @@ BD bool gatherLane(const FrameDev& F, const PathBuf& P, uint32_t p, uint32_t& nS
 
 __global__ __launch_bounds__(kWave) void gather_kernel(FrameDev F, PathBuf P, uint32_t* __restrict__ lazyList,
                                                        uint32_t* __restrict__ lazyCount) {
-  const uint32_t n = P.qcount[0];
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  bool act = false;
+  uint32_t i = 0;
+  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
   uint32_t nSplat = 0, p = 0;
   bool pending = false;
-  if (i < n) {
+  if (act) {
     p = P.queue[0][i];
     pending = gatherLane(F, P, p, nSplat);
     if (pending) P.lazyCursor[p] = 0;
   }
   waveAddCount(F.counters, C_SPLATS, nSplat);
-  wavePush(pending, p, lazyList, lazyCount);
+  wavePush(pending, p, lazyList, lazyCount, P.pathSubCap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -697,10 +708,9 @@ BD void pairFromOrdinal(int D, int ord, int& totalLength, int& cameraLength) {
 
 __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
                                                          const uint32_t* __restrict__ listCount, int batch) {
-  const uint32_t n = *listCount;
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-  const bool act = i < n;
+  bool act = false;
+  uint32_t i = 0;
+  if (!queueChunk(listCount, P.pathSubCap, act, i)) return;
   const uint32_t p = act ? list[i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int nPairs = (int)numConnectPairs((uint32_t)D);
@@ -734,12 +744,12 @@ __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, 
 __global__ __launch_bounds__(kWave) void lazy_check_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
                                                            const uint32_t* __restrict__ listCount, int batch,
                                                            uint32_t* __restrict__ nextList, uint32_t* __restrict__ nextCount) {
-  const uint32_t n = *listCount;
-  if (blockIdx.x * kWave >= n) return;
-  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  bool act = false;
+  uint32_t i = 0;
+  if (!queueChunk(listCount, P.pathSubCap, act, i)) return;
   bool again = false;
   uint32_t p = 0;
-  if (i < n) {
+  if (act) {
     p = list[i];
     bool vis = false;
     for (int b = 0; b < batch; b++) {
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(kWave) void lazy_check_kernel(FrameDev F, PathBuf P
       again = (int)P.lazyCursor[p] < nPairs;
     }
   }
-  wavePush(again, p, nextList, nextCount);
+  wavePush(again, p, nextList, nextCount, P.pathSubCap);
 }
 
 // out = saturate(out + splat) where at least one splat landed
@@ -864,6 +874,8 @@ __global__ void test_bsdf_kernel(const float* in, uint32_t n, bool fromLobe, flo
 #define PERCU 20
 #endif
 static inline uint32_t blocksFor(uint64_t n) { return (uint32_t)((n + kWave - 1) / kWave); }
+// grid of a dense kernel over a sharded path queue: every (list, chunk) pair gets a workgroup
+static inline uint32_t queueGrid(const PathBuf& P) { return (P.pathSubCap / kWave) * kNumSubQueues; }
 
 // Persistent grids: as many one-wave workgroups as can be resident (LDS 8 KiB/wave, VGPRs).
 template <class K>
@@ -895,7 +907,7 @@ void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int pa
                   const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st) {
   if (!P.Np) return;
   const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
-  RayQueue Q{nullptr, 0, 0, 1, countIn, head};
+  RayQueue Q{nullptr, 0, P.pathSubCap, kNumSubQueues, countIn, head};
   ClosestIn CI{qin, P.v + ((size_t)(path * (int)P.D1 + k) * NF + (size_t)F_POS) * P.Np, P.rayDir + (size_t)(path * 3) * P.Np, P.Np,
                F.p.minT};
   ShadowOut SO{nullptr};
@@ -911,16 +923,16 @@ void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int pa
     hipLaunchKernelGGL((trace_kernel<0, false>), dim3(g), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, 0.0f);
   }
   if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(shade_kernel<true>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
+    hipLaunchKernelGGL(shade_kernel<true>, dim3(queueGrid(P)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
                        countOut);
   else
-    hipLaunchKernelGGL(shade_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
+    hipLaunchKernelGGL(shade_kernel<false>, dim3(queueGrid(P)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
                        countOut);
 }
 
 void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
-  const dim3 g(blocksFor(P.Np)), b(kWave);
+  const dim3 g(queueGrid(P)), b(kWave);
   const bool ggx = F.p.matIndex == 0;
   if (ggx)
     hipLaunchKernelGGL(gen_nee_kernel<true>, g, b, 0, st, S, F, P);
@@ -959,16 +971,16 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
 
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(gather_kernel, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, F, P, lazyList, lazyCount);
+  hipLaunchKernelGGL(gather_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, lazyList, lazyCount);
 }
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(lazy_gen_kernel, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, F, P, list, listCount, batch);
+  hipLaunchKernelGGL(lazy_gen_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, list, listCount, batch);
 }
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
                      uint32_t* nextList, uint32_t* nextCount, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(lazy_check_kernel, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, F, P, list, listCount, batch, nextList, nextCount);
+  hipLaunchKernelGGL(lazy_check_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, list, listCount, batch, nextList, nextCount);
 }
 
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,

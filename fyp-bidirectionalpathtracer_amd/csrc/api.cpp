@@ -577,10 +577,12 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
       HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));
       launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
+      stageMark(c, st, "lazy_gen");
       launchTraceShadow(c->S, F, P, c->numCUs, st);
+      stageMark(c, st, "lazy_trace");
       launchLazyCheck(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, next, P.lazyCount + (size_t)(r + 1) * kCursorBlock, st);
     }
-    stageMark(c, st, "lazy_rounds");
+    stageMark(c, st, "lazy_check");
   }
   if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
     launchResolve(c->splat, 0, out, c->W, c->tile.y0, c->tile.y1, st);

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
   T.cur = kDone;
   uint32_t nNodes = 0, nTris = 0;
   // wave-uniform fetch state: current sub-queue and the chunk [chunkPos, chunkEnd) taken from it
-  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0;
+  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
+  const uint32_t wavesPerList = (gridDim.x + Q.numSub - 1) / Q.numSub;
   for (;;) {
     const unsigned long long idleMask = __ballot(!has);
     const int idle = __popcll(idleMask);
@@ -271,12 +272,16 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
         const uint32_t nq = Q.count[q * kCursorStride];
         uint32_t base = nq;
         if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
-          if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], kFetchChunk);
+          // rays per atomic: up to kFetchChunk, but no more than this list's fair share per wave, so
+          // that short queues (late bounces, lazy rounds) still spread over every resident wave
+          uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
+          chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
+          if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], chunk);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         }
         if (base < nq) {
           chunkPos = base;
-          chunkEnd = (base + kFetchChunk < nq) ? base + kFetchChunk : nq;
+          chunkEnd = (base + chunk < nq) ? base + chunk : nq;
           tried = 0;
         } else {
           q = (q + 1 == Q.numSub) ? 0u : q + 1;

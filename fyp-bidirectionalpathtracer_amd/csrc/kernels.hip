@@ -717,15 +717,26 @@ __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, 
   int ord = act ? (int)P.lazyCursor[p] : nPairs;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0, lightLast = act ? (int)P.lightLast[p] : -1;
   uint32_t nRays = 0;
+  const bool lightGhost = act && (int)P.lightReal[p] < lightLast;  // last light vertex is a copy of its predecessor
   for (int b = 0; b < batch; b++) {
-    while (ord < nPairs && P.slotRay[(size_t)(2 * D + ord) * P.Np + p] != kNoRay) ord++;  // had a ray: it was occluded
+    int totalLength = 0, cameraLength = 0, lightLength = 0;
+    for (; ord < nPairs; ord++) {
+      if (P.slotRay[(size_t)(2 * D + ord) * P.Np + p] != kNoRay) continue;  // had a ray: it was occluded
+      pairFromOrdinal(D, ord, totalLength, cameraLength);
+      lightLength = totalLength - cameraLength;
+      // Vertices past the end of a sub-path are all the zero vertex and a ghost repeats its predecessor,
+      // so many pairs are the SAME ray (bitwise equal end points).  Only the first pair of each such
+      // class in the reference's order needs tracing: it comes earlier and, the pixel still being
+      // pending, was occluded.
+      const int cmin = (cameraLength <= eyeLast) ? cameraLength : eyeLast + 1;
+      int lmin = (lightLength > lightLast) ? lightLast + 1 : ((lightGhost && lightLength == lightLast) ? lightLast - 1 : lightLength);
+      if (cmin == 1 && lmin == 0) lmin = 1;  // (cameraLength 1, lightLength 0) has total length 1: not a pair
+      if (cameraLength == cmin && lightLength == lmin) break;
+    }
     const bool emit = act && ord < nPairs;
     f3 posA = mk(0), dirAB = mk(0);
     float lengthAB = 0.0f;
     if (emit) {
-      int totalLength, cameraLength;
-      pairFromOrdinal(D, ord, totalLength, cameraLength);
-      const int lightLength = totalLength - cameraLength;
       posA = (cameraLength <= eyeLast) ? ldPlane3(P, PATH_EYE, cameraLength, F_POS, p) : mk(0);
       const f3 posB = (lightLength <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength, F_POS, p) : mk(0);
       lengthAB = length(posB - posA);

@@ -18,6 +18,9 @@ struct Hit {
   float t, u, v;
 };
 
+#ifndef BDPT_ORDERED_ANYHIT
+#define BDPT_ORDERED_ANYHIT 0
+#endif
 constexpr int kDone = (int)0x80000000;  // traversal cursor value: stack exhausted
 
 struct TravState {
@@ -124,22 +127,61 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
     if (r1 != kDone) travPush(T, stk, r1);
     T.cur = (r0 != kDone) ? r0 : travPop(T, stk);
   } else {
-    int next = kDone;
-    if (hit[3]) next = r3;
-    if (hit[2]) {
-      if (next != kDone) travPush(T, stk, next);
-      next = r2;
+    // Branch-free: walk the slots from 3 down to 0 keeping the last hit in `next`; a newly found hit
+    // pushes the previous one.  The LDS store is unconditional (a slot above sp is scratch), only the
+    // stack pointer moves conditionally, so the wave never splits here.
+    int next = hit[3] ? r3 : kDone;
+    int sp = T.sp;
+#pragma unroll
+    for (int c = 2; c >= 0; c--) {
+      const int rc = (c == 2) ? r2 : ((c == 1) ? r1 : r0);
+      stk[sp * kWave] = next;
+      sp += (hit[c] && next != kDone) ? 1 : 0;
+      next = hit[c] ? rc : next;
     }
-    if (hit[1]) {
-      if (next != kDone) travPush(T, stk, next);
-      next = r1;
-    }
-    if (hit[0]) {
-      if (next != kDone) travPush(T, stk, next);
-      next = r0;
-    }
-    T.cur = (next != kDone) ? next : travPop(T, stk);
+    T.sp = sp;
+    if (next == kDone) next = travPop(T, stk);
+    T.cur = next;
   }
+}
+
+// One triangle of a leaf (index into S.tris); returns true when an any-hit query is finished.
+// Moeller-Trumbore exactly as the oracle evaluates it (this is the part that must match bit for bit).
+template <int MODE>
+BD bool triStep(const SceneDev& S, TravState& T, uint32_t triIndex) {
+  const float4* tp = S.tris + (size_t)triIndex * 3;
+  const float4 a = tp[0], b = tp[1], c = tp[2];
+  const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
+  const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
+  const f3 pvec = cross(T.d, e2);
+  const float det = dot(e1, pvec);
+  if (MODE == 1 && !(flags & 2u)) {
+    if (!(det > 0.0f)) return false;
+  } else {
+    if (det == 0.0f) return false;
+  }
+  const float inv = 1.0f / det;
+  const f3 tvec = T.o - v0;
+  const float u = dot(tvec, pvec) * inv;
+  if (u < 0.0f || u > 1.0f) return false;
+  const f3 qvec = cross(tvec, e1);
+  const float v = dot(T.d, qvec) * inv;
+  if (v < 0.0f || u + v > 1.0f) return false;
+  const float t = dot(e2, qvec) * inv;
+  if (!((t > T.tmin) && (t < T.tmax))) return false;
+  if ((flags & 1u) && alphaTestFails(S, prim, u, v)) return false;  // any-hit shader: IgnoreHit()
+  if (MODE == 2) {
+    T.best.prim = 0;
+    T.best.t = t;
+    return true;
+  }
+  if (t < T.best.t || (t == T.best.t && T.best.prim >= 0 && (int)prim < T.best.prim)) {
+    T.best.prim = (int)prim;
+    T.best.t = t;
+    T.best.u = u;
+    T.best.v = v;
+  }
+  return false;
 }
 
 // All triangles of the leaf in T.cur; returns true when an any-hit query is finished.
@@ -148,39 +190,8 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   const uint32_t enc = (uint32_t)(-1 - T.cur);
   const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
   for (uint32_t k = 0; k < cnt; k++) {
-    const float4* tp = S.tris + (size_t)(first + k) * 3;
-    const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) nTris++;
-    const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
-    const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
-    const f3 pvec = cross(T.d, e2);
-    const float det = dot(e1, pvec);
-    if (MODE == 1 && !(flags & 2u)) {
-      if (!(det > 0.0f)) continue;
-    } else {
-      if (det == 0.0f) continue;
-    }
-    const float inv = 1.0f / det;
-    const f3 tvec = T.o - v0;
-    const float u = dot(tvec, pvec) * inv;
-    if (u < 0.0f || u > 1.0f) continue;
-    const f3 qvec = cross(tvec, e1);
-    const float v = dot(T.d, qvec) * inv;
-    if (v < 0.0f || u + v > 1.0f) continue;
-    const float t = dot(e2, qvec) * inv;
-    if (!((t > T.tmin) && (t < T.tmax))) continue;
-    if ((flags & 1u) && alphaTestFails(S, prim, u, v)) continue;  // any-hit shader: IgnoreHit()
-    if (MODE == 2) {
-      T.best.prim = 0;
-      T.best.t = t;
-      return true;
-    }
-    if (t < T.best.t || (t == T.best.t && T.best.prim >= 0 && (int)prim < T.best.prim)) {
-      T.best.prim = (int)prim;
-      T.best.t = t;
-      T.best.u = u;
-      T.best.v = v;
-    }
+    if (triStep<MODE>(S, T, first + k)) return true;
   }
   return false;
 }
@@ -193,7 +204,7 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
   while (T.cur != kDone) {
     while (T.cur >= 0) {
       if (COUNT) nNodes++;
-      nodeStep<MODE != 2>(S, T, stk);
+      nodeStep<(MODE != 2) || BDPT_ORDERED_ANYHIT>(S, T, stk);
     }
     if (T.cur == kDone) break;
     if (leafStep<MODE, COUNT>(S, T, nTris)) break;
@@ -220,7 +231,10 @@ BD void waveAddCount(DevCounters* c, int idx, uint32_t n) {
 // Inside, the loop is while-while: all lanes descend interior nodes together, then all lanes
 // that reached a leaf intersect triangles together.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRefillIdle = 16;
+#ifndef BDPT_REFILL_IDLE
+#define BDPT_REFILL_IDLE 16
+#endif
+constexpr int kRefillIdle = BDPT_REFILL_IDLE;
 
 struct RayQueue {         // SoA planes, stride = cap: ox oy oz dx dy dz tmax
   const float* rays;
@@ -311,10 +325,15 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
       }
     }
     if (__ballot(has) == 0ull) break;  // exhausted and every lane retired
+    // while-while: every occupied lane descends interior nodes until it sits on a leaf (or is done),
+    // then every lane on a leaf intersects its triangles.  (A majority-vote schedule — one node step
+    // OR one triangle test per iteration, whichever group is larger — raised lane utilisation from
+    // 0.33 to 0.52 but executed as many wave instructions because of its per-iteration bookkeeping,
+    // so the simpler loop stays: profiles/r1.)
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<MODE != 2>(S, T, stk);
+        nodeStep<(MODE != 2) || BDPT_ORDERED_ANYHIT>(S, T, stk);
       }
       bool finished = (T.cur == kDone);
       if (!finished) {

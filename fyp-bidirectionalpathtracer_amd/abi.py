@@ -18,6 +18,8 @@ PARAM_NO_NEE = 4
 PARAM_NO_SPLAT = 8
 PARAM_NO_CONNECT = 16
 PARAM_SPECULAR_FROM_LOBE = 32
+PARAM_MIS_POWER = 64
+PARAM_MIS_LINEAR = 128
 
 
 class Material(C.Structure):

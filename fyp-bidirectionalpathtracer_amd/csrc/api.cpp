@@ -444,6 +444,8 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     if ((rc = devAlloc(c, c->frameAllocs, &P.slotRay, (size_t)slots * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.splatPix, (size_t)D * np))) return rc;
     const uint32_t batch = (numConnectPairs(D) + kLazyRounds - 1) / kLazyRounds;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.misE, (size_t)(D + 1) * np))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &P.misL, (size_t)(D + 1) * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyCursor, np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyRay, (size_t)std::max<uint32_t>(batch, 1) * np))) return rc;
   }
@@ -562,6 +564,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     }
     stageMark(c, st, "light_extend");
   }
+  if (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) launchMisPrefix(F, P, st);
   launchGenShadow(c->S, F, P, st);
   stageMark(c, st, "gen_shadow");
   launchTraceShadow(c->S, F, P, c->numCUs, st);

@@ -23,9 +23,9 @@ constexpr uint32_t kCursorStride = 32;
 constexpr uint32_t kCursorBlock = kNumSubQueues * kCursorStride;  // words of one sharded cursor  // uint32 words between two sub-queue cursors: one 128-byte line each
 constexpr uint32_t kCounterShards = 64;
 
-// Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45, minus pdfForward which only
-// the never-called MIS code reads).
-enum : int { F_COL = 0, F_POS = 3, F_N = 6, F_V = 9, F_DIF = 12, F_SPEC = 15, F_ROUGH = 18, F_ISSPEC = 19, NF = 20 };
+// Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45).  pdfForward is only read by the
+// MIS weights (BDPT_PARAM_MIS_*), which the reference defines but never calls.
+enum : int { F_COL = 0, F_POS = 3, F_N = 6, F_V = 9, F_DIF = 12, F_SPEC = 15, F_ROUGH = 18, F_ISSPEC = 19, F_PDF = 20, NF = 21 };
 enum : int { PATH_EYE = 0, PATH_LIGHT = 1 };
 
 struct TexDev {
@@ -94,6 +94,8 @@ struct PathBuf {
   uint32_t raySubCap;    // capacity of one sub-queue; ray id = subQueue*raySubCap + offset
   uint32_t* slotRay;     // planes: slot*Np + p -> ray id or kNoRay.  slots: [0,D) NEE, [D,2D) splat, [2D,..) pairs
   uint32_t* splatPix;    // planes: t*Np + p -> full-frame pixel index of splat t
+  float* misE;           // planes: k*Np + p, k in [0, D]: eye-side prefix product of getWeightPower/Linear
+  float* misL;           // same, light side
   uint8_t* lazyCursor;   // next connection-pair ordinal a pending pixel has not examined yet
   uint32_t* lazyRay;     // planes: b*Np + p -> ray id of the b-th lazy ray of the current round
   uint32_t* lazyCount;   // cursor blocks: pending-list lengths, one block per round
@@ -125,6 +127,7 @@ void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hip
 // one bounce = persistent closest-hit trace over qin + dense shade/compact into qout
 void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
                   const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st);
+void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st);
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st);

@@ -81,12 +81,14 @@ struct Vtx {
   f3 color, pos, N, V, dif, spec;
   float rough;
   bool isSpec;
+  float pdf;
 };
 BD Vtx zeroVtx() {
   Vtx v;
   v.color = v.pos = v.N = v.V = v.dif = v.spec = mk(0);
   v.rough = 0.0f;
   v.isSpec = false;
+  v.pdf = 0.0f;
   return v;
 }
 BD void storeVtx(const PathBuf& P, int path, int k, uint32_t p, const Vtx& v) {
@@ -98,6 +100,7 @@ BD void storeVtx(const PathBuf& P, int path, int k, uint32_t p, const Vtx& v) {
   stPlane3(P, path, k, F_SPEC, p, v.spec);
   stPlane1(P, path, k, F_ROUGH, p, v.rough);
   stPlane1(P, path, k, F_ISSPEC, p, v.isSpec ? 1.0f : 0.0f);
+  stPlane1(P, path, k, F_PDF, p, v.pdf);
 }
 // geometry + material of a stored vertex (no colour, no V)
 BD void loadSurf(const PathBuf& P, int path, int k, uint32_t p, Vtx& v) {
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
       v.spec = spec;
       v.rough = roughness;
       v.isSpec = isSpec;
+      v.pdf = pdf;
       storeVtx(P, PATH_EYE, 1, p, v);
       float* rd = P.rayDir + (size_t)(PATH_EYE * 3) * P.Np + p;
       rd[0] = outDir.x;
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
       Vtx lv = zeroVtx();
       lv.pos = ld3(l.posW);
       lv.color = ld3(l.intensity);
+      lv.pdf = 1.0f / (float)lightsCount;  // lightPath[0].pdfForward, BDPTMain.rt.hlsl:132
       storeVtx(P, PATH_LIGHT, 0, p, lv);
       float* rl = P.rayDir + (size_t)(PATH_LIGHT * 3) * P.Np + p;
       rl[0] = lightDir.x;
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, Pa
       v.spec = sd.specular;
       v.rough = sd.roughness;
       v.isSpec = isSpec;
+      v.pdf = pdf;
       storeVtx(P, path, k + 1, p, v);
       float* wr = P.rayDir + (size_t)(path * 3) * P.Np + p;
       wr[0] = L.x;
@@ -336,6 +342,7 @@ __global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, Pa
       } else {
         loadSurf(P, path, k, p, g);
         g.V = ldPlane3(P, path, k, F_V, p);
+        g.pdf = (path == PATH_LIGHT && k == 0) ? 0.0f : ldPlane1(P, path, k, F_PDF, p);  // initPayload: pdfForward = 0
       }
       g.color = mk(0);
       storeVtx(P, path, k + 1, p, g);
@@ -364,6 +371,88 @@ __global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, Pa
 // way; connection terms only matter through the per-write saturate, which the gather stage
 // reproduces with at most a few lazily traced rays.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// MIS weights — getWeightPower / getWeightLinear (BDPT/BDPTUtils.hlsli:226-278), which the reference
+// defines but never calls (it weights every strategy 1/k).  Behind BDPT_PARAM_MIS_POWER / _LINEAR:
+//   pE(i) = cameraPath[0].pdfForward * prod_{x=1..i} cameraPath[x].pdfForward * evalGWithoutV(x-1, x)
+//   pL(j) likewise on the light path;  w(c,l) = f(pE(c) pL(l)) / sum_{i+j=c+l} f(pE(i) pL(j)),  f = x or x^2
+// (`if (i == cameraIndex, j == lightIndex)` at :245/:272 is a comma expression; since i + j is fixed it
+// selects the same term as the intended `&&`.)  Faithful consequence worth knowing: lightPath[0].N = 0
+// makes evalGWithoutV(light[0], light[1]) = 0, so pL(j >= 1) = 0 and every strategy that uses a light
+// vertex gets weight 0 while NEE gets 1 — the estimator degenerates to path tracing with NEE.
+// ------------------------------------------------------------------------------------------------
+BD float evalGWithoutVPos(f3 posA, f3 nA, f3 posB, f3 nB) {  // BDPTUtils.hlsli:172-184
+  const f3 vecAB = posB - posA;
+  const float invLengthAB = 1.0f / length(vecAB);
+  const f3 dirAB = vecAB * invLengthAB;
+  const float cosA = fabsf(dot(nA, dirAB));
+  const float cosB = fabsf(dot(nB, dirAB));
+  return cosA * cosB * invLengthAB * invLengthAB;
+}
+
+__global__ __launch_bounds__(kWave) void mis_prefix_kernel(FrameDev F, PathBuf P) {
+  bool act = false;
+  uint32_t i = 0;
+  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
+  if (!act) return;
+  const uint32_t p = P.queue[0][i];
+  const int D = (int)F.p.maxDepth;
+  const int eyeLast = P.eyeLast[p], lightLast = P.lightLast[p];
+  // eye side: vertex 0 is the camera (pos, N = normalize(cameraW), pdfForward 1), BDPTMain.rt.hlsl:90-93
+  f3 prevPos = ld3(F.cam.posW), prevN = normalize(ld3(F.cam.cameraW));
+  float pE = 1.0f;
+  P.misE[p] = pE;
+  for (int x = 1; x <= D; x++) {
+    f3 pos = mk(0), N = mk(0);
+    float pdf = 0.0f;
+    if (x <= eyeLast) {
+      pos = ldPlane3(P, PATH_EYE, x, F_POS, p);
+      N = ldPlane3(P, PATH_EYE, x, F_N, p);
+      pdf = ldPlane1(P, PATH_EYE, x, F_PDF, p);
+    }
+    pE *= pdf * evalGWithoutVPos(prevPos, prevN, pos, N);
+    P.misE[(size_t)x * P.Np + p] = pE;
+    prevPos = pos;
+    prevN = N;
+  }
+  prevPos = ldPlane3(P, PATH_LIGHT, 0, F_POS, p);
+  prevN = ldPlane3(P, PATH_LIGHT, 0, F_N, p);
+  float pL = ldPlane1(P, PATH_LIGHT, 0, F_PDF, p);
+  P.misL[p] = pL;
+  for (int x = 1; x <= D; x++) {
+    f3 pos = mk(0), N = mk(0);
+    float pdf = 0.0f;
+    if (x <= lightLast) {
+      pos = ldPlane3(P, PATH_LIGHT, x, F_POS, p);
+      N = ldPlane3(P, PATH_LIGHT, x, F_N, p);
+      pdf = ldPlane1(P, PATH_LIGHT, x, F_PDF, p);
+    }
+    pL *= pdf * evalGWithoutVPos(prevPos, prevN, pos, N);
+    P.misL[(size_t)x * P.Np + p] = pL;
+    prevPos = pos;
+    prevN = N;
+  }
+}
+
+BD float misWeight(const PathBuf& P, uint32_t p, int cameraIndex, int lightIndex, bool power) {
+  const int totalLength = cameraIndex + lightIndex;
+  float totalPdf = 0.0f, currentPdf = 1.0f;
+  for (int i = 0; i <= totalLength; i++) {
+    const int j = totalLength - i;
+    const float pE = P.misE[(size_t)i * P.Np + p], pL = P.misL[(size_t)j * P.Np + p];
+    const float term = power ? (pE * pE * pL * pL) : (pE * pL);
+    totalPdf += term;
+    if (j == lightIndex) currentPdf = term;
+  }
+  return currentPdf / totalPdf;
+}
+// the factor a term is scaled by: the reference's uniform 1/k, or the MIS weight when switched on
+BD f3 applyStrategyWeight(const FrameDev& F, const PathBuf& P, uint32_t p, f3 v, int k, int cameraIndex, int lightIndex) {
+  if (F.p.flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR))
+    return v * misWeight(P, p, cameraIndex, lightIndex, (F.p.flags & BDPT_PARAM_MIS_POWER) != 0);
+  return v / (float)k;
+}
+
 BD uint32_t emitRay(const PathBuf& P, bool active, f3 o, f3 d, float tmax, f3 contrib) {
   const unsigned long long mask = __ballot(active);
   uint32_t id = kNoRay;
@@ -450,7 +539,7 @@ __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, 
         f3 lightIntensity;
         getLightData(S.sc->lights[lightToSample], pos, L, lightIntensity, distToLight);
         f3 direct = directIfVisible<GGX>((float)lightsCount, L, lightIntensity, N, V, dif, spec, rough);
-        shade = clampVec((prevColor * direct) / (float)(t + 2), F.p.clampUpper);
+        shade = clampVec(applyStrategyWeight(F, P, p, prevColor * direct, t + 2, t + 1, 0), F.p.clampUpper);
         emit = !allZero(shade);
         prevColor = ldPlane3(P, PATH_EYE, t + 1, F_COL, p);
       } else {
@@ -511,7 +600,7 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
             if (GGX) vV = ldPlane3(P, PATH_LIGHT, t + 1, F_V, p);
             f3 fr = evalBRDF<GGX>(vV, normalize(camPos - lv.pos), lv.N, lv.N, lv.dif, lv.spec, lv.rough, lv.isSpec);
             f3 prevColor = ldPlane3(P, PATH_LIGHT, t, F_COL, p);
-            shade = clampVec(((prevColor * fr) * G) / (float)(t + 2), F.p.clampUpper);
+            shade = clampVec(applyStrategyWeight(F, P, p, (prevColor * fr) * G, t + 2, 0, t + 1), F.p.clampUpper);
             if (isnan3(shade)) shade = mk(0);
           }
         }
@@ -592,7 +681,7 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
             c = (aL * cst) * aE;
           }
         }
-        shade = clampVec(c / (float)totalLength, F.p.clampUpper);
+        shade = clampVec(applyStrategyWeight(F, P, p, c, totalLength, cameraLength, lightLength), F.p.clampUpper);
         if (isnan3(shade)) shade = mk(0);
         if (!allZero(shade)) {
           emit = true;
@@ -941,6 +1030,10 @@ void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int pa
                        countOut);
 }
 
+void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st) {
+  if (!P.Np) return;
+  hipLaunchKernelGGL(mis_prefix_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P);
+}
 void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
   const dim3 g(queueGrid(P)), b(kWave);

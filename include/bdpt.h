@@ -174,6 +174,10 @@ typedef struct bdpt_params {
 /* sampleGGXBRDF never writes its `out bool isSpecular` (MaterialUtils.hlsli:209-252): undefined in
  * HLSL.  Default build definition: false.  With this flag: true iff the GGX lobe was sampled. */
 #define BDPT_PARAM_SPECULAR_FROM_LOBE 32u
+/* Weight every strategy with getWeightPower / getWeightLinear (BDPTUtils.hlsli:226-278) instead of the
+ * uniform 1/k the reference applies (it defines these functions but never calls them). */
+#define BDPT_PARAM_MIS_POWER 64u
+#define BDPT_PARAM_MIS_LINEAR 128u
 
 /* RayGenCB of lightProbeGBuffer.rt.hlsl:45-52 + the miss shader's env map. */
 typedef struct bdpt_gbuffer_params {

@@ -915,6 +915,34 @@ f3 getUnweightedContribution(const Globals& g, const PathVertex* cameraPath, con
   return (aL * cst) * aE;
 }
 
+// BDPT/BDPTUtils.hlsli:226-251 (power = true) and :253-278 (power = false).  The reference defines both
+// and never calls them; the build wires them in behind BDPT_PARAM_MIS_POWER / BDPT_PARAM_MIS_LINEAR.
+// `if (i == cameraIndex, j == lightIndex)` is a comma expression: it tests j == lightIndex, which,
+// i + j being fixed, selects the intended term.
+float getWeight(const PathVertex* cameraPath, const PathVertex* lightPath, uint32_t cameraIndex, uint32_t lightIndex, bool power) {
+  uint32_t totalLength = cameraIndex + lightIndex;
+  float totalPdf = 0;
+  float currentPdf = 1;
+  for (uint32_t i = 0; i <= totalLength; i++) {
+    uint32_t j = totalLength - i;
+    float pE = cameraPath[0].pdfForward;
+    for (uint32_t x = 1; x <= i; x++) pE *= cameraPath[x].pdfForward * evalGWithoutV(cameraPath[x - 1], cameraPath[x]);
+    float pL = lightPath[0].pdfForward;
+    for (uint32_t x = 1; x <= j; x++) pL *= lightPath[x].pdfForward * evalGWithoutV(lightPath[x - 1], lightPath[x]);
+    const float term = power ? (pE * pE * pL * pL) : (pE * pL);
+    totalPdf += term;
+    if (j == lightIndex) currentPdf = term;
+  }
+  return currentPdf / totalPdf;
+}
+// uniform 1/k of the reference, or the MIS weight when switched on
+inline f3 applyStrategyWeight(const Globals& g, const PathVertex* cameraPath, const PathVertex* lightPath, f3 v, uint32_t k,
+                              uint32_t cameraIndex, uint32_t lightIndex) {
+  if (g.p.flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR))
+    return v * getWeight(cameraPath, lightPath, cameraIndex, lightIndex, (g.p.flags & BDPT_PARAM_MIS_POWER) != 0);
+  return v / (float)k;
+}
+
 // BDPT/BDPTUtils.hlsli:129-138; signed index + range check is the build's definition (quirk 8)
 inline bool getLaunchIndexFromDirection(const Globals& g, f3 dir, int& ix, int& iy) {
   f3 U = ld3(g.cam.cameraU), V = ld3(g.cam.cameraV), Wv = ld3(g.cam.cameraW);
@@ -1041,7 +1069,7 @@ void bdptPixel(const Globals& g, Tally& tl, oracle_frame* f, uint32_t x, uint32_
     f3 direct = (g.p.matIndex == 0) ? ggxDirect(g, tl, randSeed, v.posW, v.N, v.V, v.dif, v.spec, v.rough)
                                     : lambertianDirect(g, tl, randSeed, v.posW, v.N, v.dif);
     f3 shade = cameraPath[i].color * direct;
-    shade = clampVec(g, shade / (float)(i + 2));
+    shade = clampVec(g, applyStrategyWeight(g, cameraPath, lightPath, shade, i + 2, i + 1, 0));
     bool colorsNan = isnan3(shade);
     if (doNee) {
       out[0] = out[0] + (colorsNan ? 0.0f : shade.x);
@@ -1071,7 +1099,7 @@ void bdptPixel(const Globals& g, Tally& tl, oracle_frame* f, uint32_t x, uint32_
         // connectToCamera, MaterialUtils.hlsli:10-13
         f3 fr = evalBRDF(g, lv.V, normalize(camPos - lv.posW), lv.N, lv.N, lv.dif, lv.spec, lv.rough, lv.isSpecular);
         f3 shade = (lightPath[i].color * fr) * G;
-        shade = clampVec(g, shade / (float)(i + 2));
+        shade = clampVec(g, applyStrategyWeight(g, cameraPath, lightPath, shade, i + 2, 0, i + 1));
         bool colorsNan = isnan3(shade);
         if (colorsNan) shade = mk(0);
         if (inside) {
@@ -1099,7 +1127,7 @@ void bdptPixel(const Globals& g, Tally& tl, oracle_frame* f, uint32_t x, uint32_
       bool vis = shadowRayVisibility(g, tl, 5, posA, dirAB, g.p.minT, lengthAB);
       if (vis) {
         f3 shade = getUnweightedContribution(g, cameraPath, lightPath, cameraLength, lightLength, G);
-        shade = clampVec(g, shade / (float)totalLength);
+        shade = clampVec(g, applyStrategyWeight(g, cameraPath, lightPath, shade, totalLength, cameraLength, lightLength));
         bool colorsNan = isnan3(shade);
         out[0] = saturate(out[0] + (colorsNan ? 0.0f : shade.x));
         out[1] = saturate(out[1] + (colorsNan ? 0.0f : shade.y));

@@ -182,6 +182,19 @@ def test_partial_images_compose():
     assert (so[..., :3] <= 1.0).all()
 
 
+def test_mis_weights_degenerate_as_the_reference_defines_them(pkg, ob):
+    """getWeightPower/Linear (BDPTUtils.hlsli:226-278) use evalGWithoutV(lightPath[0], lightPath[1]) with
+    lightPath[0].N = 0, so every strategy that uses a light vertex gets weight 0 and NEE gets weight 1."""
+    for flag in (pkg.abi.PARAM_MIS_POWER, pkg.abi.PARAM_MIS_LINEAR):
+        img, splat, cnt, _ = _golden_render(pkg, "mis", 32, 4, 1, flag, brute=False)
+        assert (splat[:, :3] == 0).all() and splat[:, 3].sum() > 0      # splats land but carry zero radiance
+        nee, _, _, _ = _golden_render(pkg, "nee", 32, 4, 1, flag | pkg.abi.PARAM_NO_SPLAT | pkg.abi.PARAM_NO_CONNECT, brute=False)
+        lit = nee[..., :3].sum(axis=-1) > 0
+        assert lit.sum() > 100
+        # with connections on, rgb only differs from NEE-only through the per-write saturate
+        assert np.array_equal(np.minimum(nee[..., :3], 1.0)[lit], np.minimum(img[..., :3], 1.0)[lit])
+
+
 def test_oracle_accumulate_running_mean(pkg, ob):
     lib = ob.load_oracle(pkg.abi)
     rng = np.random.default_rng(7)

@@ -211,6 +211,7 @@ def test_partial_stage_images_and_depths(pkg, ob):
     a = pkg.abi
     for depth, mat, flags in ((3, 0, a.PARAM_NO_SPLAT | a.PARAM_NO_CONNECT), (3, 0, a.PARAM_NO_NEE | a.PARAM_NO_CONNECT),
                               (4, 0, a.PARAM_NO_NEE | a.PARAM_NO_SPLAT), (5, 0, a.PARAM_SPECULAR_FROM_LOBE), (12, 1, 0),
+                              (4, 0, a.PARAM_MIS_POWER), (5, 1, a.PARAM_MIS_LINEAR),
                               (16, 0, 0)):
         pipe = pkg.FramePipeline(scene, 32, 24, max_depth=depth, mat_index=mat, flags=flags)
         gp, p = pipe.render_frame()

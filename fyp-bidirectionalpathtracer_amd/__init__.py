@@ -48,6 +48,15 @@ class Scene:
     def soup(cls, seed, num_triangles, max_edge=0.25):
         return cls(load_library().bdpt_scene_create_soup(seed, num_triangles, max_edge))
 
+    @classmethod
+    def load(cls, path):
+        """`.fscene` / `.obj` ingestion (SharedUtils/SceneLoaderWrapper.cpp:56-103)."""
+        msg = C.create_string_buffer(512)
+        h = load_library().bdpt_scene_load(str(path).encode(), msg, 512)
+        if not h:
+            raise BdptError("bdpt_scene_load: " + msg.value.decode(errors="replace"))
+        return cls(h)
+
     def camera(self, aspect):
         cam = Camera()
         if self._lib.bdpt_scene_get_camera(self._h, float(aspect), C.byref(cam)) != 0:

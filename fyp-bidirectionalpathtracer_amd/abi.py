@@ -40,6 +40,9 @@ class Light(C.Structure):
                 ("penumbraAngle", C.c_float), ("reserved", C.c_float * 3)]
 
 
+LIGHT_POINT, LIGHT_DIRECTIONAL = 0, 1
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("numVertices", C.c_uint32), ("numTriangles", C.c_uint32), ("numMaterials", C.c_uint32),
                 ("numTextures", C.c_uint32), ("numLights", C.c_uint32), ("reserved", C.c_uint32),
@@ -125,6 +128,7 @@ PROTOTYPES = {
     "bdpt_scene_create_cornell": (C.c_void_p, []),
     "bdpt_scene_create_atrium": (C.c_void_p, [C.c_uint32, C.c_uint32]),
     "bdpt_scene_create_soup": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
+    "bdpt_scene_load": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_uint32]),
     "bdpt_scene_destroy": (None, [C.c_void_p]),
     "bdpt_scene_get_desc": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "bdpt_scene_get_camera": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(Camera)]),

@@ -59,6 +59,9 @@ class Scene {
   static SharedPtr createCornellBox();
   static SharedPtr createAtrium(uint32_t seed, uint32_t targetTriangles);
   static SharedPtr createTriangleSoup(uint32_t seed, uint32_t numTriangles, float maxEdge);
+  // `.fscene` (Falcor scene JSON) or `.obj` (+ .mtl, PPM/PGM/TGA textures); the role of
+  // RtScene::loadFromFile behind SharedUtils/SceneLoaderWrapper.cpp:56-60.  nullptr + *error on failure.
+  static SharedPtr loadFromFile(const std::string& path, std::string* error = nullptr);
 
   // Streams (12-byte stride each, Falcor ShadingUtils/Raytracing.slang:79-85)
   std::vector<float> positions, normals, bitangents, texcoords;

@@ -1,0 +1,771 @@
+// SceneLoader.cpp — scene ingestion: Falcor `.fscene` JSON + Wavefront OBJ/MTL
+// models + PPM/PGM/TGA textures, following the reference's loader semantics:
+//   .fscene keys, degrees->radians, instances      Falcor Graphics/Scene/SceneImporter.cpp:106-175, 310-460
+//   instance matrix = T * yawPitchRoll * S          Falcor Graphics/Model/ObjectInstance.h:271-278
+//   wrapper defaults (default light, aspect)       SharedUtils/SceneLoaderWrapper.cpp:56-103
+//   material rules                                 Falcor Graphics/Model/Loaders/AssimpModelImporter.cpp:326-417
+//     (MetalRough unless "shading_model": "spec_gloss"; Kd->baseColor, Ks->specular rgb, Ns->specular.a,
+//      Ke->emissive, d->baseColor.a, ".doublesided" name suffix; OBJ bump maps go to the normal-map slot)
+//   channel type: texture / const / unused(lum==0)  Falcor Graphics/Material/Material.cpp:162-184
+//   alpha mode = mask iff the base-colour texture has an alpha channel   Material.cpp:119-126
+//   specular TEXTURES are dropped: Material::setSpecularTexture never stores its argument (Material.cpp:128-132)
+//   colour textures are sRGB, normal maps linear     AssimpModelImporter.cpp:241-270
+// What the reference gets from Assimp/FreeImage and this loader does not: FBX and other model formats,
+// PNG/JPG/HDR images, smoothing groups (normals are taken from the file or set per face).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+#include "../../include/bdpt_scene.h"
+#include "Scene.h"
+
+namespace bdpt {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// minimal JSON (objects, arrays, strings, numbers, true/false/null)
+// ---------------------------------------------------------------------------------------------
+struct Json {
+  enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+  double num = 0;
+  bool b = false;
+  std::string str;
+  std::vector<Json> arr;
+  std::vector<std::pair<std::string, Json>> obj;
+  const Json* get(const std::string& k) const {
+    for (auto& kv : obj)
+      if (kv.first == k) return &kv.second;
+    return nullptr;
+  }
+};
+struct JsonParser {
+  const std::string& s;
+  size_t i = 0;
+  bool ok = true;
+  explicit JsonParser(const std::string& src) : s(src) {}
+  void ws() {
+    while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) i++;
+  }
+  Json value() {
+    ws();
+    Json j;
+    if (i >= s.size()) {
+      ok = false;
+      return j;
+    }
+    char c = s[i];
+    if (c == '{') {
+      j.type = Json::Obj;
+      i++;
+      ws();
+      if (i < s.size() && s[i] == '}') {
+        i++;
+        return j;
+      }
+      while (ok) {
+        ws();
+        Json k = value();
+        if (k.type != Json::Str) ok = false;
+        ws();
+        if (i >= s.size() || s[i] != ':') ok = false;
+        i++;
+        Json v = value();
+        j.obj.emplace_back(k.str, std::move(v));
+        ws();
+        if (i < s.size() && s[i] == ',') {
+          i++;
+          continue;
+        }
+        if (i < s.size() && s[i] == '}') {
+          i++;
+          break;
+        }
+        ok = false;
+      }
+    } else if (c == '[') {
+      j.type = Json::Arr;
+      i++;
+      ws();
+      if (i < s.size() && s[i] == ']') {
+        i++;
+        return j;
+      }
+      while (ok) {
+        j.arr.push_back(value());
+        ws();
+        if (i < s.size() && s[i] == ',') {
+          i++;
+          continue;
+        }
+        if (i < s.size() && s[i] == ']') {
+          i++;
+          break;
+        }
+        ok = false;
+      }
+    } else if (c == '"') {
+      j.type = Json::Str;
+      i++;
+      while (i < s.size() && s[i] != '"') {
+        if (s[i] == '\\' && i + 1 < s.size()) {
+          i++;
+          char e = s[i];
+          j.str += (e == 'n') ? '\n' : (e == 't') ? '\t' : e;
+        } else {
+          j.str += s[i];
+        }
+        i++;
+      }
+      i++;
+    } else if (!s.compare(i, 4, "true")) {
+      j.type = Json::Bool;
+      j.b = true;
+      i += 4;
+    } else if (!s.compare(i, 5, "false")) {
+      j.type = Json::Bool;
+      i += 5;
+    } else if (!s.compare(i, 4, "null")) {
+      i += 4;
+    } else {
+      j.type = Json::Num;
+      size_t st = i;
+      while (i < s.size() && (std::isdigit((unsigned char)s[i]) || s[i] == '-' || s[i] == '+' || s[i] == '.' || s[i] == 'e' || s[i] == 'E')) i++;
+      if (st == i) {
+        ok = false;
+        return j;
+      }
+      j.num = std::strtod(s.substr(st, i - st).c_str(), nullptr);
+    }
+    return j;
+  }
+};
+bool vec3Of(const Json* j, float v[3]) {
+  if (!j || j->type != Json::Arr || j->arr.size() != 3) return false;
+  for (int k = 0; k < 3; k++) v[k] = (float)j->arr[(size_t)k].num;
+  return true;
+}
+
+std::string dirOf(const std::string& path) {
+  size_t p = path.find_last_of("/\\");
+  return p == std::string::npos ? "." : path.substr(0, p);
+}
+std::string lower(std::string s) {
+  std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+  return s;
+}
+bool endsWith(const std::string& s, const std::string& suf) { return s.size() >= suf.size() && lower(s).compare(s.size() - suf.size(), suf.size(), suf) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// images: binary PPM (P6) / PGM (P5), TGA (uncompressed and RLE, 24/32-bit colour, 8-bit grey)
+// ---------------------------------------------------------------------------------------------
+bool loadImage(const std::string& path, Scene::Texture& out, bool& hasAlpha) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  hasAlpha = false;
+  if (d.size() > 2 && d[0] == 'P' && (d[1] == '6' || d[1] == '5')) {
+    size_t p = 2;
+    auto num = [&]() -> long {
+      for (;;) {
+        while (p < d.size() && std::isspace(d[p])) p++;
+        if (p < d.size() && d[p] == '#') {
+          while (p < d.size() && d[p] != '\n') p++;
+          continue;
+        }
+        break;
+      }
+      long v = 0;
+      while (p < d.size() && std::isdigit(d[p])) v = v * 10 + (d[p++] - '0');
+      return v;
+    };
+    long w = num(), h = num(), mx = num();
+    p++;  // single whitespace after maxval
+    const int ch = d[1] == '6' ? 3 : 1;
+    if (w <= 0 || h <= 0 || mx != 255 || d.size() < p + (size_t)w * h * ch) return false;
+    out.width = (uint32_t)w;
+    out.height = (uint32_t)h;
+    out.rgba8.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+      const uint8_t* s = &d[p + i * ch];
+      out.rgba8[i * 4] = s[0];
+      out.rgba8[i * 4 + 1] = s[ch == 3 ? 1 : 0];
+      out.rgba8[i * 4 + 2] = s[ch == 3 ? 2 : 0];
+      out.rgba8[i * 4 + 3] = 255;
+    }
+    return true;
+  }
+  if (endsWith(path, ".tga") && d.size() >= 18) {
+    const int idLen = d[0], type = d[2], w = d[12] | (d[13] << 8), h = d[14] | (d[15] << 8), bpp = d[16], desc = d[17];
+    if ((type != 2 && type != 3 && type != 10 && type != 11) || (bpp != 8 && bpp != 24 && bpp != 32) || w <= 0 || h <= 0) return false;
+    const int ch = bpp / 8;
+    size_t p = 18 + (size_t)idLen;
+    std::vector<uint8_t> px((size_t)w * h * ch);
+    if (type == 2 || type == 3) {
+      if (d.size() < p + px.size()) return false;
+      std::memcpy(px.data(), &d[p], px.size());
+    } else {
+      size_t o = 0;
+      while (o < px.size() && p < d.size()) {
+        int hdr = d[p++], cnt = (hdr & 127) + 1;
+        if (hdr & 128) {
+          if (p + ch > d.size()) return false;
+          for (int k = 0; k < cnt && o + ch <= px.size(); k++, o += ch) std::memcpy(&px[o], &d[p], ch);
+          p += ch;
+        } else {
+          size_t nb = (size_t)cnt * ch;
+          if (p + nb > d.size() || o + nb > px.size()) return false;
+          std::memcpy(&px[o], &d[p], nb);
+          p += nb;
+          o += nb;
+        }
+      }
+    }
+    out.width = (uint32_t)w;
+    out.height = (uint32_t)h;
+    out.rgba8.resize((size_t)w * h * 4);
+    const bool topDown = (desc & 0x20) != 0;
+    for (int y = 0; y < h; y++) {
+      const int sy = topDown ? y : (h - 1 - y);
+      for (int x = 0; x < w; x++) {
+        const uint8_t* s = &px[((size_t)sy * w + x) * ch];
+        uint8_t* o = &out.rgba8[((size_t)y * w + x) * 4];
+        if (ch == 1) {
+          o[0] = o[1] = o[2] = s[0];
+          o[3] = 255;
+        } else {  // BGR(A)
+          o[0] = s[2];
+          o[1] = s[1];
+          o[2] = s[0];
+          o[3] = ch == 4 ? s[3] : 255;
+        }
+      }
+    }
+    hasAlpha = (ch == 4);
+    return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OBJ / MTL
+// ---------------------------------------------------------------------------------------------
+struct MtlInfo {
+  bdpt_material m;
+  std::string name;
+};
+inline float lum(const float* c) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
+
+struct ModelLoader {
+  Scene& s;
+  std::string dir;
+  bool specGloss;
+  std::map<std::string, int> texCache;
+  std::string err;
+  std::map<std::string, uint32_t> matIndex;  // per model file: instances share materials and textures
+  std::map<std::string, bool> mtlLoaded;
+  ModelLoader(Scene& sc, const std::string& d, bool sg) : s(sc), dir(d), specGloss(sg) {}
+
+  int texture(const std::string& file, bool srgb, bool* hasAlpha) {
+    std::string key = file + (srgb ? "|s" : "|l");
+    auto it = texCache.find(key);
+    if (it != texCache.end()) {
+      if (hasAlpha) *hasAlpha = alphaOf[it->second];
+      return it->second;
+    }
+    Scene::Texture t;
+    bool a = false;
+    std::string p = dir + "/" + file;
+    std::replace(p.begin(), p.end(), '\\', '/');
+    int id = -1;
+    if (loadImage(p, t, a)) {
+      t.srgb = srgb ? 1u : 0u;
+      id = (int)s.textures.size();
+      s.textures.push_back(std::move(t));
+    } else {
+      std::fprintf(stderr, "[SceneLoader] cannot load texture %s (supported: PPM/PGM/TGA)\n", p.c_str());
+    }
+    texCache[key] = id;
+    alphaOf[id] = a;
+    if (hasAlpha) *hasAlpha = a;
+    return id;
+  }
+  std::map<int, bool> alphaOf;
+
+  void finishMaterial(bdpt_material& m, bool doubleSided) {
+    // Material.cpp:162-184: texture > const (luminance != 0) > unused; emissive likewise
+    const uint32_t dif = m.texBaseColor >= 0 ? BDPT_CHANNEL_TEXTURE : (lum(m.baseColor) == 0 ? BDPT_CHANNEL_UNUSED : BDPT_CHANNEL_CONST);
+    const uint32_t spc = lum(m.specular) == 0 ? BDPT_CHANNEL_UNUSED : BDPT_CHANNEL_CONST;  // specular textures are dropped (see header)
+    const uint32_t emi = m.texEmissive >= 0 ? BDPT_CHANNEL_TEXTURE : (lum(m.emissive) == 0 ? BDPT_CHANNEL_UNUSED : BDPT_CHANNEL_CONST);
+    const bool mask = m.texBaseColor >= 0 && alphaOf[m.texBaseColor];
+    m.texSpecular = -1;
+    m.flags = BDPT_MAKE_FLAGS(specGloss ? BDPT_SHADING_MODEL_SPEC_GLOSS : BDPT_SHADING_MODEL_METAL_ROUGH, dif, spc, emi,
+                              m.texNormal >= 0 ? BDPT_NORMAL_MAP_RGB : BDPT_NORMAL_MAP_UNUSED, mask ? BDPT_ALPHA_MODE_MASK : BDPT_ALPHA_MODE_OPAQUE,
+                              doubleSided ? 1u : 0u);
+  }
+
+  bool loadMtl(const std::string& file, std::map<std::string, uint32_t>& matIndex) {
+    std::ifstream f(dir + "/" + file);
+    if (!f) return false;
+    std::string line;
+    bdpt_material cur{};
+    std::string curName;
+    bool have = false, dbl = false;
+    int nrmBump = -1, nrmNorm = -1, nrmDisp = -1;  // HEIGHT < NORMALS < DISPLACEMENT in aiTextureType order: the last one set wins
+    auto flush = [&]() {
+      if (!have) return;
+      cur.texNormal = (int16_t)(nrmDisp >= 0 ? nrmDisp : nrmNorm >= 0 ? nrmNorm : nrmBump);
+      // AssimpModelImporter.cpp:390-398: an OBJ material with a non-black Ke gets its BASE-COLOUR texture as emissive texture
+      if (lum(cur.emissive) > 0) cur.texEmissive = cur.texBaseColor;
+      finishMaterial(cur, dbl);
+      matIndex[curName] = (uint32_t)s.materials.size();
+      s.materials.push_back(cur);
+      nrmBump = nrmNorm = nrmDisp = -1;
+    };
+    while (std::getline(f, line)) {
+      std::istringstream ss(line);
+      std::string k;
+      if (!(ss >> k) || k[0] == '#') continue;
+      if (k == "newmtl") {
+        flush();
+        have = true;
+        std::string nm;
+        ss >> nm;
+        curName = nm;
+        std::string ln = lower(nm);
+        dbl = ln.find(".doublesided") != std::string::npos;  // AssimpModelImporter.cpp:405-413
+        cur = bdpt_material{};
+        cur.baseColor[0] = cur.baseColor[1] = cur.baseColor[2] = 0.6f;  // Assimp's OBJ material default (ObjFileData.h); Falcor copies it
+        cur.baseColor[3] = 1.0f;
+        cur.alphaThreshold = 0.5f;
+        cur.IoR = 1.0f;
+        cur.texBaseColor = cur.texSpecular = cur.texEmissive = cur.texNormal = -1;
+      } else if (!have) {
+        continue;
+      } else if (k == "Kd") {
+        ss >> cur.baseColor[0] >> cur.baseColor[1] >> cur.baseColor[2];
+      } else if (k == "Ks") {
+        ss >> cur.specular[0] >> cur.specular[1] >> cur.specular[2];
+      } else if (k == "Ns") {
+        ss >> cur.specular[3];
+      } else if (k == "Ke") {
+        ss >> cur.emissive[0] >> cur.emissive[1] >> cur.emissive[2];
+      } else if (k == "d") {
+        ss >> cur.baseColor[3];
+      } else if (k == "Ni") {
+        ss >> cur.IoR;
+      } else if (k == "map_Kd" || k == "map_kd" || k == "map_Ke" || k == "map_emissive" || k == "map_bump" || k == "map_Bump" || k == "bump" ||
+                 k == "norm" || k == "map_Kn" || k == "disp" || k == "map_disp") {
+        std::string t, last;
+        while (ss >> t) last = t;  // options such as `-bm 1.0` precede the file name
+        if (last.empty()) continue;
+        if (k == "map_Kd" || k == "map_kd")
+          cur.texBaseColor = (int16_t)texture(last, true, nullptr);
+        else if (k == "map_Ke" || k == "map_emissive")
+          cur.texEmissive = (int16_t)texture(last, true, nullptr);
+        else if (k == "norm" || k == "map_Kn")
+          nrmNorm = texture(last, false, nullptr);
+        else if (k == "disp" || k == "map_disp")
+          nrmDisp = texture(last, false, nullptr);
+        else
+          nrmBump = texture(last, false, nullptr);
+      }
+    }
+    flush();
+    return true;
+  }
+
+  // appends the model transformed by `mat` (row-major 3x4) to the scene
+  bool loadObj(const std::string& path, const float mat[12], const float nmat[9]) {
+    std::ifstream f(path);
+    if (!f) {
+      err = "cannot open " + path;
+      return false;
+    }
+    dir = dirOf(path);
+    std::vector<float> P, N, T;
+    uint32_t curMat = 0xFFFFFFFFu;
+    auto defaultMat = [&]() -> uint32_t {
+      auto it = matIndex.find("\x01" "default");
+      if (it != matIndex.end()) return it->second;
+      bdpt_material m{};
+      m.baseColor[0] = m.baseColor[1] = m.baseColor[2] = 0.6f;  // Assimp's "DefaultMaterial"
+      m.baseColor[3] = 1.0f;
+      m.alphaThreshold = 0.5f;
+      m.IoR = 1.0f;
+      m.texBaseColor = m.texSpecular = m.texEmissive = m.texNormal = -1;
+      finishMaterial(m, false);
+      matIndex["\x01" "default"] = (uint32_t)s.materials.size();
+      s.materials.push_back(m);
+      return matIndex["\x01" "default"];
+    };
+    faces.clear();
+    std::string line;
+    while (std::getline(f, line)) {
+      std::istringstream ss(line);
+      std::string k;
+      if (!(ss >> k) || k[0] == '#') continue;
+      if (k == "v") {
+        float a, b, c;
+        ss >> a >> b >> c;
+        P.insert(P.end(), {a, b, c});
+      } else if (k == "vn") {
+        float a, b, c;
+        ss >> a >> b >> c;
+        N.insert(N.end(), {a, b, c});
+      } else if (k == "vt") {
+        float a = 0, b = 0;
+        ss >> a >> b;
+        T.insert(T.end(), {a, b});
+      } else if (k == "mtllib") {
+        std::string m;
+        ss >> m;
+        if (!mtlLoaded[m]) loadMtl(m, matIndex);
+        mtlLoaded[m] = true;
+      } else if (k == "usemtl") {
+        std::string m;
+        ss >> m;
+        auto it = matIndex.find(m);
+        curMat = it != matIndex.end() ? it->second : defaultMat();
+      } else if (k == "f") {
+        std::vector<Corner> cs;
+        std::string tok;
+        while (ss >> tok) {
+          Corner c{0, 0, 0};
+          int* dst[3] = {&c.v, &c.t, &c.n};
+          size_t st = 0;
+          for (int part = 0; part < 3 && st <= tok.size(); part++) {
+            size_t e = tok.find('/', st);
+            std::string sub = tok.substr(st, e == std::string::npos ? std::string::npos : e - st);
+            if (!sub.empty()) *dst[part] = std::atoi(sub.c_str());
+            if (e == std::string::npos) break;
+            st = e + 1;
+          }
+          const int nv = (int)(P.size() / 3), nt = (int)(T.size() / 2), nn = (int)(N.size() / 3);
+          if (c.v < 0) c.v = nv + c.v + 1;
+          if (c.t < 0) c.t = nt + c.t + 1;
+          if (c.n < 0) c.n = nn + c.n + 1;
+          if (c.v < 1 || c.v > nv) {
+            err = "face index out of range in " + path;
+            return false;
+          }
+          if (c.t > nt) c.t = 0;
+          if (c.n > nn) c.n = 0;
+          cs.push_back(c);
+        }
+        if (cs.size() < 3) continue;
+        if (curMat == 0xFFFFFFFFu) curMat = defaultMat();
+        for (size_t k2 = 1; k2 + 1 < cs.size(); k2++) faces.push_back({{cs[0], cs[k2], cs[k2 + 1]}, curMat});  // fan triangulation
+      }
+    }
+    emit(P, N, T, faces, mat, nmat);
+    return true;
+  }
+
+  struct Corner {
+    int v, t, n;
+  };
+  struct Face {
+    Corner c[3];
+    uint32_t mat;
+  };
+  std::vector<Face> faces;
+
+  static float3 sub(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+  static float3 add(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+  static float3 mul(float3 a, float k) { return {a.x * k, a.y * k, a.z * k}; }
+  static float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+  static float3 cross(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+  static float3 nrm(float3 a) {
+    float l = std::sqrt(dot(a, a));
+    return {a.x / l, a.y / l, a.z / l};  // 0-length -> NaN, caught by invalid() like the reference's isInvalidVec
+  }
+  static bool invalid(float3 a) { return !std::isfinite(a.x) || !std::isfinite(a.y) || !std::isfinite(a.z); }
+  // BinaryModelImporter.cpp:64-76
+  static float3 projectNormalToBitangent(float3 n) {
+    float3 b;
+    if (std::fabs(n.x) > std::fabs(n.y))
+      b = mul(float3{n.z, 0.f, -n.x}, 1.0f / std::sqrt(n.x * n.x + n.z * n.z));
+    else
+      b = mul(float3{0.f, n.z, -n.y}, 1.0f / std::sqrt(n.y * n.y + n.z * n.z));
+    return nrm(b);
+  }
+
+  // Joins identical (position, texcoord, normal) corners per material (what Assimp's JoinIdenticalVertices leaves
+  // Falcor with, one aiMesh per material), generates smooth normals when the file has none, and builds the
+  // bitangent stream the way Falcor does (AssimpModelImporter.cpp:150-176 -> BinaryModelImporter.cpp:84-173),
+  // on the pre-transformed (world-space) vertices.
+  void emit(const std::vector<float>& P, const std::vector<float>& N, const std::vector<float>& T, const std::vector<Face>& fs, const float mat[12],
+            const float nmat[9]) {
+    auto xf = [&](const float* p) -> float3 {
+      return {mat[0] * p[0] + mat[1] * p[1] + mat[2] * p[2] + mat[3], mat[4] * p[0] + mat[5] * p[1] + mat[6] * p[2] + mat[7],
+              mat[8] * p[0] + mat[9] * p[1] + mat[10] * p[2] + mat[11]};
+    };
+    auto xn = [&](float3 n) -> float3 {
+      float3 r{nmat[0] * n.x + nmat[1] * n.y + nmat[2] * n.z, nmat[3] * n.x + nmat[4] * n.y + nmat[5] * n.z,
+               nmat[6] * n.x + nmat[7] * n.y + nmat[8] * n.z};
+      r = nrm(r);
+      return invalid(r) ? float3{0, 1, 0} : r;
+    };
+    // smooth normals per position index (area-weighted face normals), used for corners without vn
+    std::vector<float3> smooth;
+    bool needSmooth = false;
+    for (const Face& f : fs)
+      for (int c = 0; c < 3; c++) needSmooth |= f.c[c].n <= 0;
+    if (needSmooth) {
+      smooth.assign(P.size() / 3, float3{0, 0, 0});
+      for (const Face& f : fs) {
+        float3 p[3];
+        for (int c = 0; c < 3; c++) p[c] = {P[(size_t)(f.c[c].v - 1) * 3], P[(size_t)(f.c[c].v - 1) * 3 + 1], P[(size_t)(f.c[c].v - 1) * 3 + 2]};
+        float3 fn = cross(sub(p[1], p[0]), sub(p[2], p[0]));
+        for (int c = 0; c < 3; c++) smooth[(size_t)f.c[c].v - 1] = add(smooth[(size_t)f.c[c].v - 1], fn);
+      }
+    }
+    struct Key {
+      uint32_t mat;
+      int v, t, n;
+      bool operator<(const Key& o) const { return std::tie(mat, v, t, n) < std::tie(o.mat, o.v, o.t, o.n); }
+    };
+    std::map<Key, uint32_t> uniq;
+    std::vector<float3> pos, nor, bit;
+    std::vector<float> uvs;
+    std::vector<uint32_t> idx;
+    idx.reserve(fs.size() * 3);
+    for (const Face& f : fs) {
+      for (int c = 0; c < 3; c++) {
+        const Corner& cr = f.c[c];
+        Key k{f.mat, cr.v, cr.t, cr.n};
+        auto it = uniq.find(k);
+        if (it == uniq.end()) {
+          it = uniq.emplace(k, (uint32_t)pos.size()).first;
+          pos.push_back(xf(&P[(size_t)(cr.v - 1) * 3]));
+          float3 n = cr.n > 0 ? float3{N[(size_t)(cr.n - 1) * 3], N[(size_t)(cr.n - 1) * 3 + 1], N[(size_t)(cr.n - 1) * 3 + 2]} : smooth[(size_t)cr.v - 1];
+          nor.push_back(xn(n));
+          // aiProcess_FlipUVs (AssimpModelImporter.cpp:516): v -> 1 - v
+          uvs.push_back(cr.t > 0 ? T[(size_t)(cr.t - 1) * 2] : 0.0f);
+          uvs.push_back(cr.t > 0 ? 1.0f - T[(size_t)(cr.t - 1) * 2 + 1] : 0.0f);
+        }
+        idx.push_back(it->second);
+      }
+    }
+    bit.assign(pos.size(), float3{0, 0, 0});
+    const bool haveUv = !T.empty();
+    for (size_t f = 0; f < fs.size(); f++) {
+      const uint32_t* i3 = &idx[f * 3];
+      const float3 d0 = sub(pos[i3[1]], pos[i3[0]]), d1 = sub(pos[i3[2]], pos[i3[0]]);
+      float sx = 0, sy = 0, tx = 0, ty = 0;
+      if (haveUv) {
+        sx = uvs[i3[1] * 2] - uvs[i3[0] * 2];
+        sy = uvs[i3[1] * 2 + 1] - uvs[i3[0] * 2 + 1];
+        tx = uvs[i3[2] * 2] - uvs[i3[0] * 2];
+        ty = uvs[i3[2] * 2 + 1] - uvs[i3[0] * 2 + 1];
+      }
+      float3 tangent, bitangent;
+      if ((sx == 0 && sy == 0) || (tx == 0 && ty == 0)) {
+        bitangent = projectNormalToBitangent(nor[i3[0]]);
+        tangent = cross(bitangent, nor[i3[0]]);
+      } else {
+        const float dc = 1.0f / (sx * ty - sy * tx);
+        tangent = mul(sub(mul(d0, ty), mul(d1, tx)), dc);
+        bitangent = mul(sub(mul(d1, sx), mul(d0, sy)), dc);  // sic: the reference uses s.y here, not t.x
+      }
+      for (int c = 0; c < 3; c++) {
+        const float3 n = nor[i3[c]];
+        float3 lt = nrm(sub(tangent, mul(n, dot(tangent, n))));
+        float3 lb = nrm(sub(bitangent, mul(n, dot(bitangent, n))));
+        lb = nrm(sub(lb, mul(lt, dot(lb, lt))));
+        if (!invalid(bitangent)) bit[i3[c]] = add(bit[i3[c]], nrm(lb));
+      }
+    }
+    const uint32_t base = s.getVertexCount();
+    for (size_t v = 0; v < pos.size(); v++) {
+      float3 b = nrm(bit[v]);
+      if (invalid(b)) b = projectNormalToBitangent(nor[v]);
+      if (invalid(b)) b = float3{1, 0, 0};
+      s.addVertex(pos[v], nor[v], b, uvs[v * 2], uvs[v * 2 + 1]);
+    }
+    for (size_t f = 0; f < fs.size(); f++) s.addTriangle(base + idx[f * 3], base + idx[f * 3 + 1], base + idx[f * 3 + 2], fs[f].mat);
+  }
+};
+
+void instanceMatrix(const float t[3], const float yprDeg[3], const float sc[3], float m[12], float nm[9]) {
+  // glm::yawPitchRoll(yaw, pitch, roll) = Ry(yaw) * Rx(pitch) * Rz(roll); M = T * R * S
+  const float d2r = 3.14159265358979323846f / 180.0f;
+  const float y = yprDeg[0] * d2r, p = yprDeg[1] * d2r, r = yprDeg[2] * d2r;
+  const float cy = std::cos(y), sy = std::sin(y), cp = std::cos(p), sp = std::sin(p), cr = std::cos(r), sr = std::sin(r);
+  const float R[9] = {cy * cr + sy * sp * sr, -cy * sr + sy * sp * cr, sy * cp,  //
+                      cp * sr,                cp * cr,                 -sp,      //
+                      -sy * cr + cy * sp * sr, sy * sr + cy * sp * cr, cy * cp};
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      m[i * 4 + j] = R[i * 3 + j] * sc[j];
+      nm[i * 3 + j] = sc[j] != 0 ? R[i * 3 + j] / sc[j] : R[i * 3 + j];  // inverse transpose of R*S
+    }
+    m[i * 4 + 3] = t[i];
+  }
+}
+
+}  // namespace
+
+Scene::SharedPtr Scene::loadFromFile(const std::string& path, std::string* error) {
+  auto fail = [&](const std::string& e) -> SharedPtr {
+    if (error) *error = e;
+    return nullptr;
+  };
+  SharedPtr s = create();
+  const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, identN[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (endsWith(path, ".obj")) {
+    ModelLoader ml(*s, dirOf(path), false);
+    if (!ml.loadObj(path, ident, identN)) return fail(ml.err);
+  } else if (endsWith(path, ".fscene")) {
+    std::ifstream f(path);
+    if (!f) return fail("cannot open " + path);
+    std::stringstream buf;
+    buf << f.rdbuf();
+    const std::string src = buf.str();
+    JsonParser jp(src);
+    Json root = jp.value();
+    if (!jp.ok || root.type != Json::Obj) return fail("malformed JSON in " + path);
+    const std::string dir = dirOf(path);
+    if (const Json* models = root.get("models")) {
+      for (const Json& jm : models->arr) {
+        const Json* file = jm.get("file");
+        if (!file || file->type != Json::Str) return fail("Model must have a filename");
+        bool specGloss = false;
+        if (const Json* mat = jm.get("material"))
+          if (const Json* sm = mat->get("shading_model")) specGloss = sm->str == "spec_gloss";
+        if (!endsWith(file->str, ".obj")) return fail("Could not load model: " + file->str + " (only OBJ is supported)");
+        const Json* inst = jm.get("instances");
+        std::vector<Json> one(1);
+        const std::vector<Json>& list = (inst && inst->type == Json::Arr && !inst->arr.empty()) ? inst->arr : one;
+        ModelLoader ml(*s, dir, specGloss);
+        for (const Json& ji : list) {
+          float t[3] = {0, 0, 0}, sc[3] = {1, 1, 1}, rot[3] = {0, 0, 0};
+          vec3Of(ji.get("translation"), t);
+          vec3Of(ji.get("scaling"), sc);
+          vec3Of(ji.get("rotation"), rot);
+          float m[12], nm[9];
+          instanceMatrix(t, rot, sc, m, nm);
+          if (!ml.loadObj(dir + "/" + file->str, m, nm)) return fail(ml.err);
+        }
+      }
+    }
+    // scene extents for the directional lights' far-away position (Light.cpp:199-210)
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (size_t i = 0; i + 2 < s->positions.size(); i += 3)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(lo[k], s->positions[i + k]);
+        hi[k] = std::max(hi[k], s->positions[i + k]);
+      }
+    float center[3], radius = 0;
+    for (int k = 0; k < 3; k++) {
+      center[k] = 0.5f * (lo[k] + hi[k]);
+      radius += (hi[k] - center[k]) * (hi[k] - center[k]);
+    }
+    radius = std::sqrt(radius);
+    if (const Json* lights = root.get("lights")) {
+      for (const Json& jl : lights->arr) {
+        const Json* type = jl.get("type");
+        bdpt_light l{};
+        l.openingAngle = 3.14159265f;
+        l.cosOpeningAngle = -1.0f;
+        l.intensity[0] = l.intensity[1] = l.intensity[2] = 1.0f;
+        l.dirW[1] = -1.0f;
+        vec3Of(jl.get("intensity"), l.intensity);
+        if (type && type->str == "dir_light") {
+          l.type = BDPT_LIGHT_DIRECTIONAL;
+          float d[3] = {0, -1, 0};
+          vec3Of(jl.get("direction"), d);
+          float n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          for (int k = 0; k < 3; k++) {
+            l.dirW[k] = d[k] / n;  // setWorldDirection normalises
+            l.posW[k] = center[k] - l.dirW[k] * radius;
+          }
+        } else if (type && type->str == "point_light") {
+          l.type = BDPT_LIGHT_POINT;
+          vec3Of(jl.get("pos"), l.posW);
+          vec3Of(jl.get("direction"), l.dirW);  // PointLight::setWorldDirection does not normalise
+          if (const Json* a = jl.get("opening_angle")) {
+            float ang = (float)a->num * 3.14159265358979323846f / 180.0f;
+            ang = std::min(std::max(ang, 0.0f), 3.14159265358979323846f);
+            l.openingAngle = ang;
+            l.cosOpeningAngle = std::cos(ang);
+          }
+          if (const Json* a = jl.get("penumbra_angle")) l.penumbraAngle = (float)a->num * 3.14159265358979323846f / 180.0f;
+        } else {
+          continue;  // area lights: not on this path
+        }
+        if (s->lights.size() < BDPT_MAX_LIGHTS) s->lights.push_back(l);
+      }
+    }
+    const Json* cams = root.get("cameras");
+    const Json* active = root.get("active_camera");
+    if (cams && cams->type == Json::Arr) {
+      for (const Json& jc : cams->arr) {
+        const Json* nm = jc.get("name");
+        if (active && nm && nm->str != active->str && cams->arr.size() > 1) continue;
+        Camera::SharedPtr cam = Camera::create();
+        float v[3];
+        if (vec3Of(jc.get("pos"), v)) cam->setPosition({v[0], v[1], v[2]});
+        if (vec3Of(jc.get("target"), v)) cam->setTarget({v[0], v[1], v[2]});
+        if (vec3Of(jc.get("up"), v)) cam->setUpVector({v[0], v[1], v[2]});
+        if (const Json* fl = jc.get("focal_length")) cam->setFocalLength((float)fl->num);
+        if (const Json* ar = jc.get("aspect_ratio")) cam->setAspectRatio((float)ar->num);
+        cam->setFocalDistance(1.0f);
+        s->setActiveCamera(cam);
+        break;
+      }
+    }
+  } else {
+    return fail("unsupported scene file type: " + path);
+  }
+  if (s->getTriangleCount() == 0) return fail("scene has no triangles: " + path);
+  s->addDefaultLightIfNone();  // SceneLoaderWrapper.cpp:71-78
+  if (!s->getActiveCamera()) {  // SceneLoaderWrapper.cpp:81-95: look at the scene centre from 3 radii along +z
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (size_t i = 0; i + 2 < s->positions.size(); i += 3)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(lo[k], s->positions[i + k]);
+        hi[k] = std::max(hi[k], s->positions[i + k]);
+      }
+    float c[3], r = 0;
+    for (int k = 0; k < 3; k++) {
+      c[k] = 0.5f * (lo[k] + hi[k]);
+      r += (hi[k] - c[k]) * (hi[k] - c[k]);
+    }
+    r = std::sqrt(r);
+    Camera::SharedPtr cam = Camera::create();
+    cam->setPosition({c[0], c[1], c[2] + 3.0f * r});
+    cam->setTarget({c[0], c[1], c[2]});
+    cam->setUpVector({0, 1, 0});
+    cam->setFocalDistance(1.0f);
+    s->setActiveCamera(cam);
+  }
+  bool anyTex = false;
+  for (const bdpt_material& m : s->materials) anyTex |= (m.texBaseColor >= 0 || m.texEmissive >= 0 || m.texNormal >= 0);
+  (void)anyTex;
+  return s;
+}
+
+}  // namespace bdpt
+
+struct bdpt_scene {
+  bdpt::Scene::SharedPtr scene;
+};
+
+extern "C" bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap) {
+  if (!path) return nullptr;
+  std::string err;
+  bdpt::Scene::SharedPtr s = bdpt::Scene::loadFromFile(path, &err);
+  if (!s) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "%s", err.c_str());
+    return nullptr;
+  }
+  bdpt_scene* h = new bdpt_scene();
+  h->scene = s;
+  return h;
+}

@@ -40,12 +40,23 @@ int main(int argc, char** argv) {
     else if (const char* v = next("--out")) out = v;
     else if (const char* v = next("--raw")) raw = v;
     else {
-      std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium] [--width W] [--height H] [--frames N] [--depth D] "
+      std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
                            "[--mat 0|1] [--accum-limit N] [--out file.pfm] [--raw file.f32]\n");
       return 2;
     }
   }
-  Scene::SharedPtr pScene = scene == "atrium" ? Scene::createAtrium(1, 262144) : Scene::createCornellBox();
+  // a path (.fscene / .obj) goes through the loader, as SceneLoaderWrapper::loadScene does for the file dialog's pick
+  Scene::SharedPtr pScene;
+  if (scene.find('.') != std::string::npos) {
+    std::string err;
+    pScene = Scene::loadFromFile(scene, &err);
+    if (!pScene) {
+      std::fprintf(stderr, "bdpt_render: %s\n", err.c_str());
+      return 1;
+    }
+  } else {
+    pScene = scene == "atrium" ? Scene::createAtrium(1, 262144) : Scene::createCornellBox();
+  }
 
   // Create our rendering pipeline and add the passes, as Main.cpp:12-18 does
   RenderingPipeline* pipeline = new RenderingPipeline(W, H, device);

@@ -33,6 +33,14 @@ bdpt_scene* bdpt_scene_create_atrium(uint32_t seed, uint32_t targetTriangles);
 /* Uniform random triangle soup in the unit cube (intersection KATs). */
 bdpt_scene* bdpt_scene_create_soup(uint32_t seed, uint32_t numTriangles, float maxEdge);
 
+/* Loads a Falcor `.fscene` (JSON: models/instances, lights, cameras) or a bare
+ * Wavefront `.obj` (+ `.mtl`; PPM/PGM/TGA textures), applying the reference's
+ * import rules (SceneImporter.cpp:106-460, AssimpModelImporter.cpp:326-417,
+ * Material.cpp:119-184, SceneLoaderWrapper.cpp:56-103).  Returns NULL and writes
+ * a message into msg (if msgCap > 0) on failure, as loadScene returns nullptr
+ * (SceneLoaderWrapper.cpp:60). */
+bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap);
+
 void bdpt_scene_destroy(bdpt_scene* s);
 
 /* Pointers stay valid until bdpt_scene_destroy. */

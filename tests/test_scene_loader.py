@@ -1,0 +1,267 @@
+"""Scene ingestion: `.fscene` + OBJ/MTL + PPM/TGA -> bdpt_scene_desc.
+
+CPU tests check the loader against the reference's import rules restated independently here in numpy
+(SceneImporter.cpp:106-460, ObjectInstance.h:271-278, Light.cpp:90-210, AssimpModelImporter.cpp:326-417,
+Material.cpp:119-184) and against the one scene file the reference ships (tests/golden/pink_room.fscene, a copy of
+CommonPasses/Data/pink_room/pink_room.fscene; its geometry blob is absent from the reference tree, so the test
+points the model entry at a generated OBJ).  The GPU test renders the loaded scene and compares with the oracle.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import scene_files
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _flags(abi, f):
+    return dict(model=f & 7, dif=(f >> 3) & 7, spec=(f >> 6) & 7, emis=(f >> 9) & 7, nmap=(f >> 12) & 3,
+                alpha=(f >> 17) & 3, dbl=(f >> 19) & 1)
+
+
+def _arr(ptr, n, dt=np.float32):
+    if n == 0:
+        return np.zeros(0, dt)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float if dt == np.float32 else C.c_uint32)), shape=(n,)).copy()
+
+
+@pytest.fixture(scope="module")
+def courtyard(pkg, tmp_path_factory):
+    d = tmp_path_factory.mktemp("courtyard")
+    path = scene_files.write_scene_set(d)
+    scene = pkg.Scene.load(path)
+    yield scene, str(d)
+    scene.close()
+
+
+def test_counts_and_materials(pkg, courtyard):
+    scene, _ = courtyard
+    d = scene.desc
+    # room: 9 quads -> 18 triangles; pillar: 5 side quads + 2 pentagon caps = 10 + 6 = 16 triangles, two instances
+    assert d.numTriangles == 18 + 2 * 16
+    assert d.numLights == 2 and d.numTextures == 3          # floor.ppm, bumps.ppm, lattice.tga (map_Ks is never loaded)
+    mats = [d.materials[i] for i in range(d.numMaterials)]
+    assert d.numMaterials == 9                             # 7 from room.mtl + room's default + pillar's default
+    fl = [_flags(pkg.abi, m.flags) for m in mats]
+    floor, red, green, white, lamp, fence, black, dflt_room, dflt_pillar = range(9)
+    # shading model: the .fscene asks for spec_gloss on room.obj only (SceneImporter.cpp:143-147)
+    assert all(f["model"] == 2 for f in fl[:8]) and fl[dflt_pillar]["model"] == 0
+    # channel types (Material.cpp:162-184)
+    assert fl[floor]["dif"] == 2 and fl[floor]["spec"] == 1 and fl[floor]["emis"] == 0
+    assert mats[floor].texSpecular == -1                    # Material::setSpecularTexture stores nothing (Material.cpp:128-132)
+    assert fl[red]["dif"] == 1 and fl[red]["spec"] == 0
+    assert fl[green]["spec"] == 1 and abs(mats[green].specular[3] - 0.3) < 1e-7
+    assert fl[white]["nmap"] == 1 and mats[white].texNormal >= 0
+    assert fl[lamp]["dif"] == 0 and fl[lamp]["emis"] == 1 and list(mats[lamp].emissive) == [4.0, 3.5, 3.0]
+    assert fl[black]["dif"] == 0 and fl[black]["spec"] == 0
+    # name suffix + alpha: `.DoubleSided` (case-insensitive), d -> baseColor.a, TGA alpha -> mask mode (Material.cpp:119-126)
+    assert fl[fence]["dbl"] == 1 and fl[fence]["alpha"] == 1 and abs(mats[fence].baseColor[3] - 0.75) < 1e-7
+    assert all(f["alpha"] == 0 for i, f in enumerate(fl) if i != fence)
+    assert all(f["dbl"] == 0 for i, f in enumerate(fl) if i != fence)
+    # Assimp's default OBJ material is 0.6 grey
+    assert np.allclose(list(mats[dflt_pillar].baseColor), [0.6, 0.6, 0.6, 1.0])
+    # textures: colour maps sRGB, the bump/normal map linear (AssimpModelImporter.cpp:241-269)
+    tex = [d.textures[i] for i in range(d.numTextures)]
+    assert tex[mats[floor].texBaseColor].srgb == 1 and tex[mats[fence].texBaseColor].srgb == 1
+    assert tex[mats[white].texNormal].srgb == 0
+    t = tex[mats[fence].texBaseColor]
+    px = np.ctypeslib.as_array(C.cast(t.rgba8, C.POINTER(C.c_uint8)), shape=(t.height, t.width, 4))
+    assert np.array_equal(px, scene_files.lattice_rgba())   # RLE TGA, bottom-up, BGRA -> top-down RGBA
+    t = tex[mats[floor].texBaseColor]
+    px = np.ctypeslib.as_array(C.cast(t.rgba8, C.POINTER(C.c_uint8)), shape=(t.height, t.width, 4))
+    assert np.array_equal(px[..., :3], scene_files.checker()) and (px[..., 3] == 255).all()
+
+
+def test_emissive_obj_material_reuses_base_texture(pkg, tmp_path):
+    """AssimpModelImporter.cpp:390-398: Ke with luminance > 0 -> emissive texture := base-colour texture."""
+    scene_files.write_ppm(tmp_path / "glow.ppm", scene_files.checker(8))
+    (tmp_path / "m.mtl").write_text("newmtl screen\nKd 1 1 1\nKe 2 2 2\nmap_Kd glow.ppm\nmap_Ke other.ppm\n"
+                                    "newmtl plain\nKe 0 0 0\nmap_Kd glow.ppm\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nusemtl screen\nf 1 2 3\n"
+                                    "usemtl plain\nf 2 4 3\n")
+    s = pkg.Scene.load(tmp_path / "m.obj")
+    m0, m1 = s.desc.materials[0], s.desc.materials[1]
+    assert m0.texEmissive == m0.texBaseColor >= 0 and _flags(pkg.abi, m0.flags)["emis"] == 2
+    assert m1.texEmissive == -1 and _flags(pkg.abi, m1.flags)["emis"] == 0
+    assert np.allclose(list(m1.baseColor)[:3], 0.6)         # no Kd line -> Assimp default
+    # bare .obj: default light (SceneLoaderWrapper.cpp:71-78) and default camera looking at the centre (:81-95)
+    assert s.desc.numLights == 1 and s.desc.lights[0].type == pkg.abi.LIGHT_DIRECTIONAL
+    cam = s.camera(1.0)
+    assert np.allclose(list(cam.posW)[:2], [0.5, 0.5]) and cam.posW[2] > 0
+    s.close()
+
+
+def _ypr(yaw, pitch, roll):
+    """glm::yawPitchRoll: Ry(yaw) * Rx(pitch) * Rz(roll), column-vector convention."""
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    return ry @ rx @ rz
+
+
+def test_instance_transforms(pkg, courtyard):
+    scene, d = courtyard
+    desc = scene.desc
+    pos = _arr(desc.positions, desc.numVertices * 3).reshape(-1, 3)
+    nor = _arr(desc.normals, desc.numVertices * 3).reshape(-1, 3)
+    bit = _arr(desc.bitangents, desc.numVertices * 3).reshape(-1, 3)
+    idx = _arr(desc.indices, desc.numTriangles * 3, np.uint32).reshape(-1, 3)
+    # object-space pillar vertices straight from the file
+    obj = np.array([[float(x) for x in l.split()[1:]] for l in open(os.path.join(d, "pillar.obj")) if l.startswith("v ")])
+    for k, inst in enumerate(scene_files.FSCENE["models"][1]["instances"]):
+        t, s, r = (np.array(inst[n], np.float64) for n in ("translation", "scaling", "rotation"))
+        m = _ypr(*np.radians(r)) @ np.diag(s)               # ObjectInstance.h:271-278, degrees -> radians SceneImporter.cpp:131-135
+        want = obj @ m.T + t
+        tris = idx[18 + 16 * k: 18 + 16 * (k + 1)]
+        got = pos[np.unique(tris)]
+        # every transformed file vertex appears, and nothing else does
+        dist = np.abs(got[:, None, :] - want[None, :, :]).max(-1)
+        assert dist.min(1).max() < 1e-5 and dist.min(0).max() < 1e-5
+        # generated normals point away from the prism axis after the inverse-transpose transform
+        centre = want.mean(0)
+        for tri in tris:
+            p = pos[tri].astype(np.float64)
+            fn = np.cross(p[1] - p[0], p[2] - p[0])
+            assert np.dot(fn, p.mean(0) - centre) > 0       # winding preserved (outward faces)
+    n_len = np.linalg.norm(nor, axis=1)
+    b_len = np.linalg.norm(bit, axis=1)
+    assert np.allclose(n_len, 1, atol=1e-5) and np.allclose(b_len, 1, atol=1e-5)
+    # Falcor's generated bitangents lie in the tangent plane (BinaryModelImporter.cpp:148-154)
+    assert np.abs((nor * bit).sum(1)).max() < 1e-4
+
+
+def test_texcoords_flipped_like_assimp(pkg, courtyard):
+    scene, _ = courtyard
+    desc = scene.desc
+    uv = _arr(desc.texcoords, desc.numVertices * 3).reshape(-1, 3)[:, :2]
+    pos = _arr(desc.positions, desc.numVertices * 3).reshape(-1, 3)
+    # floor corner (-2,0,2) has vt (0,0) in the file -> (0, 1) after aiProcess_FlipUVs (AssimpModelImporter.cpp:516)
+    i = int(np.argmin(np.abs(pos - np.array([-2, 0, 2])).sum(1)))
+    floor_like = [j for j in range(len(pos)) if np.allclose(pos[j], [-2, 0, 2])]
+    assert any(np.allclose(uv[j], [0, 1]) for j in floor_like), uv[floor_like]
+    j = [j for j in range(len(pos)) if np.allclose(pos[j], [2, 0, -2]) and np.allclose(uv[j][0], 3)]
+    assert j and np.allclose(uv[j[0]], [3, -2])
+
+
+def test_lights_and_camera(pkg, courtyard):
+    scene, _ = courtyard
+    desc = scene.desc
+    spot, sun = desc.lights[0], desc.lights[1]
+    assert spot.type == pkg.abi.LIGHT_POINT and sun.type == pkg.abi.LIGHT_DIRECTIONAL
+    assert np.allclose(list(spot.posW), [0.0, 2.6, 0.6]) and list(spot.dirW) == [0.0, -2.0, -0.5]   # not normalised (Light.cpp:258-261)
+    assert abs(spot.openingAngle - math.radians(60)) < 1e-6 and abs(spot.cosOpeningAngle - 0.5) < 1e-6
+    assert abs(spot.penumbraAngle - math.radians(5)) < 1e-6
+    dvec = np.array([0.3, -2.0, -1.0])
+    dvec /= np.linalg.norm(dvec)
+    assert np.allclose(list(sun.dirW), dvec, atol=1e-6)                                              # normalised (Light.cpp:190-197)
+    pos = _arr(desc.positions, desc.numVertices * 3).reshape(-1, 3)
+    lo, hi = pos.min(0), pos.max(0)
+    centre, radius = 0.5 * (lo + hi), np.linalg.norm(0.5 * (hi - lo))
+    assert np.allclose(list(sun.posW), centre - dvec * radius, atol=1e-4)                            # Light.cpp:199-210, Scene.cpp:100
+    assert sun.openingAngle == pytest.approx(math.pi) and sun.cosOpeningAngle == -1.0
+    # the active camera is the one `active_camera` names; aspect comes from the caller (SceneLoaderWrapper.cpp:98)
+    cam = scene.camera(16 / 9)
+    c = scene_files.FSCENE["cameras"][1]
+    ref = pkg.abi.Camera()
+    pkg.load_library().bdpt_camera_look_at((C.c_float * 3)(*c["pos"]), (C.c_float * 3)(*c["target"]), (C.c_float * 3)(*c["up"]),
+                                           c["focal_length"], 24.0, 16 / 9, 1.0, C.byref(ref))
+    for f in ("posW", "cameraU", "cameraV", "cameraW"):
+        assert list(getattr(cam, f)) == list(getattr(ref, f)), f
+
+
+def test_reference_scene_file(pkg, tmp_path):
+    """The reference's own pink_room.fscene: 1 directional + 2 point lights, Camera0 (values read off the file)."""
+    src = json.load(open(os.path.join(GOLDEN, "pink_room.fscene")))
+    scene_files.write_scene_set(tmp_path)
+    text = open(os.path.join(GOLDEN, "pink_room.fscene")).read().replace("pink_room.fbx", "room.obj")
+    (tmp_path / "pink_room.fscene").write_text(text)
+    s = pkg.Scene.load(tmp_path / "pink_room.fscene")
+    d = s.desc
+    assert d.numLights == len(src["lights"]) == 3 and d.numTriangles == 18
+    for i, jl in enumerate(src["lights"]):
+        l = d.lights[i]
+        assert np.allclose(list(l.intensity), jl["intensity"], atol=1e-7)
+        if jl["type"] == "dir_light":
+            v = np.array(jl["direction"])
+            assert l.type == pkg.abi.LIGHT_DIRECTIONAL and np.allclose(list(l.dirW), v / np.linalg.norm(v), atol=1e-6)
+        else:
+            assert l.type == pkg.abi.LIGHT_POINT and np.allclose(list(l.posW), jl["pos"], atol=1e-6)
+            assert l.openingAngle == pytest.approx(math.pi, abs=1e-6) and l.cosOpeningAngle == pytest.approx(-1.0, abs=1e-6)
+            assert l.penumbraAngle == 0.0
+    jc = src["cameras"][0]
+    cam = s.camera(1.0)
+    assert np.allclose(list(cam.posW), jc["pos"], atol=1e-6)
+    w = np.array(list(cam.cameraW))
+    fwd = np.array(jc["target"]) - np.array(jc["pos"])
+    assert np.allclose(w / np.linalg.norm(w), fwd / np.linalg.norm(fwd), atol=1e-5)
+    # focal length 21 mm on a 24 mm frame: tan(fovY/2) = 12/21 = |V| / |W|
+    v = np.array(list(cam.cameraV))
+    assert np.linalg.norm(v) / np.linalg.norm(w) == pytest.approx(12.0 / 21.0, rel=1e-5)
+    s.close()
+
+
+def test_load_errors(pkg, tmp_path):
+    with pytest.raises(pkg.BdptError, match="cannot open"):
+        pkg.Scene.load(tmp_path / "nope.fscene")
+    (tmp_path / "bad.fscene").write_text("{ \"models\": [ { \"name\": \"x\" } ] }")
+    with pytest.raises(pkg.BdptError, match="Model must have a filename"):      # SceneImporter.cpp:110-113
+        pkg.Scene.load(tmp_path / "bad.fscene")
+    (tmp_path / "broken.fscene").write_text("{ \"models\": [ ")
+    with pytest.raises(pkg.BdptError, match="malformed JSON"):
+        pkg.Scene.load(tmp_path / "broken.fscene")
+    (tmp_path / "oob.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2 7\n")
+    with pytest.raises(pkg.BdptError, match="out of range"):
+        pkg.Scene.load(tmp_path / "oob.obj")
+    with pytest.raises(pkg.BdptError, match="unsupported"):
+        pkg.Scene.load(tmp_path / "scene.gltf")
+
+
+def test_oracle_renders_loaded_scene(pkg, ob, courtyard):
+    """The loaded descriptor is a valid input for the checker (no GPU): finite image, light reaches the floor."""
+    scene, _ = courtyard
+    W, H = 32, 24
+    orc = ob.OracleRender(pkg.abi, scene.desc, W, H)
+    cam = scene.camera(W / H)
+    gp = pkg.abi.GBufferParams()
+    gp.frameCount, gp.lensRadius, gp.focalLen = 0xDEADBEEF, 0.0, 1.0
+    gp.pixelJitter[0] = gp.pixelJitter[1] = 0.5
+    orc.gbuffer(cam, gp)
+    p = pkg.abi.Params()
+    p.minT, p.frameCount, p.matIndex, p.refractiveIndex, p.maxDepth, p.emitMult, p.clampUpper = 1e-4, 0x1337, 1, 1.0, 4, 1.0, 1.0
+    p.pixelJitter[0] = p.pixelJitter[1] = 0.5
+    orc.bdpt(cam, p)
+    orc.resolve()
+    img = orc.image()
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.01
+    hit = orc.chan["worldPosition"][:, 3] != 0
+    assert hit.mean() > 0.6
+    orc.close()
+
+
+@pytest.mark.gpu
+def test_loaded_scene_frame_matches_oracle(pkg, ob, courtyard):
+    import torch
+    scene, _ = courtyard
+    for mat, depth in ((1, 5), (0, 3)):
+        pipe = pkg.FramePipeline(scene, 80, 60, max_depth=depth, mat_index=mat)
+        gp, p = pipe.render_frame()
+        torch.cuda.synchronize()
+        orc = ob.OracleRender(pkg.abi, scene.desc, pipe.W, pipe.H, pipe.y0, pipe.y1)
+        orc.gbuffer(pipe.cam, gp)
+        orc.bdpt(pipe.cam, p)
+        names = {"WorldPosition": "worldPosition", "WorldNormal": "worldNormal", "MaterialDiffuse": "materialDiffuse",
+                 "MaterialSpecRough": "materialSpecRough", "MaterialExtraParams": "materialExtra", "Emissive": "emissive"}
+        for ch, on in names.items():
+            g = pipe.channels[ch].float().cpu().numpy().reshape(-1, 4)
+            assert np.array_equal(g.view(np.uint32), orc.chan[on].view(np.uint32)), ch
+        orc.resolve()
+        gpu, ref = pipe.output.cpu().numpy(), orc.image()
+        assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), f"{(gpu != ref).any(axis=-1).sum()} pixels differ"
+        orc.close()
+        pipe.close()

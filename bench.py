@@ -213,9 +213,8 @@ def main():
                 "visits_per_ray": {"shadow_nodes": round(n_int_s, 2), "shadow_tris": round(n_tri_s, 2),
                                    "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
                 "stage_ms_per_step": {k: round(v / K, 3) for k, v in stage_ms.items()},
-                "stage_mrays": {k: round(per_stage_rays.get(r, 0) / (stage_ms[k] * 1e-3) / 1e6, 1)
-                                for k, r in (("eye_extend", "raysEyeExtend"), ("light_extend", "raysLightExtend"))
-                                if stage_ms.get(k, 0) > 0},
+                "stage_mrays": {"walks": round((per_stage_rays.get("raysEyeExtend", 0) + per_stage_rays.get("raysLightExtend", 0))
+                                               / (stage_ms["walks"] * 1e-3) / 1e6, 1)} if stage_ms.get("walks", 0) > 0 else {},
                 "trace_shadow_mrays": round(shadow_rays_per_launch / (conn_ms * 1e-3) / 1e6, 1) if conn_ms > 0 else None,
                 "dominant_stage": dominant,
             },

@@ -52,6 +52,9 @@ struct bdpt_ctx {
   const char* stageNames[kMaxStages]{};
   int numStages = 0;
   bool evCreated = false;
+  // the light walk runs beside the eye walk on this stream (fork/join with events; capture-safe)
+  hipStream_t walkStream = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 namespace {
@@ -118,6 +121,12 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
     c->numCUs = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->walkStream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) {
+    bdpt_destroy(c);
+    return BDPT_E_HIP;
+  }
   *out_ctx = c;
   return BDPT_OK;
 }
@@ -130,6 +139,9 @@ void bdpt_destroy(bdpt_ctx* c) {
   freePool(c->frameAllocs);
   if (c->evCreated)
     for (int i = 0; i <= kMaxStages; i++) (void)hipEventDestroy(c->ev[i]);
+  if (c->evFork) (void)hipEventDestroy(c->evFork);
+  if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+  if (c->walkStream) (void)hipStreamDestroy(c->walkStream);
   delete c;
 }
 
@@ -413,7 +425,7 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   // a path queue = kNumSubQueues lists; workgroup b appends to list b % kNumSubQueues
   P.pathSubCap = (uint32_t)((((np + kWave - 1) / kWave + kNumSubQueues - 1) / kNumSubQueues) * kWave);
   const size_t qcap = (size_t)P.pathSubCap * kNumSubQueues;
-  for (int q = 0; q < 3; q++)
+  for (int q = 0; q < 5; q++)
     if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], qcap))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)kCursorWords))) return rc;
   P.qhead = P.qcount + kCountBlocks * kCursorBlock;
@@ -424,6 +436,10 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, qcap))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, qcap))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.hitV, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrimL, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitTL, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitUL, qcap))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.hitVL, qcap))) return rc;
   {
     // one shadow ray per NEE term, per splat term and per defined connection pair, at most
     const uint32_t D = std::max<uint32_t>(maxDepth, 1);
@@ -533,7 +549,12 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   launchInitPaths(c->S, F, P, st);
   stageMark(c, st, "init_paths");
 
-  // eye walk: vertices 2..D (BDPTMain.rt.hlsl:106-112)
+  // The two walks are independent until the connection stage, so the light walk (vertices 1..D,
+  // BDPTMain.rt.hlsl:138-145) runs on the context's second stream beside the eye walk (vertices 2..D,
+  // :106-112): the HBM-bound shade launches of one overlap the VALU-bound traversal of the other and
+  // the persistent kernels' tails fill each other.  Separate ping-pong queues and hit records.
+  HIPCHK(c, hipEventRecord(c->evFork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->walkStream, c->evFork, 0));
   int qc = 1;  // next free cursor block
   {
     const uint32_t* qin = P.queue[0];
@@ -547,23 +568,28 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
       qc++;
       ping = 3 - ping;
     }
-    stageMark(c, st, "eye_extend");
   }
-  // light walk: vertices 1..D (BDPTMain.rt.hlsl:138-145)
   {
+    PathBuf PL = P;
+    PL.hitPrim = P.hitPrimL;
+    PL.hitT = P.hitTL;
+    PL.hitU = P.hitUL;
+    PL.hitV = P.hitVL;
     const uint32_t* qin = P.queue[0];
     const uint32_t* cin = P.qcount;
-    int ping = 1;
+    int ping = 3;
     for (int k = 0; k <= D - 1; k++) {
-      launchExtend(c->S, F, P, PATH_LIGHT, k, D, qin, cin, P.qhead + (size_t)qc * kCursorBlock, P.queue[ping],
-                   P.qcount + (size_t)qc * kCursorBlock, c->numCUs, st);
+      launchExtend(c->S, F, PL, PATH_LIGHT, k, D, qin, cin, P.qhead + (size_t)qc * kCursorBlock, P.queue[ping],
+                   P.qcount + (size_t)qc * kCursorBlock, c->numCUs, c->walkStream);
       qin = P.queue[ping];
       cin = P.qcount + (size_t)qc * kCursorBlock;
       qc++;
-      ping = 3 - ping;
+      ping = 7 - ping;
     }
-    stageMark(c, st, "light_extend");
   }
+  HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
+  HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
+  stageMark(c, st, "walks");
   if (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) launchMisPrefix(F, P, st);
   launchGenShadow(c->S, F, P, st);
   stageMark(c, st, "gen_shadow");

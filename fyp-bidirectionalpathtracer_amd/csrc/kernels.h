@@ -75,16 +75,20 @@ struct PathBuf {
   uint8_t* eyeLast;    // last stored eye vertex (ghost included); 0 = pixel has no geometry
   uint8_t* lightLast;  // last stored light vertex (ghost included)
   uint8_t* lightReal;  // number of light vertices produced by hits (takeContribution, BDPTMain.rt.hlsl:144)
-  uint32_t* queue[3];  // sharded path queues (kernels.hip "Path queues"): [0] valid pixels; [1],[2] ping-pong
+  uint32_t* queue[5];  // sharded path queues (kernels.hip "Path queues"): [0] valid pixels; [1],[2] eye ping-pong; [3],[4] light
   uint32_t pathSubCap; // capacity of one list of a path queue (multiple of 64)
   // cursor blocks: each is kNumSubQueues cursors, one per 128-byte line (kCursorBlock words)
   uint32_t* qcount;    // block 0 = valid-pixel list lengths; block 1+s = lengths after extension step s
   uint32_t* qhead;     // block s = fetch cursors of the persistent trace of extension step s
-  // closest-hit records by queue position
+  // closest-hit records by queue position (the light walk runs on its own stream with the second set)
   int* hitPrim;
   float* hitT;
   float* hitU;
   float* hitV;
+  int* hitPrimL;
+  float* hitTL;
+  float* hitUL;
+  float* hitVL;
   // shadow-ray queue (NEE + splat + connection rays of one frame)
   float* rayQ;           // 7 planes, stride rayCap
   float* rayContrib;     // 3 planes, stride rayCap: the clamped contribution the ray gates

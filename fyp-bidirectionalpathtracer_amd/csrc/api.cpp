@@ -53,6 +53,7 @@ struct bdpt_ctx {
   int numStages = 0;
   bool evCreated = false;
   // the light walk runs beside the eye walk on this stream (fork/join with events; capture-safe)
+  int lazyRounds = kLazyRounds;
   hipStream_t walkStream = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
@@ -459,7 +460,9 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     if ((rc = devAlloc(c, c->frameAllocs, &P.rayVis, (size_t)cap))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.slotRay, (size_t)slots * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.splatPix, (size_t)D * np))) return rc;
-    const uint32_t batch = (numConnectPairs(D) + kLazyRounds - 1) / kLazyRounds;
+    // Lazy rounds: each costs three small launches, so small tiles (multi-GPU bands) take fewer, larger ones.
+    c->lazyRounds = np >= (1u << 20) ? kLazyRounds : (np >= (1u << 18) ? kLazyRounds / 2 : kLazyRounds / 4);
+    const uint32_t batch = (numConnectPairs(D) + (uint32_t)c->lazyRounds - 1) / (uint32_t)c->lazyRounds;
     if ((rc = devAlloc(c, c->frameAllocs, &P.misE, (size_t)(D + 1) * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.misL, (size_t)(D + 1) * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyCursor, np))) return rc;
@@ -600,8 +603,8 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   if (!(p->flags & BDPT_PARAM_NO_CONNECT) && D >= 2) {
     // zero-valued connection pairs of the pixels no visible connection has saturated yet
     const int nPairs = (int)numConnectPairs((uint32_t)D);
-    const int batch = (nPairs + kLazyRounds - 1) / kLazyRounds;
-    for (int r = 0; r < kLazyRounds; r++) {
+    const int batch = (nPairs + c->lazyRounds - 1) / c->lazyRounds;
+    for (int r = 0; r < c->lazyRounds; r++) {
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
       HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));

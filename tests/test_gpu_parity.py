@@ -225,18 +225,15 @@ def test_partial_stage_images_and_depths(pkg, ob):
     scene.close()
 
 
-def test_tiled_execution_equals_full_frame(pkg, ob):
-    """Two contexts rendering two row bands with deferred resolve + summed splat buffers reproduce the
-    single-context frame bit for bit (the N>1 path of bench.py on one GPU)."""
+def _bands_equal_full(pkg, scene, W, H, depth, mat, bands):
     import torch
-    scene = pkg.Scene.cornell()
-    W, H = 48, 40
-    full = pkg.FramePipeline(scene, W, H, max_depth=4, mat_index=0)
+    full = pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat)
     full.render_frame()
     torch.cuda.synchronize()
     ref = full.output.cpu().numpy()
-    bands = [(0, 17), (17, 40)]
-    pipes = [pkg.FramePipeline(scene, W, H, max_depth=4, mat_index=0, tile=b) for b in bands]
+    cnt = full.ctx.counters().as_dict()
+    full.close()
+    pipes = [pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat, tile=b) for b in bands]
     splats = []
     for pp in pipes:
         buf = torch.zeros(W * H * 4, dtype=torch.int64, device="cuda")
@@ -244,15 +241,40 @@ def test_tiled_execution_equals_full_frame(pkg, ob):
         pp.render_frame(extra_flags=pkg.abi.PARAM_DEFER_RESOLVE)
         splats.append(buf)
     torch.cuda.synchronize()
-    total = splats[0] + splats[1]
+    total = splats[0]
+    for b in splats[1:]:
+        total = total + b
     img = np.zeros_like(ref)
     for pp, (y0, y1) in zip(pipes, bands):
         pp.ctx.resolve(C.c_void_p(total.data_ptr()), 0, C.c_void_p(pp.output.data_ptr()))
         torch.cuda.synchronize()
         img[y0:y1] = pp.output.cpu().numpy()[y0:y1]
-    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
-    for pp in pipes + [full]:
         pp.close()
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    return ref, cnt
+
+
+def test_tiled_execution_equals_full_frame(pkg, ob):
+    """Contexts rendering row bands with deferred resolve + summed splat buffers reproduce the
+    single-context frame bit for bit (the N>1 path of bench.py on one GPU)."""
+    scene = pkg.Scene.cornell()
+    _bands_equal_full(pkg, scene, 48, 40, 4, 0, [(0, 17), (17, 40)])
+    _bands_equal_full(pkg, scene, 40, 33, 3, 1, [(0, 11), (11, 22), (22, 33)])
+    scene.close()
+
+
+def test_full_size_config_bands_equal_full_frame(pkg, ob):
+    """BASELINE configs[3] shape (Bistro-class: 2.8 M triangles, 3840x2160, depth 12) — far beyond what the
+    oracle finishes in seconds, so the check is the size-independent property: two bands + exact integer splat
+    sum == the full frame, every value finite, rays within the (D+1)^2 bound of SURVEY.md §8d."""
+    scene = pkg.Scene.atrium(1, 2_800_000)
+    W, H, D = 3840, 2160, 12
+    img, cnt = _bands_equal_full(pkg, scene, W, H, D, 0, [(0, H // 2), (H // 2, H)])
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.01
+    rays = sum(cnt[k] for k in ("raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect"))
+    assert 0 < rays <= W * H * (D + 1) ** 2
+    assert cnt["pixelsValid"] > 0.5 * W * H
+    scene.close()
 
 
 def test_atrium_frame_matches_oracle(pkg, ob):
@@ -280,6 +302,48 @@ def test_atrium_frame_matches_oracle(pkg, ob):
     assert c["raysSplat"] == o["raysSplat"] and c["raysNee"] <= o["raysNee"] and c["raysConnect"] <= o["raysConnect"]
     assert c["pixelsValid"] == o["pixelsValid"] and c["splatsLanded"] == o["splatsLanded"]
     orc.close()
+    pipe.close()
+    scene.close()
+
+
+def test_thin_lens_random_jitter_and_env_map(pkg, ob):
+    """The primary stage's other modes: thin-lens origin sampling, a host-drawn random pixel
+    jitter (LightProbeGBufferPass.cpp:142-157) and an environment map on the miss shader
+    (lightProbeGBuffer.rt.hlsl:63-80, 127-143), then the BDPT pass on that G-buffer — all bit-exact."""
+    import torch
+    scene = pkg.Scene.atrium(3, 20000)
+    pipe = pkg.FramePipeline(scene, 72, 48, max_depth=4, mat_index=0)
+    rng = np.random.default_rng(20260104)
+    ew, eh = 64, 32
+    env = rng.random((eh, ew, 4), dtype=np.float32) * 2.0
+    env_dev = torch.from_numpy(env).cuda()
+    names = {"WorldPosition": "worldPosition", "WorldNormal": "worldNormal", "MaterialDiffuse": "materialDiffuse",
+             "MaterialSpecRough": "materialSpecRough", "MaterialExtraParams": "materialExtra", "Emissive": "emissive"}
+    for thin, lens_radius, focal in ((1, 0.05, 6.0), (1, 0.5, 2.5), (0, 0.0, 1.0)):
+        gp = pipe.gbuffer_params()
+        gp.useThinLens, gp.lensRadius, gp.focalLen = thin, lens_radius, focal
+        gp.pixelJitter[0], gp.pixelJitter[1] = float(rng.random()), float(rng.random())
+        gp.envMap = env_dev.data_ptr()
+        gp.envWidth, gp.envHeight = ew, eh
+        pipe.ctx.gbuffer_execute(gp, pipe.gb, pipe._stream_ptr())
+        p = pipe.bdpt_params()
+        pipe.ctx.execute(p, pipe.gb, C.c_void_p(pipe.output.data_ptr()), pipe._stream_ptr())
+        torch.cuda.synchronize()
+        orc = ob.OracleRender(pkg.abi, scene.desc, pipe.W, pipe.H)
+        orc.gbuffer(pipe.cam, gp, env=env.reshape(-1))
+        orc.bdpt(pipe.cam, p)
+        orc.resolve()
+        for ch, on in names.items():
+            g = pipe.channels[ch].float().cpu().numpy().reshape(-1, 4)
+            assert np.array_equal(g.view(np.uint32), orc.chan[on].view(np.uint32)), (ch, thin)
+        gpu, ref = pipe.output.cpu().numpy(), orc.image()
+        assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), thin
+        # the atrium is open to the sky: some pixels must have taken the environment colour
+        miss = orc.chan["worldPosition"][:, 3] == 0
+        assert miss.any() and (~miss).any()
+        orc.close()
+        pipe.gbuffer_frame += 1
+        pipe.bdpt_frame += 1
     pipe.close()
     scene.close()
 

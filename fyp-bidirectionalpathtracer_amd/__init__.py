@@ -75,6 +75,17 @@ class Scene:
             pass
 
 
+def camera_view_proj(pos, target, up, focal_length_mm=21.0, frame_height_mm=24.0, aspect=1.7777, near=0.1, far=1000.0):
+    """Falcor's jitter-free viewProjMat, row-major (Camera.cpp:60-105) -> 16 floats for BmfrParams.prevViewProj."""
+    out = (C.c_float * 16)()
+    v3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    rc = load_library().bdpt_camera_view_proj(v3(pos), v3(target), v3(up), focal_length_mm, frame_height_mm, aspect,
+                                              near, far, out)
+    if rc != 0:
+        raise BdptError("bdpt_camera_view_proj failed")
+    return list(out)
+
+
 def msaa_jitter(counter_before_increment):
     j = (C.c_float * 2)()
     load_library().bdpt_msaa_jitter(counter_before_increment & 0xFFFFFFFF, j)
@@ -135,6 +146,13 @@ class Context:
     def accumulate(self, last_ptr, cur_ptr, accum_count, max_count, num_texels, stream=None):
         self._check(self._lib.bdpt_accumulate(self._h, last_ptr, cur_ptr, accum_count, max_count, num_texels, stream),
                     "bdpt_accumulate")
+
+    def bmfr_execute(self, params, gbuffer, noisy_ptr, stream=None):
+        self._check(self._lib.bdpt_bmfr_execute(self._h, C.byref(params), C.byref(gbuffer), noisy_ptr, stream),
+                    "bdpt_bmfr_execute")
+
+    def bmfr_reset(self):
+        self._check(self._lib.bdpt_bmfr_reset(self._h), "bdpt_bmfr_reset")
 
     def counters(self):
         c = Counters()

@@ -41,6 +41,11 @@ class Light(C.Structure):
 
 
 LIGHT_POINT, LIGHT_DIRECTIONAL = 0, 1
+BMFR_PREPROCESS, BMFR_REGRESSION, BMFR_POSTPROCESS, BMFR_KEEP_LD_FEATURES, BMFR_FULL_FRAME = 1, 2, 4, 8, 16
+
+
+class BmfrParams(C.Structure):
+    _fields_ = [("frameNumber", C.c_uint32), ("flags", C.c_uint32), ("prevViewProj", C.c_float * 16)]
 
 
 class SceneDesc(C.Structure):
@@ -116,6 +121,10 @@ PROTOTYPES = {
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bdpt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bdpt_bmfr_execute": (C.c_int, [C.c_void_p, C.POINTER(BmfrParams), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
+    "bdpt_bmfr_reset": (C.c_int, [C.c_void_p]),
+    "bdpt_camera_view_proj": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "bdpt_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                   C.c_void_p]),
     "bdpt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),

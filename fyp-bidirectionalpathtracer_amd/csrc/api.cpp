@@ -54,6 +54,14 @@ struct bdpt_ctx {
   bool evCreated = false;
   // the light walk runs beside the eye walk on this stream (fork/join with events; capture-safe)
   int lazyRounds = kLazyRounds;
+  // BMFR history (allocated by the first bdpt_bmfr_execute): [2] = ping-pong pair
+  float4* bmfrPos[2] = {nullptr, nullptr};
+  float4* bmfrNorm[2] = {nullptr, nullptr};
+  float4* bmfrNoisy[2] = {nullptr, nullptr};
+  float4* bmfrFiltered[2] = {nullptr, nullptr};
+  uint8_t* bmfrAccept = nullptr;
+  uint32_t* bmfrPrevPixel = nullptr;
+  int bmfrRead = 0;  // which half holds the previous frame
   hipStream_t walkStream = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
@@ -407,6 +415,9 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
   freePool(c->frameAllocs);
+  for (int k = 0; k < 2; k++) c->bmfrPos[k] = c->bmfrNorm[k] = c->bmfrNoisy[k] = c->bmfrFiltered[k] = nullptr;
+  c->bmfrAccept = nullptr;  // history goes with the frame (BlockwiseMultiOrderFeatureRegression::resize)
+  c->bmfrPrevPixel = nullptr;
   c->haveSize = false;
   c->W = width;
   c->H = height;
@@ -622,6 +633,82 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   }
   HIPCHK(c, hipGetLastError());
   c->lastStream = st;
+  return BDPT_OK;
+}
+
+// BlockwiseMultiOrderFeatureRegression::execute (DenoisePass.cpp:146-204)
+int bdpt_bmfr_execute(bdpt_ctx* c, const bdpt_bmfr_params* p, const bdpt_gbuffer* g, float* noisy, void* stream) {
+  if (!c || !p || !g || !noisy) return BDPT_E_INVALID;
+  if (!c->haveSize) {
+    fail(c, "bmfr: bdpt_resize must be called first");
+    return BDPT_E_STATE;
+  }
+  if (c->tile.y0 != 0 || c->tile.y1 != c->H) {
+    fail(c, "bmfr: the denoiser works on the whole frame; this context renders a band");
+    return BDPT_E_STATE;
+  }
+  if (!g->worldPosition || !g->worldNormal || !g->materialDiffuse) {
+    fail(c, "bmfr: WorldPosition, WorldNormal and MaterialDiffuse are required");
+    return BDPT_E_INVALID;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = (size_t)c->W * c->H;
+  if (!c->bmfrAccept) {
+    int rc;
+    for (int k = 0; k < 2; k++) {
+      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrPos[k], n))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrNorm[k], n))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrNoisy[k], n))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrFiltered[k], n))) return rc;
+    }
+    if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrAccept, n))) return rc;
+    if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrPrevPixel, n))) return rc;
+    if ((rc = bdpt_bmfr_reset(c))) return rc;
+  }
+  BmfrDev A{};
+  A.W = c->W;
+  A.H = c->H;
+  A.frame = p->frameNumber;
+  A.full = (p->flags & BDPT_BMFR_FULL_FRAME) ? 1u : 0u;
+  A.doPre = (p->flags & BDPT_BMFR_PREPROCESS) ? 1u : 0u;
+  for (int k = 0; k < 16; k++) A.m[k] = p->prevViewProj[k];
+  A.curPos = reinterpret_cast<const float4*>(g->worldPosition);
+  A.curNorm = g->worldNormal;
+  A.albedo = g->materialDiffuse;
+  A.noisy = reinterpret_cast<float4*>(noisy);
+  const int r = c->bmfrRead, w = 1 - r;
+  A.prevPosR = c->bmfrPos[r];
+  A.prevNormR = c->bmfrNorm[r];
+  A.prevNoisyR = c->bmfrNoisy[r];
+  A.prevFilteredR = c->bmfrFiltered[r];
+  A.prevPosW = c->bmfrPos[w];
+  A.prevNormW = c->bmfrNorm[w];
+  A.prevNoisyW = c->bmfrNoisy[w];
+  A.prevFilteredW = c->bmfrFiltered[w];
+  A.accept = c->bmfrAccept;
+  A.prevPixel = c->bmfrPrevPixel;
+  if (!(p->flags & BDPT_BMFR_POSTPROCESS))  // no new filtered frame this time: keep the old one on the read side next frame
+    HIPCHK(c, hipMemcpyAsync(c->bmfrFiltered[w], c->bmfrFiltered[r], n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+  launchBmfr(A, p->flags, st);
+  HIPCHK(c, hipGetLastError());
+  c->bmfrRead = w;
+  c->lastStream = st;
+  return BDPT_OK;
+}
+
+int bdpt_bmfr_reset(bdpt_ctx* c) {
+  if (!c) return BDPT_E_INVALID;
+  if (!c->bmfrAccept) return BDPT_OK;  // nothing allocated yet
+  const size_t n = (size_t)c->W * c->H;
+  for (int k = 0; k < 2; k++) {
+    HIPCHK(c, hipMemset(c->bmfrPos[k], 0, n * sizeof(float4)));
+    HIPCHK(c, hipMemset(c->bmfrNorm[k], 0, n * sizeof(float4)));
+    HIPCHK(c, hipMemset(c->bmfrNoisy[k], 0, n * sizeof(float4)));
+    HIPCHK(c, hipMemset(c->bmfrFiltered[k], 0, n * sizeof(float4)));
+  }
+  HIPCHK(c, hipMemset(c->bmfrAccept, 0, n));
+  HIPCHK(c, hipMemset(c->bmfrPrevPixel, 0, n * sizeof(uint32_t)));
+  c->bmfrRead = 0;
   return BDPT_OK;
 }
 

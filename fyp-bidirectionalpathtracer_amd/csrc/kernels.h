@@ -125,6 +125,23 @@ struct GBufferDev {
   DevCounters* counters;
 };
 
+// BMFR denoise pass (bmfr.hip).  History buffers come in ping-pong pairs: R = previous frame (read), W = this
+// frame (written), so the reference's post-pass blits (DenoisePass.cpp:180-182, 194) cost no extra copy.
+struct BmfrDev {
+  uint32_t W, H, frame;
+  uint32_t full, doPre;
+  float m[16];                 // prevViewProj, row-major
+  const float4* curPos;        // WorldPosition
+  const uint16_t* curNorm;     // WorldNormal (half4)
+  const uint16_t* albedo;      // MaterialDiffuse (half4)
+  float4* noisy;               // channel being denoised, in/out
+  const float4 *prevPosR, *prevNormR, *prevNoisyR, *prevFilteredR;
+  float4 *prevPosW, *prevNormW, *prevNoisyW, *prevFilteredW;
+  uint8_t* accept;             // BMFR_AcceptedBools
+  uint32_t* prevPixel;         // BMFR_PrevFramePixel, RG16Float
+};
+void launchBmfr(const BmfrDev& A, uint32_t flags, hipStream_t st);
+
 // launchers (kernels.hip)
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);

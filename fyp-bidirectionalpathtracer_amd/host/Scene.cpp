@@ -13,6 +13,7 @@ namespace {
 inline float3 sub(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline float3 mul(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline float3 crs(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline float dt(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline float3 nrm(float3 a) {
   float l = std::sqrt(dt(a, a));
@@ -255,6 +256,29 @@ int bdpt_camera_look_at(const float pos[3], const float target[3], const float u
   out->cameraW[0] = W.x;
   out->cameraW[1] = W.y;
   out->cameraW[2] = W.z;
+  return BDPT_OK;
+}
+
+int bdpt_camera_view_proj(const float pos[3], const float target[3], const float up[3], float focalLengthMm, float frameHeightMm,
+                          float aspect, float nearZ, float farZ, float out16[16]) {
+  if (!pos || !target || !up || !out16) return BDPT_E_INVALID;
+  using namespace bdpt;
+  const float3 eye{pos[0], pos[1], pos[2]};
+  // glm::lookAt (right-handed), Camera.cpp:77
+  const float3 f = nrm(sub(float3{target[0], target[1], target[2]}, eye));
+  const float3 sv = nrm(crs(f, float3{up[0], up[1], up[2]}));
+  const float3 uv = crs(sv, f);
+  const float V[4][4] = {{sv.x, sv.y, sv.z, -dot(sv, eye)}, {uv.x, uv.y, uv.z, -dot(uv, eye)}, {-f.x, -f.y, -f.z, dot(f, eye)}, {0, 0, 0, 1}};
+  // glm::perspective (right-handed, depth 0..1), Camera.cpp:89; only x, y and w matter to the reprojection
+  const float fovY = 2.0f * std::atan(0.5f * frameHeightMm / focalLengthMm);
+  const float th = std::tan(fovY * 0.5f);
+  const float P[4][4] = {{1.0f / (aspect * th), 0, 0, 0}, {0, 1.0f / th, 0, 0}, {0, 0, farZ / (nearZ - farZ), -(farZ * nearZ) / (farZ - nearZ)}, {0, 0, -1, 0}};
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      float a = 0;
+      for (int k = 0; k < 4; k++) a += P[r][k] * V[k][c];
+      out16[4 * r + c] = a;
+    }
   return BDPT_OK;
 }
 

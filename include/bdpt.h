@@ -30,6 +30,14 @@
  *   bdpt_accumulate                 SimpleAccumulationPass::execute + accumulate.ps.hlsl
  *                                   (CommonPasses/SimpleAccumulationPass.cpp:104-134,
  *                                    CommonPasses/Data/CommonPasses/accumulate.ps.hlsl:28-42)
+ *   bdpt_bmfr_execute / bdpt_bmfr_reset
+ *                                   BlockwiseMultiOrderFeatureRegression::execute / resize
+ *                                   (BidirectionalPathtracing/Passes/DenoisePass.cpp:146-279 with
+ *                                    Data/preprocess.ps.hlsl:33-165, regressionCP.hlsl:100-500,
+ *                                    postprocess.ps.hlsl:22-91); the pass is off by default
+ *                                   (DenoisePass.h:71) and outside radiance parity
+ *   bdpt_camera_view_proj           Camera::calculateCameraParameters' viewProjMat without jitter
+ *                                   (Falcor Graphics/Camera/Camera.cpp:60-109), for prevViewProjMat
  *   bdpt_get_counters               (none in the reference; replaces nothing — ray tallies
  *                                    needed by the Mrays/s metric)
  *   bdpt_last_error                 Falcor logError / silent no-op conventions
@@ -293,6 +301,32 @@ int bdpt_resolve(bdpt_ctx* ctx, const uint64_t* splat, uint32_t splat_row0, floa
  *   cur = accumCount < maxAccumCount ? (accumCount*last + cur)/(accumCount+1) : last;  last = cur. */
 int bdpt_accumulate(bdpt_ctx* ctx, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount,
                     uint64_t numTexels, void* stream);
+
+/* ---- BMFR denoiser (DenoisePass.*).  Works on the full frame: the context's tile must cover it. ---- */
+#define BDPT_BMFR_PREPROCESS 1u        /* mBMFR_preprocess, default on (DenoisePass.h:72) */
+#define BDPT_BMFR_REGRESSION 2u        /* mBMFR_regression, default off (DenoisePass.h:74) */
+#define BDPT_BMFR_POSTPROCESS 4u       /* mBMFR_postprocess, default on (DenoisePass.h:73) */
+#define BDPT_BMFR_KEEP_LD_FEATURES 8u  /* mBMFR_removeFeatures == false: plain Householder QR with feature noise */
+#define BDPT_BMFR_FULL_FRAME 16u       /* deviation switch: the reference filters only texC.x <= 0.5 (its comparison split) */
+
+typedef struct bdpt_bmfr_params {
+  uint32_t frameNumber;   /* mAccumCount: 0 on the first frame after bdpt_bmfr_reset */
+  uint32_t flags;         /* BDPT_BMFR_* */
+  float prevViewProj[16]; /* gCamera.prevViewProjMat, row-major: clip[r] = sum_c m[4r+c] * (posW,1)[c] */
+} bdpt_bmfr_params;
+
+/* One execute() of the denoise pass on `noisy` (full-frame RGBA32F, in/out: the channel being
+ * denoised) with the G-buffer's WorldPosition / WorldNormal / MaterialDiffuse as features.  History
+ * (previous position, normal, noisy and filtered frames, accept masks) lives in the context. */
+int bdpt_bmfr_execute(bdpt_ctx* ctx, const bdpt_bmfr_params* p, const bdpt_gbuffer* features, float* noisy, void* stream);
+
+/* Forget the history (BlockwiseMultiOrderFeatureRegression::resize / initScene set mAccumCount = 0). */
+int bdpt_bmfr_reset(bdpt_ctx* ctx);
+
+/* projMat * viewMat of Falcor's camera without the jitter matrix (glm::perspective * glm::lookAt,
+ * Camera.cpp:77-105), row-major as bdpt_bmfr_params::prevViewProj wants it.  Host only. */
+int bdpt_camera_view_proj(const float pos[3], const float target[3], const float up[3], float focalLengthMm,
+                          float frameHeightMm, float aspect, float nearZ, float farZ, float out16[16]);
 
 /* Counters of the most recent bdpt_execute (ray tallies always; node/triangle visits when it ran
  * with BDPT_PARAM_COUNTERS).  Synchronises the stream it was launched on. */

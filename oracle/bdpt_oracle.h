@@ -80,6 +80,15 @@ void oracle_bsdf(const float* in, uint32_t n, uint32_t matIndex, float* out);
 void oracle_sincos2pi(const float* u, uint32_t n, float* s, float* c);
 void oracle_half_round(const float* in, uint32_t n, float* out);
 
+/* BMFR denoise pass (bmfr_oracle.cpp; DenoisePass.cpp:146-279 + its three shaders).  Channels are
+ * float4 per pixel; curNorm / albedo hold the half-precision G-buffer values widened to float. */
+typedef struct oracle_bmfr oracle_bmfr;
+oracle_bmfr* oracle_bmfr_create(uint32_t width, uint32_t height);
+void oracle_bmfr_destroy(oracle_bmfr* b);
+void oracle_bmfr_reset(oracle_bmfr* b);
+int oracle_bmfr_execute(oracle_bmfr* b, const bdpt_bmfr_params* p, const float* curPos, const float* curNorm,
+                        const float* albedo, float* noisy);
+
 #ifdef __cplusplus
 }
 #endif

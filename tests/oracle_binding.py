@@ -43,6 +43,12 @@ def load_oracle(abi):
     lib.oracle_bsdf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.oracle_sincos2pi.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.oracle_half_round.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.oracle_bmfr_create.restype = C.c_void_p
+    lib.oracle_bmfr_create.argtypes = [C.c_uint32, C.c_uint32]
+    lib.oracle_bmfr_destroy.argtypes = [C.c_void_p]
+    lib.oracle_bmfr_reset.argtypes = [C.c_void_p]
+    lib.oracle_bmfr_execute.restype = C.c_int
+    lib.oracle_bmfr_execute.argtypes = [C.c_void_p, C.POINTER(abi.BmfrParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -95,3 +101,28 @@ class OracleRender:
 
     def image(self):
         return self.chan["out"].reshape(self.H, self.W, 4)
+
+
+class OracleBmfr:
+    """The denoise pass of oracle/bmfr_oracle.cpp with its own history, mirroring bdpt_bmfr_execute."""
+
+    def __init__(self, abi, width, height):
+        self.lib = load_oracle(abi)
+        self.h = self.lib.oracle_bmfr_create(width, height)
+        self.W, self.H = width, height
+
+    def reset(self):
+        self.lib.oracle_bmfr_reset(self.h)
+
+    def execute(self, params, cur_pos, cur_norm, albedo, noisy):
+        """All arrays float32 [H*W, 4], C-contiguous; `noisy` is updated in place."""
+        for a in (cur_pos, cur_norm, albedo, noisy):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size == self.W * self.H * 4
+        rc = self.lib.oracle_bmfr_execute(self.h, C.byref(params), _p(cur_pos), _p(cur_norm), _p(albedo), _p(noisy))
+        assert rc == 0
+        return noisy
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_bmfr_destroy(self.h)
+            self.h = None

@@ -478,6 +478,60 @@ void SimpleAccumulationPass::execute(RenderContext* pRenderContext) {
 void SimpleAccumulationPass::stateRefreshed() { mAccumCount = 0; }
 
 // ------------------------------------------------------------------------------------------------
+// BlockwiseMultiOrderFeatureRegression (BidirectionalPathtracing/Passes/DenoisePass.cpp:12-279)
+// ------------------------------------------------------------------------------------------------
+bool BlockwiseMultiOrderFeatureRegression::initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) {
+  if (!pResManager) return false;
+  mpResManager = pResManager;
+  mpResManager->requestTextureResource(mDenoiseChannel);
+  mpResManager->requestTextureResources({"WorldPosition", "WorldNormal", "MaterialDiffuse"});  // the three feature buffers
+  mpRays = RayLaunch::create(pRenderContext);
+  setGuiSize(ivec2{250, 135});
+  return mpRays != nullptr;
+}
+void BlockwiseMultiOrderFeatureRegression::initScene(RenderContext*, Scene::SharedPtr pScene) {
+  mpScene = pScene;
+  mAccumCount = 0;
+  if (mpRays) bdpt_bmfr_reset(mpRays->ctx());
+}
+void BlockwiseMultiOrderFeatureRegression::resize(uint32_t, uint32_t) {
+  mAccumCount = 0;  // the history itself goes with bdpt_resize
+  if (mpRays) bdpt_bmfr_reset(mpRays->ctx());
+}
+void BlockwiseMultiOrderFeatureRegression::renderGui(Gui* pGui) {
+  int dirty = 0;
+  dirty |= (int)pGui->addCheckBox(mDoDenoise ? "Do BMFR Denoise" : "Ignore the denoise stage", mDoDenoise);
+  dirty |= (int)pGui->addCheckBox(mBMFR_preprocess ? "Do Pre-Process" : "Skip Pre-process", mBMFR_preprocess);
+  dirty |= (int)pGui->addCheckBox(mBMFR_regression ? "Do Regression" : "Skip Regression", mBMFR_regression);
+  dirty |= (int)pGui->addCheckBox(mBMFR_postprocess ? "Do Post-Process" : "Skip Post-process", mBMFR_postprocess);
+  dirty |= (int)pGui->addCheckBox(mBMFR_removeFeatures ? "Ignore Linearly Dependent Features" : "Add Noise", mBMFR_removeFeatures);
+  if (dirty) setRefreshFlag();
+}
+void BlockwiseMultiOrderFeatureRegression::execute(RenderContext* pRenderContext) {
+  if (!mpResManager || !mpRays) return;
+  Texture::SharedPtr inputTexture = mpResManager->getTexture(mDenoiseChannel);
+  if (!inputTexture || !mDoDenoise) return;
+  Texture::SharedPtr pos = mpResManager->getTexture("WorldPosition"), nrm = mpResManager->getTexture("WorldNormal"),
+                     alb = mpResManager->getTexture("MaterialDiffuse");
+  if (!pos || !nrm || !alb || !mpScene || !mpScene->getActiveCamera()) return;
+  if (!mpRays->ensureSize(inputTexture->getWidth(), inputTexture->getHeight())) return;
+  bdpt_bmfr_params p{};
+  p.frameNumber = mAccumCount;
+  p.flags = (mBMFR_preprocess ? BDPT_BMFR_PREPROCESS : 0u) | (mBMFR_regression ? BDPT_BMFR_REGRESSION : 0u) |
+            (mBMFR_postprocess ? BDPT_BMFR_POSTPROCESS : 0u) | (mBMFR_removeFeatures ? 0u : BDPT_BMFR_KEEP_LD_FEATURES);
+  std::memcpy(p.prevViewProj, mpScene->getActiveCamera()->getPrevViewProjMat(), sizeof(p.prevViewProj));
+  bdpt_gbuffer gb{};
+  gb.worldPosition = (float*)pos->getDevicePointer();
+  gb.worldNormal = (uint16_t*)nrm->getDevicePointer();
+  gb.materialDiffuse = (uint16_t*)alb->getDevicePointer();
+  if (bdpt_bmfr_execute(mpRays->ctx(), &p, &gb, (float*)inputTexture->getDevicePointer(), pRenderContext->getStream()) != BDPT_OK) {
+    std::fprintf(stderr, "[BMFR] %s\n", mpRays->lastError());
+    return;
+  }
+  mAccumCount++;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RenderingPipeline (headless subset of SharedUtils/RenderingPipeline.cpp)
 // ------------------------------------------------------------------------------------------------
 RenderingPipeline::RenderingPipeline(uint32_t width, uint32_t height, int device) : mContext(device, nullptr), mWidth(width), mHeight(height) {
@@ -516,6 +570,7 @@ void RenderingPipeline::applyGui(Gui* pGui) {
     if (p) p->onRenderGui(pGui);
 }
 void RenderingPipeline::renderFrame() {
+  if (mpScene && mpScene->getActiveCamera()) mpScene->getActiveCamera()->beginFrame();  // Scene::update, RenderingPipeline.cpp:630
   bool refresh = false;
   for (auto& p : mActivePasses) refresh |= (p && p->isRefreshFlagSet());
   if (refresh)

@@ -118,6 +118,40 @@ class SimpleAccumulationPass : public RenderPass {
   const int32_t mMaxCountLimit = 10000;
 };
 
+// BMFR denoiser pass (BidirectionalPathtracing/Passes/DenoisePass.{h,cpp}): same channels, switches and defaults
+// (off until "Do BMFR Denoise" is ticked; regression off, pre/post-process on, DenoisePass.h:70-75).  The three
+// shaders and their history textures live behind bdpt_bmfr_execute.
+class BlockwiseMultiOrderFeatureRegression : public RenderPass {
+ public:
+  using SharedPtr = std::shared_ptr<BlockwiseMultiOrderFeatureRegression>;
+  static SharedPtr create(const std::string& bufferToDenoise = ResourceManager::kOutputChannel) {
+    return SharedPtr(new BlockwiseMultiOrderFeatureRegression(bufferToDenoise));
+  }
+  uint32_t getAccumCount() const { return mAccumCount; }
+
+ protected:
+  BlockwiseMultiOrderFeatureRegression(const std::string& bufferToDenoise) : RenderPass("BMFR Denoise Pass", "BMFR Denoise Options") {
+    mDenoiseChannel = bufferToDenoise;
+  }
+  bool initialize(RenderContext* pRenderContext, ResourceManager::SharedPtr pResManager) override;
+  void initScene(RenderContext* pRenderContext, Scene::SharedPtr pScene) override;
+  void execute(RenderContext* pRenderContext) override;
+  void renderGui(Gui* pGui) override;
+  void resize(uint32_t width, uint32_t height) override;
+  bool appliesPostprocess() override { return true; }
+  bool hasAnimation() override { return false; }
+
+  std::string mDenoiseChannel;
+  RayLaunch::SharedPtr mpRays;
+  Scene::SharedPtr mpScene;
+  bool mDoDenoise = false;
+  bool mBMFR_preprocess = true;
+  bool mBMFR_postprocess = true;
+  bool mBMFR_regression = false;
+  bool mBMFR_removeFeatures = true;
+  uint32_t mAccumCount = 0;
+};
+
 // Headless counterpart of SharedUtils/RenderingPipeline (setPass + per-frame loop,
 // RenderingPipeline.cpp:421-471, 611-695); the window, GUI rendering and final blit are out of scope.
 class RenderingPipeline {

@@ -31,6 +31,11 @@ const bdpt_camera& Camera::getData() {
   return mData;
 }
 
+void Camera::beginFrame() {
+  float pos[3] = {mPos.x, mPos.y, mPos.z}, tgt[3] = {mTarget.x, mTarget.y, mTarget.z}, up[3] = {mUp.x, mUp.y, mUp.z};
+  bdpt_camera_view_proj(pos, tgt, up, mFocalLength, mFrameHeight, mAspect, mNearZ, mFarZ, mPrevViewProj);
+}
+
 uint32_t Scene::addVertex(float3 p, float3 n, float3 b, float u, float v) {
   uint32_t id = getVertexCount();
   positions.insert(positions.end(), {p.x, p.y, p.z});

@@ -41,6 +41,10 @@ class Camera {
   // the reference compares view matrices (CommonPasses/SimpleAccumulationPass.cpp:96-102).
   uint64_t getViewVersion() const { return mVersion; }
   const bdpt_camera& getData();
+  // Camera::beginFrame (Falcor Camera.cpp:51-62, called by Scene::update, Scene.cpp:129): the jitter-free
+  // view-projection of the state before this frame's camera changes becomes prevViewProjMat.
+  void beginFrame();
+  const float* getPrevViewProjMat() const { return mPrevViewProj; }  // row-major, see bdpt_bmfr_params
 
  private:
   Camera() = default;
@@ -50,6 +54,8 @@ class Camera {
   bool mDirty = true;
   uint64_t mVersion = 0;
   bdpt_camera mData{};
+  float mNearZ = 0.1f, mFarZ = 1000.0f;  // HostDeviceSharedCode.h:82-84
+  float mPrevViewProj[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
 class Scene {

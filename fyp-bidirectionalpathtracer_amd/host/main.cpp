@@ -1,6 +1,6 @@
 // main.cpp — headless counterpart of BidirectionalPathtracing/Main.cpp:9-29: the same pipeline
-// (G-buffer pass -> BDPT pass -> accumulation pass; the BMFR denoiser is off by default in the
-// reference and out of scope here), run for a number of frames, output written as a PFM image.
+// (G-buffer pass -> BDPT pass -> accumulation pass -> BMFR denoiser, which is off unless --denoise /
+// --denoise-regression tick its boxes), run for a number of frames, output written as a PFM image.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,12 +24,15 @@ int main(int argc, char** argv) {
   std::string scene = "cornell", out = "bdpt_out.pfm", raw;
   uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
   int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100;
+  bool denoise = false, denoiseRegression = false;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
       if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
       return nullptr;
     };
-    if (const char* v = next("--scene")) scene = v;
+    if (std::strcmp(argv[i], "--denoise") == 0) denoise = true;
+    else if (std::strcmp(argv[i], "--denoise-regression") == 0) denoise = denoiseRegression = true;
+    else if (const char* v = next("--scene")) scene = v;
     else if (const char* v = next("--width")) W = (uint32_t)std::atoi(v);
     else if (const char* v = next("--height")) H = (uint32_t)std::atoi(v);
     else if (const char* v = next("--frames")) frames = std::atoi(v);
@@ -41,7 +44,7 @@ int main(int argc, char** argv) {
     else if (const char* v = next("--raw")) raw = v;
     else {
       std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
-                           "[--mat 0|1] [--accum-limit N] [--out file.pfm] [--raw file.f32]\n");
+                           "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32]\n");
       return 2;
     }
   }
@@ -63,7 +66,8 @@ int main(int argc, char** argv) {
   pipeline->setPass(0, LightProbeGBufferPass::create());
   pipeline->setPass(1, BDPTPass::create(ResourceManager::kOutputChannel));
   pipeline->setPass(2, SimpleAccumulationPass::create(ResourceManager::kOutputChannel));
-  if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 3) {
+  pipeline->setPass(3, BlockwiseMultiOrderFeatureRegression::create());
+  if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 4) {
     std::fprintf(stderr, "pipeline initialisation failed (no GPU?)\n");
     return 1;
   }
@@ -71,6 +75,8 @@ int main(int argc, char** argv) {
   gui.overrides["Max Ray Depth"] = depth;
   gui.overrides["Material"] = mat;
   gui.overrides["Max frames to accumulate"] = accumLimit;
+  if (denoise) gui.overrides["Ignore the denoise stage"] = 1;  // the check box's label while it is off (DenoisePass.cpp:139)
+  if (denoiseRegression) gui.overrides["Skip Regression"] = 1;
   pipeline->applyGui(&gui);
 
   auto t0 = std::chrono::steady_clock::now();

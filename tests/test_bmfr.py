@@ -182,3 +182,35 @@ def test_bmfr_needs_full_frame_context(pkg):
         pipe.ctx.bmfr_execute(_params(pkg, 0, 5), pipe.gb, C.c_void_p(pipe.output.data_ptr()), pipe._stream_ptr())
     pipe.close()
     scene.close()
+
+
+@pytest.mark.gpu
+def test_cpp_host_denoise_pass_matches_python_sequence(pkg, tmp_path):
+    """host/bdpt_render with the BMFR pass ticked (fourth pass of Main.cpp:15-18) == the same frames driven from Python."""
+    import os
+    import subprocess
+    import torch
+    import __graft_entry__ as ge
+    A = pkg.abi
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe), "host/bdpt_render not built (run __graft_entry__.build())"
+    raw = tmp_path / "out.f32"
+    W, H, frames = 80, 48, 4
+    r = subprocess.run([exe, "--scene", "cornell", "--width", str(W), "--height", str(H), "--frames", str(frames), "--depth", "3",
+                        "--mat", "1", "--denoise-regression", "--out", str(tmp_path / "o.pfm"), "--raw", str(raw)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cpp = np.fromfile(raw, np.float32).reshape(H, W, 4)
+    scene = pkg.Scene.cornell()
+    pipe = pkg.FramePipeline(scene, W, H, max_depth=3, mat_index=1, accum_limit=100)
+    # Camera::beginFrame: the (static) camera's jitter-free view-projection, near/far = Falcor defaults
+    vp = pkg.camera_view_proj((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), (0.0, 1.0, 0.0), 33.6, 24.0, W / H, 0.1, 1000.0)
+    flags = A.BMFR_PREPROCESS | A.BMFR_REGRESSION | A.BMFR_POSTPROCESS
+    for k in range(frames):
+        pipe.render_frame(accumulate=True)
+        pipe.ctx.bmfr_execute(_params(pkg, k, flags, vp), pipe.gb, C.c_void_p(pipe.output.data_ptr()), pipe._stream_ptr())
+    torch.cuda.synchronize()
+    py = pipe.output.cpu().numpy()
+    assert np.array_equal(cpp.view(np.uint32), py.view(np.uint32)), np.abs(cpp - py).max()
+    pipe.close()
+    scene.close()

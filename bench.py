@@ -66,10 +66,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
-    if world > 1:
+    # BDPT_BENCH_TILED_AT_1=1 under torch.distributed.run makes a single rank take the tiled path with its RCCL
+    # exchange, so the N>1 code can be exercised on a one-GPU box; otherwise N=1 runs without any collective.
+    tiled = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("BDPT_BENCH_TILED_AT_1", "0") == "1")
+    if tiled:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -88,14 +92,14 @@ def main():
     ctx = pipe.ctx
     info = ctx.bvh_info()
     splat_full = None
-    if world > 1:
+    if tiled:
         splat_full = torch.zeros(rows * world * W * 4, dtype=torch.int64, device=dev)
         splat_mine = torch.zeros(rows * W * 4, dtype=torch.int64, device=dev)
         ctx.set_splat_buffer(C.c_void_p(splat_full.data_ptr()), splat_full.numel())
 
     def step(flags=0):
         """One pipeline frame on this rank's tile."""
-        if world == 1:
+        if not tiled:
             pipe.render_frame(accumulate=True, extra_flags=flags)
         else:
             pipe.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE)
@@ -226,7 +230,7 @@ def main():
                 "note": "all launches of the kernel in a frame (1 main + lazy rounds); bytes are algorithmic, served mostly by L2/MALL",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     pipe.close()

@@ -155,7 +155,10 @@ void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint3
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st);
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
                      uint32_t* nextList, uint32_t* nextCount, hipStream_t st);
-constexpr int kLazyRounds = 8;  // rounds per frame; batch = ceil(pairs / rounds)
+#ifndef BDPT_LAZY_ROUNDS
+#define BDPT_LAZY_ROUNDS 8
+#endif
+constexpr int kLazyRounds = BDPT_LAZY_ROUNDS;  // rounds per frame; batch = ceil(pairs / rounds)
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
                    hipStream_t st);
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);

@@ -102,9 +102,14 @@ def main():
         if not tiled:
             pipe.render_frame(accumulate=True, extra_flags=flags)
         else:
-            pipe.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE)
-            pkg.tiling.exchange_splats(dist, splat_full, splat_mine)
+            # phase 1: everything that writes the splat buffer; then the exchange starts on RCCL's stream while
+            # phase 2 (zero-valued connection rounds) runs on ours
+            _, p = pipe.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
+            work = pkg.tiling.exchange_splats_async(dist, splat_full, splat_mine)
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            ctx.execute_tail(p, pipe.gb, C.c_void_p(pipe.output.data_ptr()), st)
+            if work is not None:
+                work.wait()
             ctx.resolve(C.c_void_p(splat_mine.data_ptr()), y0, C.c_void_p(pipe.output.data_ptr()), st)
             n = pipe.accum_count
             pipe.accum_count += 1

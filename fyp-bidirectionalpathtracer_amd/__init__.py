@@ -131,6 +131,10 @@ class Context:
     def execute(self, params, gbuffer, out_ptr, stream=None):
         self._check(self._lib.bdpt_execute(self._h, C.byref(params), C.byref(gbuffer), out_ptr, stream), "bdpt_execute")
 
+    def execute_tail(self, params, gbuffer, out_ptr, stream=None):
+        self._check(self._lib.bdpt_execute_tail(self._h, C.byref(params), C.byref(gbuffer), out_ptr, stream),
+                    "bdpt_execute_tail")
+
     def splat_buffer(self):
         p = C.c_void_p()
         n = C.c_uint64()

@@ -20,6 +20,7 @@ PARAM_NO_CONNECT = 16
 PARAM_SPECULAR_FROM_LOBE = 32
 PARAM_MIS_POWER = 64
 PARAM_MIS_LINEAR = 128
+PARAM_DEFER_TAIL = 256
 
 
 class Material(C.Structure):
@@ -118,6 +119,7 @@ PROTOTYPES = {
     "bdpt_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, Tile, C.c_uint32]),
     "bdpt_gbuffer_execute": (C.c_int, [C.c_void_p, C.POINTER(GBufferParams), C.POINTER(GBuffer), C.c_void_p]),
     "bdpt_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
+    "bdpt_execute_tail": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bdpt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

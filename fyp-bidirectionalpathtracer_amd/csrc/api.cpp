@@ -520,7 +520,9 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
   return BDPT_OK;
 }
 
-int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream) {
+namespace {
+// argument checks shared by bdpt_execute and bdpt_execute_tail, and the per-frame constants the kernels take
+int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, FrameDev& F) {
   if (!c || !p || !in || !out) return BDPT_E_INVALID;
   if (!c->haveScene || !c->haveCamera || !c->haveSize) {
     fail(c, "execute: scene, camera and size must be set first");
@@ -538,9 +540,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     fail(c, "execute: G-buffer channels missing");
     return BDPT_E_INVALID;
   }
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const PathBuf& P = c->P;
-  FrameDev F{};
+  F = FrameDev{};
   F.cam = c->cam;
   F.p = *p;
   F.W = c->W;
@@ -551,6 +551,45 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   F.splat = c->splat;
   F.gb = *in;
   F.counters = c->counters;  // ray tallies are always on; node/triangle visits need BDPT_PARAM_COUNTERS
+  return BDPT_OK;
+}
+
+// Connection pairs whose contribution is exactly zero, for the pixels no visible connection has saturated
+// yet (DESIGN.md "Lazy connection rounds"), then the splat fold-in unless the caller defers it.
+int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
+  const PathBuf& P = c->P;
+  const bdpt_params* p = &F.p;
+  const int D = (int)p->maxDepth;
+  if (!(p->flags & BDPT_PARAM_NO_CONNECT) && D >= 2) {
+    const int nPairs = (int)numConnectPairs((uint32_t)D);
+    const int batch = (nPairs + c->lazyRounds - 1) / c->lazyRounds;
+    for (int r = 0; r < c->lazyRounds; r++) {
+      uint32_t* list = P.queue[1 + (r & 1)];
+      uint32_t* next = P.queue[1 + ((r + 1) & 1)];
+      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));
+      launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
+      stageMark(c, st, "lazy_gen");
+      launchTraceShadow(c->S, F, P, c->numCUs, st);
+      stageMark(c, st, "lazy_trace");
+      launchLazyCheck(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, next, P.lazyCount + (size_t)(r + 1) * kCursorBlock, st);
+    }
+    stageMark(c, st, "lazy_check");
+  }
+  if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
+    launchResolve(c->splat, 0, F.out, c->W, c->tile.y0, c->tile.y1, st);
+    stageMark(c, st, "resolve");
+  }
+  HIPCHK(c, hipGetLastError());
+  c->lastStream = st;
+  return BDPT_OK;
+}
+}  // namespace
+
+int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream) {
+  FrameDev F;
+  if (int rc = frameSetup(c, p, in, out, F)) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const PathBuf& P = c->P;
   const int D = (int)p->maxDepth;
 
   c->numStages = 0;
@@ -611,29 +650,20 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   stageMark(c, st, "trace_shadow");
   launchGather(F, P, P.queue[1], P.lazyCount, st);
   stageMark(c, st, "gather");
-  if (!(p->flags & BDPT_PARAM_NO_CONNECT) && D >= 2) {
-    // zero-valued connection pairs of the pixels no visible connection has saturated yet
-    const int nPairs = (int)numConnectPairs((uint32_t)D);
-    const int batch = (nPairs + c->lazyRounds - 1) / c->lazyRounds;
-    for (int r = 0; r < c->lazyRounds; r++) {
-      uint32_t* list = P.queue[1 + (r & 1)];
-      uint32_t* next = P.queue[1 + ((r + 1) & 1)];
-      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));
-      launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
-      stageMark(c, st, "lazy_gen");
-      launchTraceShadow(c->S, F, P, c->numCUs, st);
-      stageMark(c, st, "lazy_trace");
-      launchLazyCheck(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, next, P.lazyCount + (size_t)(r + 1) * kCursorBlock, st);
-    }
-    stageMark(c, st, "lazy_check");
+  // Everything that touches the splat buffer is enqueued by now: a tiled host may start its exchange here
+  // and run the connection tail beside it (BDPT_PARAM_DEFER_TAIL + bdpt_execute_tail).
+  if (p->flags & BDPT_PARAM_DEFER_TAIL) {
+    HIPCHK(c, hipGetLastError());
+    c->lastStream = st;
+    return BDPT_OK;
   }
-  if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
-    launchResolve(c->splat, 0, out, c->W, c->tile.y0, c->tile.y1, st);
-    stageMark(c, st, "resolve");
-  }
-  HIPCHK(c, hipGetLastError());
-  c->lastStream = st;
-  return BDPT_OK;
+  return connectionTail(c, F, st);
+}
+
+int bdpt_execute_tail(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream) {
+  FrameDev F;
+  if (int rc = frameSetup(c, p, in, out, F)) return rc;
+  return connectionTail(c, F, reinterpret_cast<hipStream_t>(stream));
 }
 
 // BlockwiseMultiOrderFeatureRegression::execute (DenoisePass.cpp:146-204)

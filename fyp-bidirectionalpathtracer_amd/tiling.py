@@ -30,3 +30,12 @@ def exchange_splats(dist, splat_full, splat_mine):
         r = dist.get_rank()
         splat_mine.copy_(splat_full[r * n:(r + 1) * n])
     return splat_mine
+
+
+def exchange_splats_async(dist, splat_full, splat_mine):
+    """Start the exchange and return a handle whose wait() orders the current stream after it (RCCL), so the
+    caller can enqueue bdpt_execute_tail in between.  gloo has no stream to overlap: it runs synchronously."""
+    if dist.get_backend() == "nccl":
+        return dist.reduce_scatter_tensor(splat_mine, splat_full, op=dist.ReduceOp.SUM, async_op=True)
+    exchange_splats(dist, splat_full, splat_mine)
+    return None

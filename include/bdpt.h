@@ -186,6 +186,11 @@ typedef struct bdpt_params {
  * uniform 1/k the reference applies (it defines these functions but never calls them). */
 #define BDPT_PARAM_MIS_POWER 64u
 #define BDPT_PARAM_MIS_LINEAR 128u
+/* Two-phase execute for tiled multi-GPU hosts: bdpt_execute returns once every launch that writes the
+ * splat buffer is enqueued (walks, NEE, splats, non-zero connections); bdpt_execute_tail enqueues the rest
+ * (zero-valued connection rounds, resolve unless deferred).  The host starts its splat exchange between
+ * the two so it overlaps the tail.  Same image as the one-call form, bit for bit. */
+#define BDPT_PARAM_DEFER_TAIL 256u
 
 /* RayGenCB of lightProbeGBuffer.rt.hlsl:45-52 + the miss shader's env map. */
 typedef struct bdpt_gbuffer_params {
@@ -281,6 +286,9 @@ int bdpt_gbuffer_execute(bdpt_ctx* ctx, const bdpt_gbuffer_params* p, const bdpt
  * BDPTPass.cpp:73).  Without BDPT_PARAM_DEFER_RESOLVE the splats of this call are
  * folded in before returning control to the stream. */
 int bdpt_execute(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream);
+
+/* Second phase of a bdpt_execute issued with BDPT_PARAM_DEFER_TAIL (same params, channels and out). */
+int bdpt_execute_tail(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream);
 
 /* Full-frame fixed-point splat accumulator: uint64[4] per pixel (r,g,b in
  * 2^-32 units, splat count), zeroed by every bdpt_execute before its splat stage.

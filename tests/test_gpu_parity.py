@@ -238,9 +238,13 @@ def _bands_equal_full(pkg, scene, W, H, depth, mat, bands):
     for pp in pipes:
         buf = torch.zeros(W * H * 4, dtype=torch.int64, device="cuda")
         pp.ctx.set_splat_buffer(C.c_void_p(buf.data_ptr()), buf.numel())
-        pp.render_frame(extra_flags=pkg.abi.PARAM_DEFER_RESOLVE)
-        splats.append(buf)
-    torch.cuda.synchronize()
+        # two-phase form (what bench.py's tiled step does): the exchange may start after phase 1
+        _, p = pp.render_frame(extra_flags=pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
+        torch.cuda.synchronize()
+        splats.append(buf.clone())   # phase 2 must not touch the splat buffer
+        pp.ctx.execute_tail(p, pp.gb, C.c_void_p(pp.output.data_ptr()), pp._stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(splats[-1], buf)
     total = splats[0]
     for b in splats[1:]:
         total = total + b

@@ -12,7 +12,10 @@ constexpr int kWave = 64;          // gfx950 wavefront
 #define KSTACK 32
 #endif
 constexpr int kStackEntries = KSTACK;  // per-lane traversal stack in LDS, 8 KiB per wave (kBvhMaxDepth = 30)
-constexpr int kShadeRecF4 = 7;     // float4s per triangle shading record (112 B)
+#ifndef BDPT_SHADE_REC_F4
+#define BDPT_SHADE_REC_F4 7
+#endif
+constexpr int kShadeRecF4 = BDPT_SHADE_REC_F4;  // float4s per triangle shading record (7 used = 112 B)
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // Hot single-word atomics top out near 90 M/s on this chip (MI355X_MICROARCH.md "dequeue"), so
 // producer and consumer cursors of the shadow-ray queue are sharded over sub-queues, consumers

@@ -110,7 +110,8 @@ def _oracle_frame(pkg, ob, scene, pipe, gp, p, brute=False):
     return orc, cnt
 
 
-@pytest.mark.parametrize("mat,depth,size", [(0, 3, 64), (1, 3, 64), (1, 8, 48), (0, 8, 48), (0, 1, 32), (1, 2, 32)])
+# (0, 3, 256) is BASELINE configs[0] (Cornell 256x256, depth 3, first frame 0x1337 with jitter (1,-3)/16) at full size
+@pytest.mark.parametrize("mat,depth,size", [(0, 3, 64), (1, 3, 64), (1, 8, 48), (0, 8, 48), (0, 1, 32), (1, 2, 32), (0, 3, 256)])
 def test_cornell_frame_bit_exact(pkg, ob, mat, depth, size):
     import torch
     scene = pkg.Scene.cornell()

@@ -22,7 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; its measured float4 copy rate is 6290 GB/s)
 
 
 def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
@@ -230,6 +230,7 @@ def main():
             "roofline": {
                 "kernel": "trace_kernel<2> (persistent any-hit traversal)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "peak_achievable_copy": 6290.0,  # float4 copy rate MI355X_MICROARCH.md reports (79 % of spec)
                 "bytes_per_frame": int(conn_bytes), "ms_per_frame": round(conn_ms, 3),
                 "bytes_per_ray": round(bytes_per_ray, 1), "rays_per_frame": int(shadow_rays_per_frame),
                 "note": "all launches of the kernel in a frame (1 main + lazy rounds); bytes are algorithmic, served mostly by L2/MALL",

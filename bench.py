@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+RAY_KEYS = ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; its measured float4 copy rate is 6290 GB/s)
 
 
@@ -40,6 +41,83 @@ def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
     return b
 
 
+class TileRenderer:
+    """This rank's share of the frame loop: one context for a whole frame, or — on the tiled path — several
+    contexts over the same row band, each with one frame in flight on its own stream."""
+
+    def __init__(self, pkg, scene, W, H, D, mat, local_rank, world, rank, dist, tiled, inflight=0):
+        import torch
+        self.torch, self.pkg, self.dist, self.tiled = torch, pkg, dist, tiled
+        self.W, self.H = W, H
+        self.dev = torch.device("cuda", local_rank)
+        # tile = contiguous band of rows; bands padded to equal height so reduce-scatter chunks are equal
+        rows = pkg.tiling.band_rows(H, world)
+        self.y0, self.y1 = pkg.tiling.band(H, world, rank)
+        # Frames in flight: a band leaves the chip underfilled (DESIGN.md section 5), so the tiled path keeps
+        # several frames going on separate streams/contexts; frames stay independent until the running mean,
+        # which is applied in frame order.  One GPU rendering the whole frame is already full: one frame there.
+        self.inflight = (inflight if inflight > 0 else 3) if tiled else 1
+        self.pipes = [pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, tile=(self.y0, self.y1),
+                                        accum_limit=10000) for _ in range(self.inflight)]
+        self.pipe = self.pipes[0]
+        self.ctx = self.pipe.ctx
+        self.state = {"frame": 0, "accum": 0, "accum_event": None}
+        if tiled:
+            self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.inflight)]
+            self.splat_full = [torch.zeros(rows * world * W * 4, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
+            self.splat_mine = [torch.zeros(rows * W * 4, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
+            for pp, sf in zip(self.pipes, self.splat_full):
+                pp.ctx.set_splat_buffer(C.c_void_p(sf.data_ptr()), sf.numel())
+        self.last_frame = self.pipe.last_frame  # the running mean is shared by all frames in flight
+
+    def step(self, flags=0):
+        """One pipeline frame on this rank's tile."""
+        torch, pkg, state = self.torch, self.pkg, self.state
+        f = state["frame"]
+        state["frame"] += 1
+        if not self.tiled:
+            self.pipe.render_frame(accumulate=True, extra_flags=flags)
+            return
+        i = f % self.inflight
+        pp, s = self.pipes[i], self.streams[i]
+        y0, y1 = self.y0, self.y1
+        pp.gbuffer_frame, pp.bdpt_frame = 0xdeadbeef + f, 0x1337 + f
+        with torch.cuda.stream(s):
+            # phase 1: everything that writes the splat buffer; then the exchange starts on RCCL's stream while
+            # phase 2 (zero-valued connection rounds) runs on ours
+            _, p = pp.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
+            work = pkg.tiling.exchange_splats_async(self.dist, self.splat_full[i], self.splat_mine[i])
+            st = C.c_void_p(s.cuda_stream)
+            pp.ctx.execute_tail(p, pp.gb, C.c_void_p(pp.output.data_ptr()), st)
+            if work is not None:
+                work.wait()
+            pp.ctx.resolve(C.c_void_p(self.splat_mine[i].data_ptr()), y0, C.c_void_p(pp.output.data_ptr()), st)
+            if state["accum_event"] is not None:
+                s.wait_event(state["accum_event"])  # running mean in frame order
+            n = state["accum"]
+            state["accum"] += 1
+            pp.ctx.accumulate(C.c_void_p(self.last_frame[y0:y1].data_ptr()), C.c_void_p(pp.output[y0:y1].data_ptr()), n,
+                              pp.accum_limit, (y1 - y0) * self.W, st)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            state["accum_event"] = ev
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.dev)
+
+    def rewind(self, frame, accum):
+        self.state["frame"], self.state["accum"] = frame, accum
+        if not self.tiled:
+            self.pipe.gbuffer_frame, self.pipe.bdpt_frame, self.pipe.accum_count = 0xdeadbeef + frame, 0x1337 + frame, accum
+
+    def close(self):
+        for pp in self.pipes:
+            pp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +129,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mat", type=int, default=None, help="0 GGX (default for atrium), 1 Lambertian (default for cornell)")
     ap.add_argument("--triangles", type=int, default=262144)
+    ap.add_argument("--inflight", type=int, default=0, help="frames in flight on the tiled path (0 = auto: 3 tiled, 1 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -85,74 +164,77 @@ def main():
     mat = args.mat if args.mat is not None else (0 if args.scene == "atrium" else 1)
     scene = pkg.Scene.atrium(1, args.triangles) if args.scene == "atrium" else pkg.Scene.cornell()
 
-    # tile = contiguous band of rows; bands padded to equal height so reduce-scatter chunks are equal
-    rows = pkg.tiling.band_rows(H, world)
-    y0, y1 = pkg.tiling.band(H, world, rank)
-    pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, tile=(y0, y1), accum_limit=10000)
-    ctx = pipe.ctx
+    R = TileRenderer(pkg, scene, W, H, D, mat, local_rank, world, rank, dist, tiled, args.inflight)
+    pipes, pipe, ctx, inflight, state = R.pipes, R.pipe, R.ctx, R.inflight, R.state
+    y0, y1 = R.y0, R.y1
+    step, barrier, rewind = R.step, R.barrier, R.rewind
     info = ctx.bvh_info()
-    splat_full = None
-    if tiled:
-        splat_full = torch.zeros(rows * world * W * 4, dtype=torch.int64, device=dev)
-        splat_mine = torch.zeros(rows * W * 4, dtype=torch.int64, device=dev)
-        ctx.set_splat_buffer(C.c_void_p(splat_full.data_ptr()), splat_full.numel())
+    dev = R.dev
 
-    def step(flags=0):
-        """One pipeline frame on this rank's tile."""
-        if not tiled:
-            pipe.render_frame(accumulate=True, extra_flags=flags)
-        else:
-            # phase 1: everything that writes the splat buffer; then the exchange starts on RCCL's stream while
-            # phase 2 (zero-valued connection rounds) runs on ours
-            _, p = pipe.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
-            work = pkg.tiling.exchange_splats_async(dist, splat_full, splat_mine)
-            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            ctx.execute_tail(p, pipe.gb, C.c_void_p(pipe.output.data_ptr()), st)
-            if work is not None:
-                work.wait()
-            ctx.resolve(C.c_void_p(splat_mine.data_ptr()), y0, C.c_void_p(pipe.output.data_ptr()), st)
-            n = pipe.accum_count
-            pipe.accum_count += 1
-            ctx.accumulate(C.c_void_p(pipe.last_frame[y0:y1].data_ptr()), C.c_void_p(pipe.output[y0:y1].data_ptr()), n,
-                           pipe.accum_limit, (y1 - y0) * W, st)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    # ---- untimed: node/triangle visit statistics of the first timed frame (deterministic per frame)
+    # ---- untimed: warm-up, then node/triangle visit statistics of the first timed frame (deterministic per frame)
     for _ in range(args.warmup):
         step()
     barrier()
-    saved = (pipe.gbuffer_frame, pipe.bdpt_frame, pipe.accum_count)
+    mark = (state["frame"], state["accum"] if tiled else pipe.accum_count)
     step(pkg.abi.PARAM_COUNTERS)
     torch.cuda.synchronize(dev)
-    stat = ctx.counters().as_dict()
-    pipe.gbuffer_frame, pipe.bdpt_frame, pipe.accum_count = saved
+    stat = pipes[mark[0] % inflight].ctx.counters().as_dict()
+    rewind(*mark)
     barrier()
 
-    # ---- timed region: exactly K steps, stage times from HIP events on the launch stream
-    ctx.enable_stage_timing(True)
     rays_total = 0
     stage_ms = {}
     per_stage_rays = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for name, ms in ctx.stage_times():  # synchronises on this frame's last event
-            stage_ms[name] = stage_ms.get(name, 0.0) + ms
-        c = ctx.counters().as_dict()
-        rays_total += sum(c[k] for k in ("raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat",
-                                         "raysConnect"))
-        for k in ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect"):
-            per_stage_rays[k] = per_stage_rays.get(k, 0) + c[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.enable_stage_timing(False)
-
+    stage_frames = args.steps
+    if inflight == 1:
+        # ---- timed region: exactly K steps, stage times from HIP events on the launch stream
+        ctx.enable_stage_timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            for name, ms in ctx.stage_times():  # synchronises on this frame's last event
+                stage_ms[name] = stage_ms.get(name, 0.0) + ms
+            c = ctx.counters().as_dict()
+            rays_total += sum(c[k] for k in ("raysPrimary",) + RAY_KEYS)
+            for k in RAY_KEYS:
+                per_stage_rays[k] = per_stage_rays.get(k, 0) + c[k]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.enable_stage_timing(False)
+    else:
+        # ---- stage times of the dominant kernel: two untimed frames run alone (with frames in flight the HIP events
+        # of one frame would also span the other frames' kernels)
+        stage_frames = 2
+        for pp in pipes:
+            pp.ctx.enable_stage_timing(True)
+        for _ in range(stage_frames):
+            f = state["frame"]
+            step()
+            torch.cuda.synchronize(dev)
+            cx = pipes[f % inflight].ctx
+            for name, ms in cx.stage_times():
+                stage_ms[name] = stage_ms.get(name, 0.0) + ms
+            c = cx.counters().as_dict()
+            for k in RAY_KEYS:
+                per_stage_rays[k] = per_stage_rays.get(k, 0) + c[k]
+        for pp in pipes:
+            pp.ctx.enable_stage_timing(False)
+        rewind(*mark)
+        barrier()
+        # ---- timed region: exactly K steps, no host synchronisation inside; ray tallies add up on the device
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(pkg.abi.PARAM_KEEP_COUNTERS if k >= inflight else 0)  # first use of each context zeroes its tallies
+        barrier()
+        elapsed = time.perf_counter() - t0
+        for i, pp in enumerate(pipes):
+            used = len(range(i, args.steps, inflight))  # frames this context rendered (contexts take frames round-robin from mark[0])
+            if used == 0:
+                continue
+            c = pp.ctx.counters().as_dict()
+            rays_total += sum(c[k] for k in RAY_KEYS) + used * (y1 - y0) * W
+    
     t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = t.clone()
@@ -178,10 +260,10 @@ def main():
         # (SURVEY.md §8d): 32 (ray) + nodeBytes*n_int + triBytes*n_tri + 4 (visibility); n_int / n_tri are the
         # device-counted means over all any-hit rays of the same frame.
         shadow_rays_per_frame = (per_stage_rays.get("raysNee", 0) + per_stage_rays.get("raysSplat", 0) +
-                                 per_stage_rays.get("raysConnect", 0)) / K
+                                 per_stage_rays.get("raysConnect", 0)) / stage_frames
         bytes_per_ray = 36 + info.nodeBytes * n_int_s + info.triBytes * n_tri_s
         conn_bytes = shadow_rays_per_frame * bytes_per_ray
-        conn_ms = (stage_ms.get("trace_shadow", 0.0) + stage_ms.get("lazy_trace", 0.0)) / K
+        conn_ms = (stage_ms.get("trace_shadow", 0.0) + stage_ms.get("lazy_trace", 0.0)) / stage_frames
         achieved = conn_bytes / (conn_ms * 1e-3) / 1e9 if conn_ms > 0 else 0.0
         shadow_rays_per_launch = shadow_rays_per_frame
         # HBM-side traffic of the same kernel from committed rocprofv3 PMC passes (separate FETCH_SIZE and
@@ -221,7 +303,10 @@ def main():
                         "max_depth": info.maxDepth, "sah_cost": round(info.sahCost, 2)},
                 "visits_per_ray": {"shadow_nodes": round(n_int_s, 2), "shadow_tris": round(n_tri_s, 2),
                                    "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
-                "stage_ms_per_step": {k: round(v / K, 3) for k, v in stage_ms.items()},
+                "frames_in_flight": inflight,
+                "stage_timing": "HIP events over the timed region" if inflight == 1 else
+                                "HIP events over %d untimed frames run alone on rank 0's band (timed frames overlap)" % stage_frames,
+                "stage_ms_per_step": {k: round(v / stage_frames, 3) for k, v in stage_ms.items()},
                 "stage_mrays": {"walks": round((per_stage_rays.get("raysEyeExtend", 0) + per_stage_rays.get("raysLightExtend", 0))
                                                / (stage_ms["walks"] * 1e-3) / 1e6, 1)} if stage_ms.get("walks", 0) > 0 else {},
                 "trace_shadow_mrays": round(shadow_rays_per_launch / (conn_ms * 1e-3) / 1e6, 1) if conn_ms > 0 else None,
@@ -239,7 +324,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    pipe.close()
+    R.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

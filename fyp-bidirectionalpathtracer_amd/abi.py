@@ -21,6 +21,7 @@ PARAM_SPECULAR_FROM_LOBE = 32
 PARAM_MIS_POWER = 64
 PARAM_MIS_LINEAR = 128
 PARAM_DEFER_TAIL = 256
+PARAM_KEEP_COUNTERS = 512
 
 
 class Material(C.Structure):

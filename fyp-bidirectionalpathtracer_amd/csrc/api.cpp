@@ -596,7 +596,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
   HIPCHK(c, hipMemsetAsync(P.qcount, 0, (size_t)kCursorWords * sizeof(uint32_t), st));
   HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->W * c->H * 4 * sizeof(unsigned long long), st));
-  HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
+  if (!(p->flags & BDPT_PARAM_KEEP_COUNTERS)) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
   stageMark(c, st, "clear");
 
   launchInitPaths(c->S, F, P, st);

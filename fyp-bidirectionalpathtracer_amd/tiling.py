@@ -35,6 +35,9 @@ def exchange_splats(dist, splat_full, splat_mine):
 def exchange_splats_async(dist, splat_full, splat_mine):
     """Start the exchange and return a handle whose wait() orders the current stream after it (RCCL), so the
     caller can enqueue bdpt_execute_tail in between.  gloo has no stream to overlap: it runs synchronously."""
+    if dist is None:  # one rank, no process group: the band is the frame
+        splat_mine.copy_(splat_full[:splat_mine.numel()])
+        return None
     if dist.get_backend() == "nccl":
         return dist.reduce_scatter_tensor(splat_mine, splat_full, op=dist.ReduceOp.SUM, async_op=True)
     exchange_splats(dist, splat_full, splat_mine)

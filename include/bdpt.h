@@ -191,6 +191,10 @@ typedef struct bdpt_params {
  * (zero-valued connection rounds, resolve unless deferred).  The host starts its splat exchange between
  * the two so it overlaps the tail.  Same image as the one-call form, bit for bit. */
 #define BDPT_PARAM_DEFER_TAIL 256u
+/* Do not zero the counters at the start of this execute: tallies add up over frames until an execute
+ * without the flag (lets a host keep several frames in flight without a per-frame read-back;
+ * raysPrimary in bdpt_get_counters stays one frame's worth). */
+#define BDPT_PARAM_KEEP_COUNTERS 512u
 
 /* RayGenCB of lightProbeGBuffer.rt.hlsl:45-52 + the miss shader's env map. */
 typedef struct bdpt_gbuffer_params {

@@ -282,6 +282,30 @@ def test_full_size_config_bands_equal_full_frame(pkg, ob):
     scene.close()
 
 
+def test_frames_in_flight_tiled_loop_equals_plain_loop(pkg):
+    """bench.py's tiled frame loop (two-phase execute, splat exchange, three frames in flight on three streams,
+    running mean applied in frame order) accumulates exactly the image of the plain one-context loop."""
+    import torch
+    import bench
+    scene = pkg.Scene.atrium(2, 20000)
+    W, H, D, frames = 128, 72, 5, 7
+    plain = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, 1, 0, None, False)
+    for _ in range(frames):
+        plain.step()
+    torch.cuda.synchronize()
+    ref = plain.last_frame.cpu().numpy().copy()
+    plain.close()
+    tiled = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, 1, 0, None, True, 3)
+    assert tiled.inflight == 3
+    for _ in range(frames):
+        tiled.step()
+    torch.cuda.synchronize()
+    img = tiled.last_frame.cpu().numpy()
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{(img != ref).any(axis=-1).sum()} pixels differ"
+    tiled.close()
+    scene.close()
+
+
 def test_atrium_frame_matches_oracle(pkg, ob):
     """Textured GGX scene (sRGB textures, roughness/metal map, normal map, alpha mask, SpecGloss, spot light)."""
     import torch

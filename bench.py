@@ -229,12 +229,12 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         for i, pp in enumerate(pipes):
-            used = len(range(i, args.steps, inflight))  # frames this context rendered (contexts take frames round-robin from mark[0])
+            used = sum(1 for k in range(args.steps) if (mark[0] + k) % inflight == i)  # frames this context rendered
             if used == 0:
                 continue
             c = pp.ctx.counters().as_dict()
             rays_total += sum(c[k] for k in RAY_KEYS) + used * (y1 - y0) * W
-    
+
     t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = t.clone()

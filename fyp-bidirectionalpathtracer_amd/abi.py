@@ -102,7 +102,8 @@ class Counters(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("maxDepth", C.c_uint32),
-                ("nodeBytes", C.c_uint32), ("triBytes", C.c_uint32), ("sahCost", C.c_float)]
+                ("nodeBytes", C.c_uint32), ("triBytes", C.c_uint32), ("sahCost", C.c_float), ("maxStack", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/*.h declares

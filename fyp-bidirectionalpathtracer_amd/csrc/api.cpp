@@ -220,6 +220,7 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->bvhInfo.nodeBytes = sizeof(BvhNode);
   c->bvhInfo.triBytes = sizeof(BvhTri);
   c->bvhInfo.sahCost = bvh.sahCost;
+  c->bvhInfo.maxStack = bvh.maxStack;
 
   // per-primitive shading records: 3 x (position, normal, uv) + material id, 112 B
   std::vector<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4, 0.0f);
@@ -301,6 +302,7 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   out->nodeBytes = sizeof(BvhNode);
   out->triBytes = sizeof(BvhTri);
   out->sahCost = bvh.sahCost;
+  out->maxStack = bvh.maxStack;
   if (bvh.maxStack > (uint32_t)kBvhMaxStack) return say("worst-case stack exceeds kBvhMaxStack");
   if (bvh.tris.size() != d->numTriangles) return say("triangle list size");
   std::vector<uint8_t> seen(d->numTriangles, 0);

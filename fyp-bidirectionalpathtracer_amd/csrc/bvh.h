@@ -38,7 +38,10 @@ struct alignas(16) BvhTri {
 };
 static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
 
-constexpr int kBvhMaxStack = 31;  // worst-case traversal stack entries (device stack holds 32 per lane)
+#ifndef KSTACK
+#define KSTACK 32
+#endif
+constexpr int kBvhMaxStack = KSTACK - 1;  // worst-case traversal stack entries (the device stack holds KSTACK per lane)
 constexpr uint32_t kTriNonOpaque = 1u, kTriDoubleSided = 2u;
 
 struct Bvh {

@@ -251,6 +251,8 @@ typedef struct bdpt_bvh_info {
   uint32_t nodeBytes; /* bytes per interior node */
   uint32_t triBytes;  /* bytes per leaf triangle */
   float sahCost;
+  uint32_t maxStack;  /* worst-case traversal stack entries this tree needs (the device holds 32 per lane) */
+  uint32_t reserved;
 } bdpt_bvh_info;
 
 typedef struct bdpt_ctx bdpt_ctx;

@@ -306,6 +306,33 @@ def test_frames_in_flight_tiled_loop_equals_plain_loop(pkg):
     scene.close()
 
 
+def test_frame_can_be_captured_in_a_hip_graph(pkg):
+    """the execute calls allocate nothing and never block, and the internal second
+    stream is forked/joined with events, so a host may capture a frame in a hipGraph; the replay is bit-identical."""
+    import torch
+    scene = pkg.Scene.atrium(5, 12000)
+    pipe = pkg.FramePipeline(scene, 160, 90, max_depth=5, mat_index=0)
+    pipe.render_frame()
+    torch.cuda.synchronize()
+    ref = pipe.output.clone()
+    pipe.gbuffer_frame, pipe.bdpt_frame = 0xdeadbeef, 0x1337
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        pipe.render_frame()
+        graph.capture_end()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        pipe.output.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(pipe.output, ref)
+    del graph
+    pipe.close()
+    scene.close()
+
+
 def test_atrium_frame_matches_oracle(pkg, ob):
     """Textured GGX scene (sRGB textures, roughness/metal map, normal map, alpha mask, SpecGloss, spot light)."""
     import torch

@@ -2,9 +2,9 @@
 
 CPU tests check the loader against the reference's import rules restated independently here in numpy
 (SceneImporter.cpp:106-460, ObjectInstance.h:271-278, Light.cpp:90-210, AssimpModelImporter.cpp:326-417,
-Material.cpp:119-184) and against the one scene file the reference ships (tests/golden/pink_room.fscene, a copy of
-CommonPasses/Data/pink_room/pink_room.fscene; its geometry blob is absent from the reference tree, so the test
-points the model entry at a generated OBJ).  The GPU test renders the loaded scene and compares with the oracle.
+Material.cpp:119-184) and against the light / camera values of the one scene file the reference ships
+(tests/golden/pink_room_values.json, extracted from CommonPasses/Data/pink_room/pink_room.fscene; its geometry
+blob is absent from the reference tree, so the test points the model entry at a generated OBJ).  The GPU test renders the loaded scene and compares with the oracle.
 """
 import ctypes as C
 import json
@@ -176,11 +176,14 @@ def test_lights_and_camera(pkg, courtyard):
 
 
 def test_reference_scene_file(pkg, tmp_path):
-    """The reference's own pink_room.fscene: 1 directional + 2 point lights, Camera0 (values read off the file)."""
-    src = json.load(open(os.path.join(GOLDEN, "pink_room.fscene")))
+    """Lights and camera of the reference's own pink_room.fscene (values extracted by
+    tests/golden/make_pink_room_fixture.py): 1 directional + 2 point lights, Camera0."""
+    src = json.load(open(os.path.join(GOLDEN, "pink_room_values.json")))
     scene_files.write_scene_set(tmp_path)
-    text = open(os.path.join(GOLDEN, "pink_room.fscene")).read().replace("pink_room.fbx", "room.obj")
-    (tmp_path / "pink_room.fscene").write_text(text)
+    doc = {"version": src["version"], "active_camera": src["active_camera"], "lights": src["lights"], "cameras": src["cameras"],
+           "models": [{"file": "room.obj", "name": "pink_room",
+                       "instances": [{"name": "pink_room0", "translation": [0, 0, 0], "scaling": [1, 1, 1], "rotation": [0, 0, 0]}]}]}
+    (tmp_path / "pink_room.fscene").write_text(json.dumps(doc, indent=4))
     s = pkg.Scene.load(tmp_path / "pink_room.fscene")
     d = s.desc
     assert d.numLights == len(src["lights"]) == 3 and d.numTriangles == 18

@@ -404,6 +404,60 @@ def test_thin_lens_random_jitter_and_env_map(pkg, ob):
     scene.close()
 
 
+def test_hip_path_against_committed_golden_fixtures(pkg, gpu_ctx):
+    """The same comparisons without the live oracle: tests/golden/oracle_golden.npz (written by make_golden.py)
+    holds RNG streams, BSDF records, hit records and Cornell images; the HIP path must reproduce them bit for bit."""
+    import os
+    import torch
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
+    st, fl = gpu_ctx.test_rng(gold["rng_v0"], gold["rng_v1"], gold["rng_states"].shape[1])
+    assert np.array_equal(st, gold["rng_states"]) and np.array_equal(fl.view(np.uint32), gold["rng_floats"].view(np.uint32))
+    for mat in (0, 1, 2):
+        out = gpu_ctx.test_bsdf(gold["bsdf_in"], mat)
+        ref = gold[f"bsdf_out_{mat}"]
+        same = (out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref))
+        assert same.all(), mat
+    soup = pkg.Scene.soup(11, 600, 0.3)
+    ctx = pkg.Context(0)
+    ctx.set_scene(soup.desc)
+    for mode in (0, 1, 2):
+        prim, tuv = ctx.test_trace(gold["trace_rays"], mode)
+        assert np.array_equal(prim, gold[f"trace_prim_{mode}_brute"]) and np.array_equal(prim, gold[f"trace_prim_{mode}_bvh"])
+        if mode != 2:
+            assert np.array_equal(tuv.view(np.uint32), gold[f"trace_tuv_{mode}_brute"].view(np.uint32))
+    ctx.close()
+    soup.close()
+    scene = pkg.Scene.cornell()
+    cam = pkg.abi.Camera()  # the stored basis (its tan/atan came from the generating machine's libm)
+    for i in range(3):
+        cam.posW[i], cam.cameraU[i], cam.cameraV[i], cam.cameraW[i] = (float(gold["cornell_camera"][r, i]) for r in range(4))
+    for key, size, depth, mat, flags in (("cornell64_d3_ggx", 64, 3, 0, 0), ("cornell64_d3_lambert", 64, 3, 1, 0),
+                                         ("cornell48_d8_lambert", 48, 8, 1, 0), ("cornell256_d3_ggx_config1", 256, 3, 0, 0),
+                                         ("cornell32_d5_ggx_lobe", 32, 5, 0, pkg.abi.PARAM_SPECULAR_FROM_LOBE),
+                                         ("cornell64_d3_ggx_nee_only", 64, 3, 0, pkg.abi.PARAM_NO_SPLAT | pkg.abi.PARAM_NO_CONNECT),
+                                         ("cornell64_d3_ggx_splat_only", 64, 3, 0, pkg.abi.PARAM_NO_NEE | pkg.abi.PARAM_NO_CONNECT),
+                                         ("cornell64_d3_ggx_connect_only", 64, 3, 0, pkg.abi.PARAM_NO_NEE | pkg.abi.PARAM_NO_SPLAT)):
+        pipe = pkg.FramePipeline(scene, size, size, max_depth=depth, mat_index=mat, flags=flags, clamp_upper=0.9, min_t=1e-4)
+        pipe.cam = cam
+        pipe.ctx.set_camera(cam)
+        pipe.render_frame()   # frame 0 of make_golden.frame_params: counters 0xdeadbeef / 0x1337, MSAA jitter
+        torch.cuda.synchronize()
+        img = pipe.output.cpu().numpy()
+        assert np.array_equal(img.view(np.uint32), gold[key + "_image"].view(np.uint32)), key
+        ptr, n64 = pipe.ctx.splat_buffer()
+        spl = torch.empty(n64, dtype=torch.int64, device=pipe.dev)
+        C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(spl.data_ptr()), C.c_void_p(ptr), C.c_size_t(n64 * 8), 3)
+        assert np.array_equal(spl.cpu().numpy().view(np.uint64).reshape(-1, 4), gold[key + "_splat"]), key
+        if key == "cornell64_d3_ggx":
+            names = {"WorldPosition": "worldPosition", "WorldNormal": "worldNormal", "MaterialDiffuse": "materialDiffuse",
+                     "MaterialSpecRough": "materialSpecRough", "MaterialExtraParams": "materialExtra", "Emissive": "emissive"}
+            for ch, on in names.items():
+                g = pipe.channels[ch].float().cpu().numpy().reshape(-1, 4)
+                assert np.array_equal(g.view(np.uint32), gold["cornell64_gbuffer_" + on].view(np.uint32)), ch
+        pipe.close()
+    scene.close()
+
+
 def test_error_conventions(pkg, gpu_ctx):
     scene = pkg.Scene.cornell()
     ctx = pkg.Context(0)

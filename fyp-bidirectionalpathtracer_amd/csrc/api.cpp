@@ -54,6 +54,8 @@ struct bdpt_ctx {
   bool evCreated = false;
   // the light walk runs beside the eye walk on this stream (fork/join with events; capture-safe)
   int lazyRounds = kLazyRounds;
+  // channels of the built-in primary stage (bdpt_execute with in == NULL), allocated on first use
+  bdpt_gbuffer ownGb{};
   // BMFR history (allocated by the first bdpt_bmfr_execute): [2] = ping-pong pair
   float4* bmfrPos[2] = {nullptr, nullptr};
   float4* bmfrNorm[2] = {nullptr, nullptr};
@@ -418,6 +420,7 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   HIPCHK(c, hipDeviceSynchronize());
   freePool(c->frameAllocs);
   for (int k = 0; k < 2; k++) c->bmfrPos[k] = c->bmfrNorm[k] = c->bmfrNoisy[k] = c->bmfrFiltered[k] = nullptr;
+  c->ownGb = bdpt_gbuffer{};
   c->bmfrAccept = nullptr;  // history goes with the frame (BlockwiseMultiOrderFeatureRegression::resize)
   c->bmfrPrevPixel = nullptr;
   c->haveSize = false;
@@ -525,7 +528,24 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
 namespace {
 // argument checks shared by bdpt_execute and bdpt_execute_tail, and the per-frame constants the kernels take
 int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, FrameDev& F) {
-  if (!c || !p || !in || !out) return BDPT_E_INVALID;
+  if (!c || !p || !out) return BDPT_E_INVALID;
+  if (!in) {  // the context's own channels: the primary stage runs inside bdpt_execute
+    if (!c->haveSize) {
+      fail(c, "execute: scene, camera and size must be set first");
+      return BDPT_E_STATE;
+    }
+    if (!c->ownGb.worldPosition) {
+      const size_t n = (size_t)c->W * c->H;
+      int rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.worldPosition, n * 4))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.worldNormal, n * 4))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.materialDiffuse, n * 4))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.materialSpecRough, n * 4))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.materialExtraParams, n * 4))) return rc;
+      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.emissive, n * 4))) return rc;
+    }
+    in = &c->ownGb;
+  }
   if (!c->haveScene || !c->haveCamera || !c->haveSize) {
     fail(c, "execute: scene, camera and size must be set first");
     return BDPT_E_STATE;
@@ -592,6 +612,19 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   if (int rc = frameSetup(c, p, in, out, F)) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const PathBuf& P = c->P;
+  if (!in) {
+    // Built-in primary stage: pinhole camera, this frame's jitter and counter, the default constant
+    // environment (SharedUtils/ResourceManager.cpp:77-87) — what LightProbeGBufferPass does with its defaults.
+    bdpt_gbuffer_params gp{};
+    gp.pixelJitter[0] = p->pixelJitter[0];
+    gp.pixelJitter[1] = p->pixelJitter[1];
+    gp.focalLen = 1.0f;
+    gp.frameCount = p->frameCount;
+    gp.envColor[0] = gp.envColor[1] = 0.5f;
+    gp.envColor[2] = 0.8f;
+    gp.envColor[3] = 1.0f;
+    if (int rc = bdpt_gbuffer_execute(c, &gp, &c->ownGb, stream)) return rc;
+  }
   const int D = (int)p->maxDepth;
 
   c->numStages = 0;

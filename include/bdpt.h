@@ -290,7 +290,10 @@ int bdpt_gbuffer_execute(bdpt_ctx* ctx, const bdpt_gbuffer_params* p, const bdpt
 /* The BDPT pass.  `out` is the full-frame RGBA32F "PipelineOutput" channel;
  * only the tile rows are written (cleared to 0 first, as getClearedTexture does,
  * BDPTPass.cpp:73).  Without BDPT_PARAM_DEFER_RESOLVE the splats of this call are
- * folded in before returning control to the stream. */
+ * folded in before returning control to the stream.
+ * `in` may be NULL: the primary stage then runs inside the call into channels the context owns
+ * (pinhole, p->pixelJitter, p->frameCount, default constant environment); the first such call
+ * allocates them. */
 int bdpt_execute(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream);
 
 /* Second phase of a bdpt_execute issued with BDPT_PARAM_DEFER_TAIL (same params, channels and out). */

@@ -458,6 +458,28 @@ def test_hip_path_against_committed_golden_fixtures(pkg, gpu_ctx):
     scene.close()
 
 
+def test_execute_with_builtin_primary_stage(pkg):
+    """bdpt_execute(in = NULL) == bdpt_gbuffer_execute with the same jitter/counter + bdpt_execute on its channels."""
+    import torch
+    scene = pkg.Scene.atrium(4, 15000)
+    pipe = pkg.FramePipeline(scene, 96, 64, max_depth=4, mat_index=0)
+    p = pipe.bdpt_params()
+    gp = pipe.gbuffer_params()
+    gp.pixelJitter[0], gp.pixelJitter[1], gp.frameCount = p.pixelJitter[0], p.pixelJitter[1], p.frameCount
+    st = pipe._stream_ptr()
+    pipe.ctx.gbuffer_execute(gp, pipe.gb, st)
+    pipe.ctx.execute(p, pipe.gb, C.c_void_p(pipe.output.data_ptr()), st)
+    torch.cuda.synchronize()
+    ref = pipe.output.clone()
+    pipe.output.zero_()
+    lib = pkg.load_library()
+    assert lib.bdpt_execute(pipe.ctx._h, C.byref(p), None, C.c_void_p(pipe.output.data_ptr()), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pipe.output, ref)
+    pipe.close()
+    scene.close()
+
+
 def test_error_conventions(pkg, gpu_ctx):
     scene = pkg.Scene.cornell()
     ctx = pkg.Context(0)

@@ -41,7 +41,10 @@ static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
 #ifndef KSTACK
 #define KSTACK 32
 #endif
-constexpr int kBvhMaxStack = KSTACK - 1;  // worst-case traversal stack entries (the device stack holds KSTACK per lane)
+#ifndef BDPT_BVH_STACK_BUDGET
+#define BDPT_BVH_STACK_BUDGET (KSTACK - 1)
+#endif
+constexpr int kBvhMaxStack = BDPT_BVH_STACK_BUDGET;  // worst-case traversal stack entries (the device stack holds KSTACK per lane)
 constexpr uint32_t kTriNonOpaque = 1u, kTriDoubleSided = 2u;
 
 struct Bvh {

@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--mat", type=int, default=None, help="0 GGX (default for atrium), 1 Lambertian (default for cornell)")
     ap.add_argument("--triangles", type=int, default=262144)
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight on the tiled path (0 = auto: 3 tiled, 1 otherwise)")
+    ap.add_argument("--no-pipelined-pass", dest="pipelined_pass", action="store_false",
+                    help="skip the informational three-frames-in-flight pass at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -235,6 +237,31 @@ def main():
             c = pp.ctx.counters().as_dict()
             rays_total += sum(c[k] for k in RAY_KEYS) + used * (y1 - y0) * W
 
+    # ---- informational second pass at N = 1: the same K frames with three frames in flight (the tiled loop on one
+    # band = the whole frame).  `value` stays the one-frame-in-flight figure the roofline durations belong to.
+    pipelined = None
+    if world == 1 and not tiled and args.pipelined_pass:
+        P3 = TileRenderer(pkg, scene, W, H, D, mat, local_rank, 1, 0, None, True, 3)
+        for _ in range(3):
+            P3.step()
+        P3.barrier()
+        P3.rewind(mark[0], mark[0])
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            P3.step(pkg.abi.PARAM_KEEP_COUNTERS if k >= P3.inflight else 0)
+        P3.barrier()
+        dt3 = time.perf_counter() - t1
+        rays3 = 0
+        for i, pp in enumerate(P3.pipes):
+            used = sum(1 for k in range(args.steps) if (mark[0] + k) % P3.inflight == i)
+            if used:
+                c = pp.ctx.counters().as_dict()
+                rays3 += sum(c[k] for k in RAY_KEYS) + used * H * W
+        pipelined = {"frames_in_flight": 3, "value": round(rays3 / dt3 / 1e6, 2), "unit": "Mrays/s",
+                     "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                     "note": "same frames, three contexts on three streams, running mean in frame order; informational"}
+        P3.close()
+
     t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = t.clone()
@@ -304,6 +331,7 @@ def main():
                 "visits_per_ray": {"shadow_nodes": round(n_int_s, 2), "shadow_tris": round(n_tri_s, 2),
                                    "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
                 "frames_in_flight": inflight,
+                "pipelined_pass": pipelined,
                 "stage_timing": "HIP events over the timed region" if inflight == 1 else
                                 "HIP events over %d untimed frames run alone on rank 0's band (timed frames overlap)" % stage_frames,
                 "stage_ms_per_step": {k: round(v / stage_frames, 3) for k, v in stage_ms.items()},

@@ -1,0 +1,53 @@
+"""The oracle against a second, independent reading of the shader code (tests/hlsl_reference_math.py: float64,
+true cos/sin/pow, written from the HLSL files).  The reference pins nothing for these functions, so this is the
+strongest check available that the oracle's BSDF arithmetic says what BRDFUtils.hlsli / MaterialUtils.hlsli say —
+and it bounds the error of the oracle's fixed polynomial transcendental forms."""
+import os
+
+import numpy as np
+
+import hlsl_reference_math as hm
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
+
+
+def _rel(a, b, floor):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert (np.isfinite(a) == np.isfinite(b)).all()
+    m = np.isfinite(a)
+    return float(np.max(np.abs(a[m] - b[m]) / (floor + np.abs(b[m])))) if m.any() else 0.0
+
+
+def test_bsdf_records_match_float64_reading_of_the_hlsl(pkg, ob):
+    rin = GOLD["bsdf_in"]
+    seeds = rin.view(np.uint32)[:, 17]
+    for mat in (0, 1, 2):
+        out = np.zeros((rin.shape[0], 16), np.float32)
+        ob.load_oracle(pkg.abi).oracle_bsdf(rin.ctypes.data, rin.shape[0], mat, out.ctypes.data)
+        assert np.array_equal(out.view(np.uint32), GOLD[f"bsdf_out_{mat}"].view(np.uint32))  # the live oracle == the fixture
+        worst = dict(w=0.0, L=0.0, pdf=0.0, f=0.0)
+        checked = 0
+        for i in range(rin.shape[0]):
+            r = rin[i, :17].astype(np.float64)  # [17] holds the seed bits
+            n, v, l, dif, spec, rough = r[0:3], r[3:6], r[6:9], r[9:12], r[12:15], r[15]
+            w, L, pdf, lobe, margin = hm.sample_brdf(mat & 1, int(seeds[i]), n, v, dif, spec, rough)
+            if margin < 1e-6:
+                continue  # the lobe choice sits on a rounding boundary
+            f = hm.eval_brdf(mat & 1, v, l, n, dif, spec, rough, rin[i, 16] != 0)
+            o = out[i].astype(np.float64)
+            worst["w"] = max(worst["w"], _rel(o[0:3], w, 1e-4))
+            worst["L"] = max(worst["L"], float(np.max(np.abs(o[3:6] - L))))
+            worst["pdf"] = max(worst["pdf"], _rel(o[6], pdf, 1e-4))
+            worst["f"] = max(worst["f"], _rel(o[8:11], f, 1e-4))
+            # isSpecular out-parameter: never written by sampleGGXBRDF -> defined false (mat 0), "lobe picked" with the flag (mat 2)
+            assert o[7] == (1.0 if (mat == 2 and lobe) else 0.0)
+            checked += 1
+        assert checked > 0.99 * rin.shape[0]
+        assert worst["w"] < 5e-4 and worst["pdf"] < 5e-4 and worst["f"] < 5e-4 and worst["L"] < 1e-4, (mat, worst)
+
+
+def test_deterministic_sincos_against_libm(ob, pkg):
+    """det_sincos2pi (the stand-in for HLSL sin/cos of 2*pi*u) against numpy's double-precision functions."""
+    u = GOLD["sincos_u"].astype(np.float64)
+    assert np.max(np.abs(GOLD["sincos_s"] - np.sin(2 * np.pi * u))) < 2e-6
+    assert np.max(np.abs(GOLD["sincos_c"] - np.cos(2 * np.pi * u))) < 2e-6

@@ -1125,6 +1125,7 @@ void bdptPixel(const Globals& g, Tally& tl, oracle_frame* f, uint32_t x, uint32_
       float lengthAB = length(posB - posA);
       f3 dirAB = (posB - posA) / lengthAB;
       bool vis = shadowRayVisibility(g, tl, 5, posA, dirAB, g.p.minT, lengthAB);
+      if (g.flags & ORACLE_CONNECT_ALL_VISIBLE) vis = true;  // cross-check hook, see bdpt_oracle.h
       if (vis) {
         f3 shade = getUnweightedContribution(g, cameraPath, lightPath, cameraLength, lightLength, G);
         shade = clampVec(g, applyStrategyWeight(g, cameraPath, lightPath, shade, totalLength, cameraLength, lightLength));

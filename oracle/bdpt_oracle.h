@@ -40,6 +40,11 @@ oracle_scene* oracle_scene_create(const bdpt_scene_desc* desc);
 void oracle_scene_destroy(oracle_scene* s);
 
 #define ORACLE_BRUTE_FORCE 1u /* intersect every triangle instead of using the BVH */
+/* Cross-check hook (tests/test_oracle_cross_check.py): treat every vertex-connection shadow ray as unoccluded.
+ * The reference ends those rays exactly ON the far surface (tmax = |B-A|, BDPTMain.rt.hlsl:222-223), so whether
+ * the far surface itself occludes them is decided by the last bit of the arithmetic; with this flag the
+ * connection sums can be compared with an implementation in another precision. */
+#define ORACLE_CONNECT_ALL_VISIBLE 2u
 
 typedef struct oracle_frame {
   uint32_t width, height;

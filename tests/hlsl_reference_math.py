@@ -29,6 +29,8 @@ def luminance(c):  # Falcor Data/HostDeviceSharedCode.h / Helpers.slang: Rec.709
 
 
 def saturate(x):
+    if x != x:  # HLSL saturate(NaN) = 0
+        return 0.0
     return min(max(x, 0.0), 1.0)
 
 
@@ -63,8 +65,9 @@ def ggx_d(ndoth, rough):
 
 
 def ggx_g(ndotl, ndotv, rough):
-    k = rough * rough / 2
-    return (ndotv / (ndotv * (1 - k) + k)) * (ndotl / (ndotl * (1 - k) + k))
+    k = np.float64(rough * rough / 2)
+    with np.errstate(divide="ignore", invalid="ignore"):  # 0/0 -> NaN as on the GPU, not an exception
+        return (np.float64(ndotv) / (ndotv * (1 - k) + k)) * (np.float64(ndotl) / (ndotl * (1 - k) + k))
 
 
 def schlick(f0, u):

@@ -7,6 +7,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_PATH = os.path.join(_ROOT, "oracle", "liboracle.so")
 ORACLE_BRUTE_FORCE = 1
+ORACLE_CONNECT_ALL_VISIBLE = 2
 
 
 class OracleFrame(C.Structure):

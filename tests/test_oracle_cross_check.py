@@ -51,3 +51,70 @@ def test_deterministic_sincos_against_libm(ob, pkg):
     u = GOLD["sincos_u"].astype(np.float64)
     assert np.max(np.abs(GOLD["sincos_s"] - np.sin(2 * np.pi * u))) < 2e-6
     assert np.max(np.abs(GOLD["sincos_c"] - np.cos(2 * np.pi * u))) < 2e-6
+
+
+def _frame_params(pkg, depth, mat, flags, min_t):
+    A = pkg.abi
+    gp = A.GBufferParams()
+    gp.pixelJitter[0], gp.pixelJitter[1] = pkg.msaa_jitter(0xdeadbeef)
+    gp.frameCount, gp.focalLen, gp.lensRadius = 0xdeadbeef, 1.0, 1.0 / 64.0
+    gp.envWidth = gp.envHeight = 128
+    for i, c in enumerate((0.5, 0.5, 0.8, 1.0)):
+        gp.envColor[i] = c
+    p = A.Params()
+    p.minT, p.frameCount, p.matIndex, p.maxDepth = min_t, 0x1337, mat, depth
+    p.refractiveIndex, p.emitMult, p.clampUpper, p.flags = 1.0, 1.0, 0.9, flags
+    p.pixelJitter[0], p.pixelJitter[1] = pkg.msaa_jitter(0x1337)
+    return gp, p
+
+
+import pytest
+
+
+@pytest.mark.parametrize("size,depth,mat", [(16, 3, 1), (16, 3, 0), (12, 5, 1), (10, 4, 0)])
+def test_integrator_matches_float64_reading_of_the_raygen_shader(pkg, ob, size, depth, mat):
+    """The whole ray-generation shader (BDPTMain.rt.hlsl:42-234: both walks, NEE, light-tracing splats, vertex
+    connections with all its indexing quirks) re-read independently in float64 (tests/hlsl_integrator_numpy.py, own
+    brute-force intersection) against the oracle, stage by stage on a small Cornell frame.
+
+    Two things make a cross-precision comparison possible at all: gMinT = 0.05 instead of 1e-4 (in the 555-unit box a
+    hit point is only known to ~1e-4, so with the default every grazing ray's self-intersection is a coin flip), and
+    the ORACLE_CONNECT_ALL_VISIBLE hook (the reference ends connection rays exactly ON the far surface, so that
+    surface occludes them or not depending on the last bit).  With those, every pixel, splat target and splat count
+    agrees."""
+    import hlsl_integrator_numpy as hi
+    A = pkg.abi
+    scene = pkg.Scene.cornell()
+    cam = scene.camera(1.0)
+    stages = (("nee", A.PARAM_NO_SPLAT | A.PARAM_NO_CONNECT, dict(splat=False, connect=False), 0),
+              ("splat", A.PARAM_NO_NEE | A.PARAM_NO_CONNECT, dict(nee=False, connect=False), 0),
+              ("connect", A.PARAM_NO_NEE | A.PARAM_NO_SPLAT, dict(nee=False, splat=False, connect_all_visible=True),
+               ob.ORACLE_CONNECT_ALL_VISIBLE))
+    for name, flags, kw, oflags in stages:
+        gp, p = _frame_params(pkg, depth, mat, flags, 0.05)
+        orc = ob.OracleRender(A, scene.desc, size, size)
+        orc.gbuffer(cam, gp)
+        orc.bdpt(cam, p, flags=oflags)
+        own = orc.image().astype(np.float64)           # own-pixel terms (before the splat fold-in)
+        splat = orc.splat.astype(np.float64)
+        splat[:, :3] /= 2.0 ** 32
+        R = hi.Renderer(hi.Scene(scene.desc), cam, p, size, size)
+        img = np.zeros((size, size, 4))
+        spl = np.zeros((size * size, 4))
+        for y in range(size):
+            for x in range(size):
+                i = y * size + x
+                with np.errstate(all="ignore"):
+                    o, ss = R.pixel(x, y, orc.chan["worldPosition"][i], orc.chan["worldNormal"][i], orc.chan["materialDiffuse"][i],
+                                    orc.chan["materialSpecRough"][i], orc.chan["emissive"][i], **kw)
+                img[y, x] = o
+                for tx, ty, c in ss:
+                    spl[ty * size + tx, :3] += c
+                    spl[ty * size + tx, 3] += 1
+        assert np.abs(img - own).max() < 2e-5, (name, np.abs(img - own).max())
+        assert np.array_equal(spl[:, 3], splat[:, 3]), name     # same splats land on the same pixels
+        assert np.abs(spl[:, :3] - splat[:, :3]).max() < 2e-5, name
+        if name == "splat":
+            assert splat[:, 3].sum() > size * size / 2
+        orc.close()
+    scene.close()

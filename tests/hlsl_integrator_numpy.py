@@ -334,3 +334,53 @@ def hm_init_rand(val0, val1, backoff=16):  # BDPTUtils.hlsli:91-103
         v0 = (v0 + ((((v1 << 4) + 0xa341316c) & 0xFFFFFFFF) ^ ((v1 + s0) & 0xFFFFFFFF) ^ (((v1 >> 5) + 0xc8013ea4) & 0xFFFFFFFF))) & 0xFFFFFFFF
         v1 = (v1 + ((((v0 << 4) + 0xad90777d) & 0xFFFFFFFF) ^ ((v0 + s0) & 0xFFFFFFFF) ^ (((v0 >> 5) + 0x7e95761e) & 0xFFFFFFFF))) & 0xFFFFFFFF
     return v0
+
+
+def gbuffer_pixel(scene, cam, gp, width, height, x, y, env_color):
+    """GBufferRayGen + PrimaryClosestHit / PrimaryMiss (CommonPasses/Data/CommonPasses/lightProbeGBuffer.rt.hlsl:63-159)
+    for constant materials and a constant environment -> dict of the channels written (None for a miss).
+
+    Back faces are culled (RAY_FLAG_CULL_BACK_FACING_TRIANGLES); which winding is "front" is the driver's business,
+    the build defines it as det > 0 in Moeller-Trumbore, and double-sided materials are exempt (Falcor marks their
+    instances TRIANGLE_CULL_DISABLE)."""
+    cam_pos = np.array(list(cam.posW), np.float64)
+    U, V, W = (np.array(list(getattr(cam, k)), np.float64) for k in ("cameraU", "cameraV", "cameraW"))
+    pc = np.array([(x + gp.pixelJitter[0]) / width, (y + gp.pixelJitter[1]) / height])
+    ndc = np.array([2.0, -2.0]) * pc + np.array([-1.0, 1.0])
+    ray_dir = ndc[0] * U + ndc[1] * V + W
+    ray_dir = ray_dir / np.linalg.norm(W)
+    focal = cam_pos + gp.focalLen * ray_dir
+    seed = hm_init_rand(x + y * width, int(gp.frameCount))
+    seed, r0 = hm.next_rand(seed)
+    seed, r1 = hm.next_rand(seed)
+    a, rad = 2.0 * M_PI * r0, gp.lensRadius * r1
+    uv = np.array([math.cos(a) * rad, math.sin(a) * rad])
+    origin = cam_pos + uv[0] * norm(U) + uv[1] * norm(V)
+    o = origin if gp.useThinLens else cam_pos
+    d = norm(focal - origin) if gp.useThinLens else norm(ray_dir)
+    # closest front-facing hit, brute force
+    e1, e2 = scene.v1 - scene.v0, scene.v2 - scene.v0
+    p = np.cross(d, e2)
+    det = np.einsum("ij,ij->i", e1, p)
+    dbl = np.array([(scene.mats[m].flags >> 19) & 1 for m in scene.mat_id], bool)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / det
+        tv = o - scene.v0
+        u = np.einsum("ij,ij->i", tv, p) * inv
+        q = np.cross(tv, e1)
+        v = np.einsum("ij,j->i", q, d) * inv
+        t = np.einsum("ij,ij->i", e2, q) * inv
+    ok = ((det > 0) | (dbl & (det != 0))) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > 0.0) & (t < 1e38)
+    if not ok.any():
+        return dict(hit=False, dif=np.array([env_color[0], env_color[1], env_color[2], 1.0]))
+    cand = np.nonzero(ok)[0]
+    prim = int(cand[np.argmin(t[cand])])
+    pos, n, vv, dif, spec, rough = scene.shading(prim, float(u[prim]), float(v[prim]), o, d, float(t[prim]))
+    # the G-buffer's V is toward gCamera.posW (prepareShadingData(vsOut, gMaterial, gCamera.posW, 0)), also for thin-lens origins
+    m = scene.mats[scene.mat_id[prim]]
+    n2 = norm(scene.n0[prim] * (1.0 - u[prim] - v[prim]) + scene.n1[prim] * u[prim] + scene.n2[prim] * v[prim])
+    v_cam = norm(cam_pos - pos)
+    if float(np.dot(n2, v_cam)) <= 0 and ((m.flags >> 19) & 1):
+        n2 = -n2
+    return dict(hit=True, pos=pos, N=n2, dist=float(np.linalg.norm(pos - cam_pos)), dif=np.append(dif, m.baseColor[3]),
+                spec=np.append(spec, math.sqrt(rough)), ior=m.IoR, prim=prim)

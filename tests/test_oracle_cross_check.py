@@ -118,3 +118,37 @@ def test_integrator_matches_float64_reading_of_the_raygen_shader(pkg, ob, size, 
             assert splat[:, 3].sum() > size * size / 2
         orc.close()
     scene.close()
+
+
+@pytest.mark.parametrize("thin_lens", [0, 1])
+def test_gbuffer_matches_float64_reading_of_the_primary_shaders(pkg, ob, thin_lens):
+    """lightProbeGBuffer.rt.hlsl:63-159 (pinhole and thin-lens ray generation, closest-hit channel writes, miss colour)
+    re-read in float64 against the oracle's G-buffer on the Cornell box; half-precision channels to half precision."""
+    import hlsl_integrator_numpy as hi
+    size = 24
+    scene = pkg.Scene.cornell()
+    cam = scene.camera(1.0)
+    gp, _ = _frame_params(pkg, 3, 0, 0, 1e-4)
+    gp.useThinLens, gp.lensRadius, gp.focalLen = thin_lens, 4.0, 700.0
+    orc = ob.OracleRender(pkg.abi, scene.desc, size, size)
+    orc.gbuffer(cam, gp)
+    sc = hi.Scene(scene.desc)
+    hits = 0
+    for y in range(size):
+        for x in range(size):
+            i = y * size + x
+            with np.errstate(all="ignore"):
+                g = hi.gbuffer_pixel(sc, cam, gp, size, size, x, y, (0.5, 0.5, 0.8))
+            wp, wn = orc.chan["worldPosition"][i], orc.chan["worldNormal"][i]
+            if not g["hit"]:
+                assert wp[3] == 0.0 and np.allclose(orc.chan["materialDiffuse"][i], g["dif"], atol=1e-3)
+                continue
+            hits += 1
+            assert wp[3] == 1.0 and np.abs(wp[:3] - g["pos"]).max() < 2e-3, (x, y, wp, g["pos"])
+            assert np.abs(wn[:3] - g["N"]).max() < 2e-3 and abs(wn[3] - g["dist"]) < 0.6           # fp16: 0.5 at ~800
+            assert np.abs(orc.chan["materialDiffuse"][i] - g["dif"]).max() < 1e-3
+            assert np.abs(orc.chan["materialSpecRough"][i] - g["spec"]).max() < 1e-3
+            assert abs(orc.chan["materialExtra"][i][0] - g["ior"]) < 1e-3
+    assert hits > 0.9 * size * size
+    orc.close()
+    scene.close()

@@ -103,7 +103,8 @@ class Vertex:
 
 
 class Renderer:
-    def __init__(self, scene, cam, params, width, height, specular_from_lobe=False):
+    def __init__(self, scene, cam, params, width, height, specular_from_lobe=False, mis=None):
+        self.mis = mis  # None: the uniform 1/k the shader applies; "power" / "linear": getWeightPower / getWeightLinear
         self.s, self.W, self.H = scene, width, height
         self.cam_pos = np.array(list(cam.posW), np.float64)
         self.U, self.Vv, self.Wv = (np.array(list(getattr(cam, k)), np.float64) for k in ("cameraU", "cameraV", "cameraW"))
@@ -233,6 +234,30 @@ class Renderer:
             d = vec * inv
             return abs(float(np.dot(a.N, d))) * abs(float(np.dot(b.N, d))) * inv * inv
 
+    def weight(self, cp, lp, ci, li):
+        """getWeightPower / getWeightLinear (BDPTUtils.hlsli:226-278); `i == cameraIndex, j == lightIndex` is a comma
+        expression, i.e. `j == lightIndex` — the same condition, since i + j is fixed."""
+        total = ci + li
+        total_pdf, current = 0.0, 1.0
+        with np.errstate(all="ignore"):
+            for i in range(total + 1):
+                j = total - i
+                pe = np.float64(cp[0].pdf)
+                for x in range(1, i + 1):
+                    pe = pe * (cp[x].pdf * self.g_without_v(cp[x - 1], cp[x]))
+                pl = np.float64(lp[0].pdf)
+                for x in range(1, j + 1):
+                    pl = pl * (lp[x].pdf * self.g_without_v(lp[x - 1], lp[x]))
+                term = pe * pe * pl * pl if self.mis == "power" else pe * pl
+                total_pdf = total_pdf + term
+                if j == li:
+                    current = term
+            return current / np.float64(total_pdf)
+
+    def weighted(self, c, k, cp, lp, ci, li):
+        with np.errstate(all="ignore"):
+            return c / k if self.mis is None else c * self.weight(cp, lp, ci, li)
+
     def contribution(self, cp, lp, ci, li, g):
         if ci == 0 or li == 0:
             return np.zeros(3)
@@ -290,7 +315,7 @@ class Renderer:
             out = out + emissive4.astype(np.float64)
         for i in range(D if nee else 0):
             seed, direct = self.eval_direct(seed, cam[i + 1])
-            c = self.clamp_vec(cam[i].color * direct / (i + 2))
+            c = self.clamp_vec(self.weighted(cam[i].color * direct, i + 2, cam, lig, i + 1, 0))
             out = out + np.append(np.zeros(3) if np.isnan(c).any() else c, 1.0)
         splats = []
         cam_n = norm(self.Wv)
@@ -307,7 +332,7 @@ class Renderer:
                 g = t1 * t2 * inv * inv
                 v = lig[i + 1]
                 f = hm.eval_brdf(self.mat, v.V, norm(self.cam_pos - v.pos), v.N, v.dif, v.spec, v.rough, v.is_spec)
-                c = self.clamp_vec((lig[i].color * f) * g / (i + 2))
+                c = self.clamp_vec(self.weighted((lig[i].color * f) * g, i + 2, cam, lig, 0, i + 1))
                 if target is not None:
                     splats.append((target[0], target[1], np.zeros(3) if np.isnan(c).any() else c))
             i += 1
@@ -322,7 +347,7 @@ class Renderer:
                     length = float(np.linalg.norm(b - a))
                     d = (b - a) / np.float64(length)
                 if connect_all_visible or self.visible(a, d, minT, length):
-                    c = self.clamp_vec(self.contribution(cam, lig, cl, ll, g) / total)
+                    c = self.clamp_vec(self.weighted(self.contribution(cam, lig, cl, ll, g), total, cam, lig, cl, ll))
                     out = np.fmin(np.fmax(out + np.append(np.zeros(3) if np.isnan(c).any() else c, 1.0), 0.0), 1.0)  # saturate
         return out, splats
 

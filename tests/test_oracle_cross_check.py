@@ -71,8 +71,9 @@ def _frame_params(pkg, depth, mat, flags, min_t):
 import pytest
 
 
-@pytest.mark.parametrize("size,depth,mat", [(16, 3, 1), (16, 3, 0), (12, 5, 1), (10, 4, 0)])
-def test_integrator_matches_float64_reading_of_the_raygen_shader(pkg, ob, size, depth, mat):
+@pytest.mark.parametrize("size,depth,mat,mis", [(16, 3, 1, None), (16, 3, 0, None), (12, 5, 1, None), (10, 4, 0, None),
+                                                  (12, 3, 1, "power"), (12, 4, 0, "linear")])
+def test_integrator_matches_float64_reading_of_the_raygen_shader(pkg, ob, size, depth, mat, mis):
     """The whole ray-generation shader (BDPTMain.rt.hlsl:42-234: both walks, NEE, light-tracing splats, vertex
     connections with all its indexing quirks) re-read independently in float64 (tests/hlsl_integrator_numpy.py, own
     brute-force intersection) against the oracle, stage by stage on a small Cornell frame.
@@ -81,9 +82,13 @@ def test_integrator_matches_float64_reading_of_the_raygen_shader(pkg, ob, size, 
     hit point is only known to ~1e-4, so with the default every grazing ray's self-intersection is a coin flip), and
     the ORACLE_CONNECT_ALL_VISIBLE hook (the reference ends connection rays exactly ON the far surface, so that
     surface occludes them or not depending on the last bit).  With those, every pixel, splat target and splat count
-    agrees."""
+    agrees.  The last two cases switch the uniform 1/k for getWeightPower / getWeightLinear (BDPTUtils.hlsli:226-278),
+    which the reference defines but never calls.  (Power at depth 3 only: its pE^2 * pL^2 products of per-vertex
+    pdf * G factors (G ~ 1e-6 in the 555-unit box) leave the fp32 range from depth 4 on, so there the fp32 weights of
+    oracle and HIP path — identical to each other — are not comparable with a float64 evaluation.)"""
     import hlsl_integrator_numpy as hi
     A = pkg.abi
+    mis_flag = {None: 0, "power": A.PARAM_MIS_POWER, "linear": A.PARAM_MIS_LINEAR}[mis]
     scene = pkg.Scene.cornell()
     cam = scene.camera(1.0)
     stages = (("nee", A.PARAM_NO_SPLAT | A.PARAM_NO_CONNECT, dict(splat=False, connect=False), 0),
@@ -91,14 +96,14 @@ def test_integrator_matches_float64_reading_of_the_raygen_shader(pkg, ob, size, 
               ("connect", A.PARAM_NO_NEE | A.PARAM_NO_SPLAT, dict(nee=False, splat=False, connect_all_visible=True),
                ob.ORACLE_CONNECT_ALL_VISIBLE))
     for name, flags, kw, oflags in stages:
-        gp, p = _frame_params(pkg, depth, mat, flags, 0.05)
+        gp, p = _frame_params(pkg, depth, mat, flags | mis_flag, 0.05)
         orc = ob.OracleRender(A, scene.desc, size, size)
         orc.gbuffer(cam, gp)
         orc.bdpt(cam, p, flags=oflags)
         own = orc.image().astype(np.float64)           # own-pixel terms (before the splat fold-in)
         splat = orc.splat.astype(np.float64)
         splat[:, :3] /= 2.0 ** 32
-        R = hi.Renderer(hi.Scene(scene.desc), cam, p, size, size)
+        R = hi.Renderer(hi.Scene(scene.desc), cam, p, size, size, mis=mis)
         img = np.zeros((size, size, 4))
         spl = np.zeros((size * size, 4))
         for y in range(size):

@@ -302,7 +302,7 @@ def main():
             with open(tj) as f:
                 t = json.load(f).get("void bdpt::trace_kernel<2, false>")
             if t:
-                launches_per_frame = 1 + 8  # main launch + lazy rounds
+                launches_per_frame = 1 + 3  # main launch + lazy rounds
                 traffic = int((2.0 * t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) * launches_per_frame)
         dominant = max(stage_ms.items(), key=lambda kv: kv[1])[0] if stage_ms else "connect"
         out = {

@@ -23,7 +23,7 @@ constexpr int kMaxStages = 64;
 // (every cursor is sharded: kNumSubQueues words, each on its own 128-byte line — atomics to one line serialise)
 constexpr size_t kCountBlocks = 2 * BDPT_MAX_DEPTH + 2;  // valid list + one per extension step
 constexpr size_t kHeadBlocks = 2 * BDPT_MAX_DEPTH + 2;
-constexpr size_t kLazyBlocks = kLazyRounds + 2;
+constexpr size_t kLazyBlocks = kMaxLazyRounds + 2;
 constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks + 2) * kCursorBlock;
 }
 
@@ -53,7 +53,7 @@ struct bdpt_ctx {
   int numStages = 0;
   bool evCreated = false;
   // the light walk runs beside the eye walk on this stream (fork/join with events; capture-safe)
-  int lazyRounds = kLazyRounds;
+  int lazyRounds = 3;
   // channels of the built-in primary stage (bdpt_execute with in == NULL), allocated on first use
   bdpt_gbuffer ownGb{};
   // BMFR history (allocated by the first bdpt_bmfr_execute): [2] = ping-pong pair
@@ -477,8 +477,11 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     if ((rc = devAlloc(c, c->frameAllocs, &P.slotRay, (size_t)slots * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.splatPix, (size_t)D * np))) return rc;
     // Lazy rounds: each costs three small launches, so small tiles (multi-GPU bands) take fewer, larger ones.
-    c->lazyRounds = np >= (1u << 20) ? kLazyRounds : (np >= (1u << 18) ? kLazyRounds / 2 : kLazyRounds / 4);
-    const uint32_t batch = (numConnectPairs(D) + (uint32_t)c->lazyRounds - 1) / (uint32_t)c->lazyRounds;
+    // Lazy rounds: each costs three small launches and cannot finish faster than its slowest ray, so there are few:
+    // two or three rounds of kLazyBatchDiv-th shares, the last of which takes every candidate that is left.
+    c->lazyRounds = np >= (1u << 18) ? 3 : 2;
+    // the largest batch any round can ask for: the last round of the front-loaded schedule takes what is left
+    const uint32_t batch = numConnectPairs(D);
     if ((rc = devAlloc(c, c->frameAllocs, &P.misE, (size_t)(D + 1) * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.misL, (size_t)(D + 1) * np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyCursor, np))) return rc;
@@ -584,8 +587,13 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
   const int D = (int)p->maxDepth;
   if (!(p->flags & BDPT_PARAM_NO_CONNECT) && D >= 2) {
     const int nPairs = (int)numConnectPairs((uint32_t)D);
-    const int batch = (nPairs + c->lazyRounds - 1) / c->lazyRounds;
-    for (int r = 0; r < c->lazyRounds; r++) {
+    // Schedule: rounds of ceil(pairs / kLazyBatchDiv) candidates; the last round takes everything that is left.  A launch
+    // cannot finish faster than its slowest ray (~0.1 ms), so once few pixels are pending one big round beats several.
+    const int b0 = (nPairs + kLazyBatchDiv - 1) / kLazyBatchDiv;
+    int left = nPairs;
+    for (int r = 0; r < c->lazyRounds && left > 0; r++) {
+      const int batch = (r + 1 == c->lazyRounds) ? left : (b0 < left ? b0 : left);
+      left -= batch;
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
       HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));

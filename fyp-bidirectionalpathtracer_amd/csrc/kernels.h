@@ -158,10 +158,8 @@ void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint3
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st);
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
                      uint32_t* nextList, uint32_t* nextCount, hipStream_t st);
-#ifndef BDPT_LAZY_ROUNDS
-#define BDPT_LAZY_ROUNDS 8
-#endif
-constexpr int kLazyRounds = BDPT_LAZY_ROUNDS;  // rounds per frame; batch = ceil(pairs / rounds)
+constexpr int kLazyBatchDiv = 8;    // a front round examines ceil(pairs / 8) candidates per pending pixel
+constexpr int kMaxLazyRounds = 8;   // cursor blocks reserved for lazy rounds  // rounds per frame; batch = ceil(pairs / rounds)
 void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
                    hipStream_t st);
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);

@@ -297,7 +297,7 @@ def main():
         # WRITE_SIZE runs of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM — the guide calls
         # the correction uncalibrated for 16-B-per-lane gathers, so read it as an upper estimate).
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1", "e_hbm_traffic_pmc.json")
+        tj = os.path.join(ROOT, "profiles", "r1", "g_hbm_traffic_pmc.json")
         if args.scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(tj):
             with open(tj) as f:
                 t = json.load(f).get("void bdpt::trace_kernel<2, false>")

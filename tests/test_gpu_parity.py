@@ -480,6 +480,41 @@ def test_execute_with_builtin_primary_stage(pkg):
     scene.close()
 
 
+def test_scene_and_size_can_be_replaced(pkg):
+    """initScene / resize happen again when a user loads another scene or resizes the window (BDPTPass.cpp:52-57,
+    RenderingPipeline.cpp:421-471): a context that has rendered something else before gives the same frame as a new one."""
+    import torch
+    cornell, atrium = pkg.Scene.cornell(), pkg.Scene.atrium(6, 9000)
+    fresh = pkg.FramePipeline(atrium, 64, 40, max_depth=4, mat_index=0)
+    fresh.render_frame()
+    torch.cuda.synchronize()
+    ref = fresh.output.clone()
+    fresh.close()
+    used = pkg.FramePipeline(cornell, 48, 48, max_depth=3, mat_index=1)
+    used.render_frame()
+    torch.cuda.synchronize()
+    used.ctx.set_scene(atrium.desc)
+    used.ctx.resize(64, 40, 0, 40, 4)
+    cam = atrium.camera(64 / 40)
+    used.ctx.set_camera(cam)
+    reuse = pkg.FramePipeline.__new__(pkg.FramePipeline)   # same context, new channel tensors of the new size
+    reuse.__dict__.update(used.__dict__)
+    reuse.W, reuse.H, reuse.y0, reuse.y1, reuse.max_depth, reuse.mat_index, reuse.cam = 64, 40, 0, 40, 4, 0, cam
+    reuse.channels = {"WorldPosition": torch.zeros(40, 64, 4, dtype=torch.float32, device=used.dev)}
+    for name in ("WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams", "Emissive"):
+        reuse.channels[name] = torch.zeros(40, 64, 4, dtype=torch.float16, device=used.dev)
+    reuse.channels["PipelineOutput"] = torch.zeros(40, 64, 4, dtype=torch.float32, device=used.dev)
+    reuse.gb = pkg.abi.GBuffer(*[reuse.channels[n].data_ptr() for n in
+                                 ("WorldPosition", "WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams", "Emissive")])
+    reuse.gbuffer_frame, reuse.bdpt_frame = 0xdeadbeef, 0x1337
+    reuse.render_frame()
+    torch.cuda.synchronize()
+    assert torch.equal(reuse.output, ref)
+    used.close()
+    cornell.close()
+    atrium.close()
+
+
 def test_error_conventions(pkg, gpu_ctx):
     scene = pkg.Scene.cornell()
     ctx = pkg.Context(0)

@@ -179,11 +179,15 @@ __global__ __launch_bounds__(256) void bmfr_fit_kernel(BmfrDev A, int horizontal
   for (int s = 0; s < kSub; s++) {
     const int index = s * kLocal + tid;
     const int ux = mirror(bx + index % kBlockEdge, W), uy = mirror(by + index / kBlockEdge, H);
-    const size_t i = (size_t)uy * W + ux;
-    const float4 p = A.curPos[i];
-    const float4 nrm = loadHalf4(A.curNorm, i);
-    const float4 alb = loadHalf4(A.albedo, i);
-    const float4 c = A.prevNoisyW[i];  // the copy of gCurNoisy made just before the dispatch (DenoisePass.cpp:180)
+    // a frame narrower than the block offset is not covered by one reflection: such loads fall outside the
+    // texture and return 0 in D3D
+    const bool inside = ux >= 0 && uy >= 0 && ux < W && uy < H;
+    const size_t i = inside ? (size_t)uy * W + ux : 0;
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 p = inside ? A.curPos[i] : zero;
+    const float4 nrm = inside ? loadHalf4(A.curNorm, i) : zero;
+    const float4 alb = inside ? loadHalf4(A.albedo, i) : zero;
+    const float4 c = inside ? A.prevNoisyW[i] : zero;  // the copy of gCurNoisy made just before the dispatch (DenoisePass.cpp:180)
     tmp[s][0] = 1.0f;
     tmp[s][1] = nrm.x;
     tmp[s][2] = nrm.y;

@@ -194,8 +194,14 @@ static void fitBlock(const oracle_bmfr& B, const bdpt_bmfr_params& P, int group,
     pixelOf(index, ux, uy);
     ux = mirror(ux, W);
     uy = mirror(uy, H);
-    const size_t i = (size_t)uy * W + ux;
     tmp(index, 0) = 1.0f;
+    if (ux < 0 || uy < 0 || ux >= W || uy >= H) {
+      // one reflection is not enough when the frame is narrower than the block offset: the shader then loads
+      // outside the texture, which returns 0 in D3D
+      for (int k = 1; k < kBufferCount; k++) tmp(index, k) = 0.0f;
+      continue;
+    }
+    const size_t i = (size_t)uy * W + ux;
     tmp(index, 1) = curNorm[i * 4];
     tmp(index, 2) = curNorm[i * 4 + 1];
     tmp(index, 3) = curNorm[i * 4 + 2];

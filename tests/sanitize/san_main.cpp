@@ -1,0 +1,122 @@
+// CPU-only sanitizer run (AddressSanitizer + UBSan; GPU sanitizers are not available on the pool): the host-side
+// C++ that never touches the device — scene factories, scene loader, BVH builder — and the oracle, driven the way
+// the tests drive them.  Built and run by tests/test_sanitizers.py.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../fyp-bidirectionalpathtracer_amd/csrc/bvh.h"
+#include "../../include/bdpt.h"
+#include "../../include/bdpt_scene.h"
+#include "../../oracle/bdpt_oracle.h"
+
+static int renderWith(const bdpt_scene_desc& d, const bdpt_camera& cam, uint32_t W, uint32_t H, uint32_t depth, uint32_t mat, uint32_t flags) {
+  oracle_scene* s = oracle_scene_create(&d);
+  if (!s) return 1;
+  const size_t n = (size_t)W * H;
+  std::vector<float> pos(n * 4), nrm(n * 4), dif(n * 4), spec(n * 4), extra(n * 4), emis(n * 4), out(n * 4);
+  std::vector<uint64_t> splat(n * 4);
+  oracle_frame f{};
+  f.width = W;
+  f.height = H;
+  f.y0 = 0;
+  f.y1 = H;
+  f.worldPosition = pos.data();
+  f.worldNormal = nrm.data();
+  f.materialDiffuse = dif.data();
+  f.materialSpecRough = spec.data();
+  f.materialExtra = extra.data();
+  f.emissive = emis.data();
+  f.out = out.data();
+  f.splat = splat.data();
+  bdpt_gbuffer_params gp{};
+  gp.pixelJitter[0] = gp.pixelJitter[1] = 0.5f;
+  gp.focalLen = 1.0f;
+  gp.frameCount = 0xdeadbeefu;
+  gp.envColor[0] = gp.envColor[1] = 0.5f;
+  gp.envColor[2] = 0.8f;
+  gp.envColor[3] = 1.0f;
+  bdpt_params p{};
+  p.minT = 1e-4f;
+  p.frameCount = 0x1337;
+  p.matIndex = mat;
+  p.refractiveIndex = 1.0f;
+  p.maxDepth = depth;
+  p.emitMult = 1.0f;
+  p.clampUpper = 0.9f;
+  p.pixelJitter[0] = p.pixelJitter[1] = 0.5f;
+  p.flags = flags;
+  bdpt_counters cnt{};
+  int rc = oracle_gbuffer(s, &cam, &gp, nullptr, &f, 0, 2);
+  rc |= oracle_bdpt(s, &cam, &p, &f, 0, 2, &cnt);
+  rc |= oracle_resolve(&f);
+  // BMFR on top, three frames, regression on
+  oracle_bmfr* b = oracle_bmfr_create(W, H);
+  for (uint32_t k = 0; k < 3; k++) {
+    bdpt_bmfr_params bp{};
+    bp.frameNumber = k;
+    bp.flags = BDPT_BMFR_PREPROCESS | BDPT_BMFR_REGRESSION | BDPT_BMFR_POSTPROCESS | (k == 2 ? BDPT_BMFR_KEEP_LD_FEATURES | BDPT_BMFR_FULL_FRAME : 0u);
+    for (int i = 0; i < 4; i++) bp.prevViewProj[i * 5] = 1.0f;
+    rc |= oracle_bmfr_execute(b, &bp, pos.data(), nrm.data(), dif.data(), out.data());
+  }
+  oracle_bmfr_destroy(b);
+  oracle_scene_destroy(s);
+  double sum = 0;
+  for (float v : out) sum += v;
+  std::printf("  %ux%u depth %u mat %u: rc=%d rays=%llu sum=%.4f\n", W, H, depth, mat, rc, (unsigned long long)(cnt.raysNee + cnt.raysConnect + cnt.raysSplat), sum);
+  return rc;
+}
+
+int main(int argc, char** argv) {
+  const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+  int rc = 0;
+  for (int which = 0; which < 3; which++) {
+    bdpt_scene* sc = which == 0 ? bdpt_scene_create_cornell() : which == 1 ? bdpt_scene_create_atrium(3, 6000) : bdpt_scene_create_soup(5, 700, 0.2f);
+    bdpt_scene_desc d{};
+    bdpt_camera cam{};
+    rc |= bdpt_scene_get_desc(sc, &d);
+    rc |= bdpt_scene_get_camera(sc, 1.5f, &cam);
+    bdpt::Bvh bvh;
+    bdpt::buildBvh(d.positions, d.indices, d.numTriangles, nullptr, bvh);
+    std::printf("scene %d: %u triangles, %zu nodes, stack %u\n", which, d.numTriangles, bvh.nodes.size(), bvh.maxStack);
+    if (which < 2) {
+      rc |= renderWith(d, cam, 36, 24, 4, 0, 0);
+      rc |= renderWith(d, cam, 24, 16, 8, 1, BDPT_PARAM_MIS_POWER);
+    }
+    bdpt_scene_destroy(sc);
+  }
+  {  // scene loader on a small OBJ + MTL + PPM
+    std::ofstream(tmp + "/san.mtl") << "newmtl a\nKd 0.5 0.6 0.7\nKs 0.1 0.1 0.1\nNs 0.4\nmap_Kd san.ppm\nnewmtl b.DoubleSided\nKe 1 1 1\n";
+    {
+      std::ofstream ppm(tmp + "/san.ppm", std::ios::binary);
+      ppm << "P6\n2 2\n255\n";
+      const unsigned char px[12] = {255, 0, 0, 0, 255, 0, 0, 0, 255, 255, 255, 255};
+      ppm.write(reinterpret_cast<const char*>(px), 12);
+    }
+    std::ofstream(tmp + "/san.obj") << "mtllib san.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3 4/4\n"
+                                      "usemtl b.DoubleSided\nf -1 -4 -3\nusemtl nope\nf 1 5 2\n";
+    std::ofstream(tmp + "/san.fscene") << "{ \"models\": [ { \"file\": \"san.obj\", \"instances\": [ { \"translation\": [1,2,3], \"rotation\": [10,20,30], \"scaling\": [1,2,1] } ] } ],"
+                                         " \"lights\": [ { \"type\": \"point_light\", \"pos\": [0,3,0], \"direction\": [0,-1,0], \"intensity\": [5,5,5], \"opening_angle\": 45.0, \"penumbra_angle\": 3.0 } ],"
+                                         " \"cameras\": [ { \"name\": \"c\", \"pos\": [0,1,5], \"target\": [0,0,0], \"up\": [0,1,0], \"focal_length\": 30.0 } ] }";
+    char msg[256] = {0};
+    bdpt_scene* sc = bdpt_scene_load((tmp + "/san.fscene").c_str(), msg, sizeof(msg));
+    if (!sc) {
+      std::printf("loader failed: %s\n", msg);
+      rc |= 1;
+    } else {
+      bdpt_scene_desc d{};
+      bdpt_camera cam{};
+      bdpt_scene_get_desc(sc, &d);
+      bdpt_scene_get_camera(sc, 1.0f, &cam);
+      std::printf("loaded: %u triangles %u materials %u textures %u lights\n", d.numTriangles, d.numMaterials, d.numTextures, d.numLights);
+      rc |= renderWith(d, cam, 16, 16, 3, 0, 0);
+      bdpt_scene_destroy(sc);
+    }
+    bdpt_scene* bad = bdpt_scene_load((tmp + "/missing.fscene").c_str(), msg, sizeof(msg));
+    if (bad) rc |= 1;
+  }
+  std::printf("sanitizer run finished rc=%d\n", rc);
+  return rc;
+}

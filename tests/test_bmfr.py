@@ -214,3 +214,35 @@ def test_cpp_host_denoise_pass_matches_python_sequence(pkg, tmp_path):
     assert np.array_equal(cpp.view(np.uint32), py.view(np.uint32)), np.abs(cpp - py).max()
     pipe.close()
     scene.close()
+
+
+@pytest.mark.gpu
+def test_bmfr_frame_smaller_than_the_block_offsets(pkg, ob):
+    """A 40x20 frame: block offsets reach -32, one reflection does not bring every load back inside, and the shader
+    would read outside its textures (0 in D3D).  Found by the CPU sanitizer run; both sides now define those loads as 0."""
+    import torch
+    A = pkg.abi
+    scene = pkg.Scene.cornell()
+    W, H = 40, 20
+    pipe = pkg.FramePipeline(scene, W, H, max_depth=3, mat_index=1)
+    orc = ob.OracleRender(A, scene.desc, W, H)
+    den = ob.OracleBmfr(A, W, H)
+    flags = A.BMFR_PREPROCESS | A.BMFR_REGRESSION | A.BMFR_POSTPROCESS | A.BMFR_FULL_FRAME
+    vp = pkg.camera_view_proj((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), (0.0, 1.0, 0.0), 33.6, 24.0, W / H)
+    for k in range(3):
+        gp, p = pipe.render_frame()
+        bp = _params(pkg, k, flags, vp)
+        pipe.ctx.bmfr_execute(bp, pipe.gb, C.c_void_p(pipe.output.data_ptr()), pipe._stream_ptr())
+        torch.cuda.synchronize()
+        orc.gbuffer(pipe.cam, gp)
+        orc.bdpt(pipe.cam, p)
+        orc.resolve()
+        ref = orc.image().reshape(-1, 4).copy()
+        den.execute(bp, orc.chan["worldPosition"], orc.chan["worldNormal"], orc.chan["materialDiffuse"], ref)
+        gpu = pipe.output.cpu().numpy().reshape(-1, 4)
+        same = (gpu.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(gpu) & np.isnan(ref))
+        assert same.all(), f"frame {k}: {(~same).any(axis=1).sum()} pixels differ"
+    den.close()
+    orc.close()
+    pipe.close()
+    scene.close()

@@ -1,0 +1,27 @@
+"""AddressSanitizer + UBSan over the host-side C++ (scene factories, loader, BVH builder) and the oracle, on the CPU —
+the only place sanitizers can run (GPU ASan / XNACK are not available on the pool)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
+    pk = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd")
+    srcs = [os.path.join(ROOT, "tests", "sanitize", "san_main.cpp"),
+            os.path.join(pk, "host", "Scene.cpp"), os.path.join(pk, "host", "Atrium.cpp"), os.path.join(pk, "host", "SceneLoader.cpp"),
+            os.path.join(pk, "csrc", "bvh_build.cpp"),
+            os.path.join(ROOT, "oracle", "bdpt_oracle.cpp"), os.path.join(ROOT, "oracle", "bmfr_oracle.cpp")]
+    exe = str(tmp_path / "san_main")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-o", exe] + srcs + ["-lpthread"]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "sanitizer run finished rc=0" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]

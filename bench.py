@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight on the tiled path (0 = auto: 3 tiled, 1 otherwise)")
     ap.add_argument("--no-pipelined-pass", dest="pipelined_pass", action="store_false",
                     help="skip the informational three-frames-in-flight pass at N=1")
+    ap.add_argument("--dump-frames", type=int, default=0, help="render this many frames from a fresh state, write the "
+                    "accumulated image of all ranks to --dump-path (rank 0) and exit: lets runs with different N be compared")
+    ap.add_argument("--dump-path", default="bench_image.npy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -155,8 +158,16 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # BDPT_BENCH_BACKEND=gloo + BDPT_BENCH_DEVICE=0 rehearse several ranks on a one-GPU box (the exchange then goes
+        # through gloo instead of RCCL; everything else is the N>1 path)
+        backend = os.environ.get("BDPT_BENCH_BACKEND", "nccl")
+        if "BDPT_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["BDPT_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render pass has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -172,6 +183,31 @@ def main():
     step, barrier, rewind = R.step, R.barrier, R.rewind
     info = ctx.bvh_info()
     dev = R.dev
+
+    if args.dump_frames > 0:
+        for _ in range(args.dump_frames):
+            step()
+        barrier()
+        band = R.last_frame[y0:y1].contiguous()
+        if dist is not None:
+            rows = pkg.tiling.band_rows(H, world)
+            gdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # gloo gathers host tensors
+            padded = torch.zeros(rows, W, 4, dtype=torch.float32, device=gdev)
+            padded[: y1 - y0] = band.to(gdev)
+            parts = [torch.zeros_like(padded) for _ in range(world)]
+            dist.all_gather(parts, padded)
+            full = torch.cat(parts, 0)[:H]
+        else:
+            full = band
+        if rank == 0:
+            import numpy as np
+            np.save(args.dump_path, full.cpu().numpy())
+            print(json.dumps({"dumped": args.dump_path, "frames": args.dump_frames, "n_gpus": world, "frames_in_flight": inflight}), flush=True)
+        R.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- untimed: warm-up, then node/triangle visit statistics of the first timed frame (deterministic per frame)
     for _ in range(args.warmup):

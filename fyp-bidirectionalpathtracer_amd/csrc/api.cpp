@@ -665,6 +665,10 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
       ping = 3 - ping;
     }
   }
+  // NEE terms need the eye path only, splat terms the light path only: each generator follows its walk on that
+  // walk's stream and so overlaps the end of the other walk.  (The MIS weights read both paths: sequential then.)
+  const bool mis = (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) != 0;
+  if (!mis) launchGenNee(c->S, F, P, st);
   {
     PathBuf PL = P;
     PL.hitPrim = P.hitPrimL;
@@ -682,12 +686,17 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
       qc++;
       ping = 7 - ping;
     }
+    if (!mis) launchGenSplat(c->S, F, P, c->walkStream);
   }
   HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
   HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
   stageMark(c, st, "walks");
-  if (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) launchMisPrefix(F, P, st);
-  launchGenShadow(c->S, F, P, st);
+  if (mis) {
+    launchMisPrefix(F, P, st);
+    launchGenNee(c->S, F, P, st);
+    launchGenSplat(c->S, F, P, st);
+  }
+  launchGenConnect(c->S, F, P, st);
   stageMark(c, st, "gen_shadow");
   launchTraceShadow(c->S, F, P, c->numCUs, st);
   stageMark(c, st, "trace_shadow");

@@ -152,7 +152,9 @@ void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hip
 void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
                   const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st);
 void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st);
-void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchGenNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchGenSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
+void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st);
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st);
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st);

@@ -1034,26 +1034,31 @@ void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
   hipLaunchKernelGGL(mis_prefix_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P);
 }
-void launchGenShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+// The three generators only share the ray queue (atomic appends), so the host may launch them on different
+// streams: NEE needs the eye path, the splats the light path, the connections both.
+void launchGenNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
   const dim3 g(queueGrid(P)), b(kWave);
-  const bool ggx = F.p.matIndex == 0;
-  if (ggx)
+  if (F.p.matIndex == 0)
     hipLaunchKernelGGL(gen_nee_kernel<true>, g, b, 0, st, S, F, P);
   else
     hipLaunchKernelGGL(gen_nee_kernel<false>, g, b, 0, st, S, F, P);
-  if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
-    if (ggx)
-      hipLaunchKernelGGL(gen_splat_kernel<true>, g, b, 0, st, S, F, P);
-    else
-      hipLaunchKernelGGL(gen_splat_kernel<false>, g, b, 0, st, S, F, P);
-  }
-  if (!(F.p.flags & BDPT_PARAM_NO_CONNECT)) {
-    if (ggx)
-      hipLaunchKernelGGL(gen_connect_kernel<true>, g, b, 0, st, S, F, P);
-    else
-      hipLaunchKernelGGL(gen_connect_kernel<false>, g, b, 0, st, S, F, P);
-  }
+}
+void launchGenSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+  if (!P.Np || (F.p.flags & BDPT_PARAM_NO_SPLAT)) return;
+  const dim3 g(queueGrid(P)), b(kWave);
+  if (F.p.matIndex == 0)
+    hipLaunchKernelGGL(gen_splat_kernel<true>, g, b, 0, st, S, F, P);
+  else
+    hipLaunchKernelGGL(gen_splat_kernel<false>, g, b, 0, st, S, F, P);
+}
+void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
+  if (!P.Np || (F.p.flags & BDPT_PARAM_NO_CONNECT)) return;
+  const dim3 g(queueGrid(P)), b(kWave);
+  if (F.p.matIndex == 0)
+    hipLaunchKernelGGL(gen_connect_kernel<true>, g, b, 0, st, S, F, P);
+  else
+    hipLaunchKernelGGL(gen_connect_kernel<false>, g, b, 0, st, S, F, P);
 }
 
 void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st) {

@@ -24,21 +24,47 @@ sys.path.insert(0, ROOT)
 
 RAY_KEYS = ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; its measured float4 copy rate is 6290 GB/s)
+PROFILE_ROUND = "r2"   # profiles/<round>/hbm_traffic_pmc.json holds the PMC traffic the roofline block quotes
+
+
+def num_connect_pairs(D):
+    """Connection pairs the reference defines for depth D (BDPTMain.rt.hlsl:212-216)."""
+    return sum(min(t, D - 1) for t in range(2, D + 1))
 
 
 def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
-    """SURVEY.md §8(d): B_ray = 32 + nodeBytes*n_int + triBytes*n_tri + O (O = 4 shadow / 20 closest);
-    388 B per closest-hit shade; 200 B per connection pair; 116 B per NEE/splat term; 120 B per pixel-frame."""
-    closest = cnt["raysPrimary"] + cnt["raysEyeExtend"] + cnt["raysLightExtend"]
+    """SURVEY.md §8(d), per frame and per kernel: B_ray = 32 + nodeBytes*n_int + triBytes*n_tri + O (O = 4 shadow /
+    20 closest); 388 B per closest-hit shade; 200 B per connection pair; 116 B per NEE/splat term; 120 B per
+    pixel-frame (56 G-buffer + 16 output + 48 accumulate)."""
+    closest = cnt["raysEyeExtend"] + cnt["raysLightExtend"]
     shadow = cnt["raysNee"] + cnt["raysSplat"] + cnt["raysConnect"]
     b = {}
-    b["closest"] = 52 * closest + node_b * cnt["nodeVisitsClosest"] + tri_b * cnt["triTestsClosest"] + 388 * closest
-    b["nee"] = 116 * cnt["raysNee"]
-    b["splat"] = 116 * cnt["raysSplat"]
-    b["connect_pairs"] = 200 * n_pairs_eval
-    b["shadow_rays"] = 36 * shadow + node_b * cnt["nodeVisitsShadow"] + tri_b * cnt["triTestsShadow"]
-    b["fixed"] = 120 * n_pix_tile
+    # walk_kernel: every extension ray of both walks and the hit/miss shader that follows it
+    b["walk_kernel"] = 52 * closest + node_b * cnt["nodeVisitsClosest"] + tri_b * cnt["triTestsClosest"] + 388 * closest
+    # trace_shadow_kernel: main launch + lazy rounds
+    b["trace_shadow_kernel"] = 36 * shadow + node_b * cnt["nodeVisitsShadow"] + tri_b * cnt["triTestsShadow"]
+    # gen_nee + gen_splat + gen_connect (+ lazy_gen): D NEE and D splat terms and every defined pair per valid pixel
+    b["gen_kernels"] = 116 * cnt["raysNee"] + 116 * cnt["raysSplat"] + 200 * n_pairs_eval
+    # gbuffer (primary ray costed with the closest-hit means) + init_paths + gather + resolve + accumulate
+    b["per_pixel_kernels"] = 120 * n_pix_tile + 32 * n_pix_tile
     return b
+
+
+def load_traffic(scene, W, H, D, world):
+    """HBM-side bytes per frame per kernel from the committed rocprofv3 PMC passes of this very command
+    (separate FETCH_SIZE and WRITE_SIZE runs; profiles/README.md).  FETCH_SIZE is doubled here per
+    MI355X_MICROARCH.md §HBM (gfx950 counts 64-B requests as 32 B; calibrated on accumulate_kernel)."""
+    tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "hbm_traffic_pmc.json")
+    if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(tj)):
+        return {}
+    with open(tj) as f:
+        raw = json.load(f)
+    out = {}
+    for k, v in raw.items():
+        if isinstance(v, dict) and "fetch_bytes_per_frame" in v:
+            name = k.replace("void bdpt::", "").split("<")[0]
+            out[name] = out.get(name, 0) + int(2.0 * v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"])
+    return out
 
 
 class TileRenderer:
@@ -202,7 +228,8 @@ def main():
         if rank == 0:
             import numpy as np
             np.save(args.dump_path, full.cpu().numpy())
-            print(json.dumps({"dumped": args.dump_path, "frames": args.dump_frames, "n_gpus": world, "frames_in_flight": inflight}), flush=True)
+            print(json.dumps({"dumped": args.dump_path, "frames": args.dump_frames, "n_gpus": world, "frames_in_flight": inflight,
+                              "tiled": bool(tiled), "backend": dist.get_backend() if dist is not None else None}), flush=True)
         R.close()
         if dist is not None:
             dist.barrier()
@@ -311,38 +338,52 @@ def main():
     if rank == 0:
         K = args.steps
         mrays = rays_all / elapsed_max / 1e6
-        # roofline of the dominant kernel (connect): algorithmic bytes per launch / mean launch duration
         n_shadow = max(1, stat["raysNee"] + stat["raysSplat"] + stat["raysConnect"])
         n_int_s = stat["nodeVisitsShadow"] / n_shadow
         n_tri_s = stat["triTestsShadow"] / n_shadow
         n_closest = max(1, stat["raysEyeExtend"] + stat["raysLightExtend"])
         n_int_c = stat["nodeVisitsClosest"] / n_closest
         n_tri_c = stat["triTestsClosest"] / n_closest
-        # dominant kernel: the persistent any-hit trace kernel, launched once for the NEE + splat + non-zero
-        # connection rays ("trace_shadow") and once per lazy round ("lazy_trace").  Algorithmic bytes per ray
-        # (SURVEY.md §8d): 32 (ray) + nodeBytes*n_int + triBytes*n_tri + 4 (visibility); n_int / n_tri are the
-        # device-counted means over all any-hit rays of the same frame.
-        shadow_rays_per_frame = (per_stage_rays.get("raysNee", 0) + per_stage_rays.get("raysSplat", 0) +
-                                 per_stage_rays.get("raysConnect", 0)) / stage_frames
-        bytes_per_ray = 36 + info.nodeBytes * n_int_s + info.triBytes * n_tri_s
-        conn_bytes = shadow_rays_per_frame * bytes_per_ray
-        conn_ms = (stage_ms.get("trace_shadow", 0.0) + stage_ms.get("lazy_trace", 0.0)) / stage_frames
-        achieved = conn_bytes / (conn_ms * 1e-3) / 1e9 if conn_ms > 0 else 0.0
-        shadow_rays_per_launch = shadow_rays_per_frame
-        # HBM-side traffic of the same kernel from committed rocprofv3 PMC passes (separate FETCH_SIZE and
-        # WRITE_SIZE runs of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM — the guide calls
-        # the correction uncalibrated for 16-B-per-lane gathers, so read it as an upper estimate).
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1", "g_hbm_traffic_pmc.json")
-        if args.scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(tj):
-            with open(tj) as f:
-                t = json.load(f).get("void bdpt::trace_kernel<2, false>")
-            if t:
-                launches_per_frame = 1 + 3  # main launch + lazy rounds
-                traffic = int((2.0 * t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) * launches_per_frame)
-        dominant = max(stage_ms.items(), key=lambda kv: kv[1])[0] if stage_ms else "connect"
+        # ---- roofline per kernel and for the whole frame.  Algorithmic bytes from the device tallies
+        # of one frame of the same sequence; durations = HIP events on the launch stream around each kernel's launches
+        # (bdpt_get_stage_times), summed over the frame, averaged over the frames named in stage_timing.
+        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), (y1 - y0) * W, info.nodeBytes, info.triBytes)
+        ms = {k: v / stage_frames for k, v in stage_ms.items()}
+        kernel_ms = {
+            "walk_kernel": ms.get("walk", 0.0),
+            "trace_shadow_kernel": ms.get("trace_shadow", 0.0) + ms.get("lazy_trace", 0.0),
+            "gen_kernels": ms.get("gen_shadow", 0.0) + ms.get("lazy_gen", 0.0),
+            "per_pixel_kernels": ms.get("clear", 0.0) + ms.get("init_paths", 0.0) + ms.get("gather", 0.0) +
+                                 ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0),
+        }
+        traffic = load_traffic(args.scene, W, H, D, world)
+        traffic_of = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
+                      "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
+                      "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
+
+        def roof(name):
+            t_ms, by = kernel_ms[name], alg[name]
+            ach = by / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+            tr = sum(traffic.get(k, 0) for k in traffic_of[name]) if traffic else None
+            r = {"ms_per_frame": round(t_ms, 3), "bytes_per_frame": int(by), "achieved": round(ach, 1),
+                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr}
+            if tr:
+                r["traffic_over_algorithmic"] = round(tr / by, 3)
+                # what the counters say: well under the algorithmic bytes reach HBM -> the BVH is served by L2 / MALL and
+                # the kernel is bound by VALU issue under divergence (profiles/README.md: lane utilisation, VALU busy)
+                r["bound"] = "valu" if tr < 0.5 * by else "hbm"
+            return r
+
+        kernels = {k: roof(k) for k in kernel_ms}
+        dominant = max(kernel_ms.items(), key=lambda kv: kv[1])[0]
+        frame_ms = sum(kernel_ms.values())
+        frame_bytes = sum(alg.values())
+        dom = kernels[dominant]
+        closest_per_frame = (per_stage_rays.get("raysEyeExtend", 0) + per_stage_rays.get("raysLightExtend", 0)) / stage_frames
+        shadow_per_frame = (per_stage_rays.get("raysNee", 0) + per_stage_rays.get("raysSplat", 0) +
+                            per_stage_rays.get("raysConnect", 0)) / stage_frames
         out = {
-            "metric": "Mrays/s, BDPT pass, Sponza-class scene 1080p depth 8",
+            "metric": "Mrays/s + RMSE vs the scalar oracle, BDPT pass, Sponza-class scene 1080p depth 8",
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -370,23 +411,36 @@ def main():
                 "pipelined_pass": pipelined,
                 "stage_timing": "HIP events over the timed region" if inflight == 1 else
                                 "HIP events over %d untimed frames run alone on rank 0's band (timed frames overlap)" % stage_frames,
-                "stage_ms_per_step": {k: round(v / stage_frames, 3) for k, v in stage_ms.items()},
-                "stage_mrays": {"walks": round((per_stage_rays.get("raysEyeExtend", 0) + per_stage_rays.get("raysLightExtend", 0))
-                                               / (stage_ms["walks"] * 1e-3) / 1e6, 1)} if stage_ms.get("walks", 0) > 0 else {},
-                "trace_shadow_mrays": round(shadow_rays_per_launch / (conn_ms * 1e-3) / 1e6, 1) if conn_ms > 0 else None,
-                "dominant_stage": dominant,
+                "stage_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
+                "stage_mrays": {"walk_kernel": round(closest_per_frame / (kernel_ms["walk_kernel"] * 1e-3) / 1e6, 1)
+                                if kernel_ms["walk_kernel"] > 0 else None,
+                                "trace_shadow_kernel": round(shadow_per_frame / (kernel_ms["trace_shadow_kernel"] * 1e-3) / 1e6, 1)
+                                if kernel_ms["trace_shadow_kernel"] > 0 else None},
+                "dominant_kernel": dominant,
             },
+            # the kernel with the largest summed duration in the frame; every figure below can be recomputed from
+            # profiles/<round>/ (kernel stats csv for the durations, hbm_traffic_pmc.json for the traffic)
             "roofline": {
-                "kernel": "trace_kernel<2> (persistent any-hit traversal)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": dominant, "bound": dom.get("bound", "hbm"), "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac"], "traffic": dom["traffic"],
                 "peak_achievable_copy": 6290.0,  # float4 copy rate MI355X_MICROARCH.md reports (79 % of spec)
-                "bytes_per_frame": int(conn_bytes), "ms_per_frame": round(conn_ms, 3),
-                "bytes_per_ray": round(bytes_per_ray, 1), "rays_per_frame": int(shadow_rays_per_frame),
-                "note": "all launches of the kernel in a frame (1 main + lazy rounds); bytes are algorithmic, served mostly by L2/MALL",
+                "bytes_per_frame": dom["bytes_per_frame"], "ms_per_frame": dom["ms_per_frame"],
+                "kernels": kernels,
+                "frame": {"ms_per_frame": round(frame_ms, 3), "bytes_per_frame": int(frame_bytes),
+                          "achieved": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 1) if frame_ms > 0 else 0.0,
+                          "frac": round(frame_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms > 0 else 0.0,
+                          "traffic": sum(traffic.values()) if traffic else None},
+                "note": "achieved = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit) / measured time, against HBM peak; "
+                        "traffic = HBM-side bytes from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE).  The BVH of this scene "
+                        "lives in L2/MALL, so traffic << algorithmic bytes for the two traversal kernels: they are bound by "
+                        "VALU issue under lane divergence, not by HBM; frac says how close node/triangle delivery is to what "
+                        "HBM could stream",
             },
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds)
+            base, parity = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds)
+            out["cpu_baseline"] = base
+            out.update(parity)
         print(json.dumps(out), flush=True)
     R.close()
     if dist is not None:
@@ -412,15 +466,19 @@ def effective_cpus():
 
 
 def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s):
-    """The oracle (scalar C++ restatement, kind "port") on this box's host cores, on a band of rows of
-    the same frame in the middle of the image, sized from a short probe to take about budget_s."""
+    """The oracle (scalar C++ restatement, kind "port") on this box's host cores, on a band of rows of the same frame
+    in the middle of the image, sized from a short probe to take about budget_s.  The rows it rendered are then
+    rendered by the HIP path as a tile with the same frame counters and jitter, and compared: `rmse` (linear fp32
+    RGB, the metric's second half) and the fraction of bit-identical pixels."""
+    import numpy as np
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     cores = effective_cpus()
     gp = pipe.gbuffer_params()
     p = pipe.bdpt_params()
 
-    def run(rows):
+    def run(rows, keep=False):
         ya = max(0, H // 2 - rows // 2)
         yb = min(H, ya + rows)
         orc = ob.OracleRender(pkg.abi, scene.desc, W, H, ya, yb)
@@ -429,19 +487,37 @@ def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s):
         cnt = orc.bdpt(pipe.cam, p, threads=cores)
         dt = time.perf_counter() - t0
         rays = cnt.total_rays() + (yb - ya) * W
+        img = None
+        if keep:
+            orc.resolve()
+            img = orc.image()[ya:yb].copy()
         orc.close()
-        return rays, dt, yb - ya
+        return rays, dt, yb - ya, (ya, yb), img
 
-    rays, dt, r = run(max(2, min(H, cores // 4 + 2)))
+    rays, dt, r, band, img = run(max(2, min(H, cores // 4 + 2)), keep=True)
     for _ in range(2):  # the short probe overestimates the rate (thread start-up, sky rows): size twice
         rate = rays / max(dt, 1e-6)
         rows = int(max(r, min(H, budget_s * rate / max(1.0, rays / r))))
         if rows <= r or dt >= 0.6 * budget_s:
             break
-        rays, dt, r = run(rows)
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        rays, dt, r, band, img = run(rows, keep=True)
+    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d middle rows of the same %dx%d depth-%d frame (%d rays, %.1f s); the oracle traces every ray the "
                       "reference issues, incl. zero-contribution ones the GPU path skips" % (r, W, H, D, rays, dt)}
+    # ---- parity leg: the same rows, same counters, through the HIP path
+    ya, yb = band
+    tp = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=pipe.dev.index or 0, tile=(ya, yb))
+    tp.gbuffer_frame, tp.bdpt_frame = pipe.gbuffer_frame, pipe.bdpt_frame
+    tp.render_frame()
+    torch.cuda.synchronize(tp.dev)
+    gpu = tp.output[ya:yb].cpu().numpy()
+    tp.close()
+    d = gpu[..., :3].astype(np.float64) - img[..., :3].astype(np.float64)
+    parity = {"rmse": float(np.sqrt(np.mean(d * d))),
+              "bit_exact_frac": float((gpu.view(np.uint32) == img.view(np.uint32)).all(axis=-1).mean()),
+              "rmse_sample": "rows [%d, %d) of the benchmark frame (1 spp, frame counter 0x%x), HIP tile vs the oracle over the same "
+                             "rows; the oracle is parity-unpinned against the DXR reference (DESIGN.md section 2)" % (ya, yb, p.frameCount)}
+    return base, parity
 
 
 if __name__ == "__main__":

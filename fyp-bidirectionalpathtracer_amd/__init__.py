@@ -45,6 +45,11 @@ class Scene:
         return cls(load_library().bdpt_scene_create_atrium(seed, target_triangles))
 
     @classmethod
+    def courtyard(cls, seed=1, target_triangles=262144, foliage_fraction=0.5):
+        """Atrium + alpha-masked foliage (San Miguel stand-in, BASELINE config 5)."""
+        return cls(load_library().bdpt_scene_create_courtyard(seed, target_triangles, foliage_fraction))
+
+    @classmethod
     def soup(cls, seed, num_triangles, max_edge=0.25):
         return cls(load_library().bdpt_scene_create_soup(seed, num_triangles, max_edge))
 
@@ -134,6 +139,9 @@ class Context:
     def execute_tail(self, params, gbuffer, out_ptr, stream=None):
         self._check(self._lib.bdpt_execute_tail(self._h, C.byref(params), C.byref(gbuffer), out_ptr, stream),
                     "bdpt_execute_tail")
+
+    def prepare(self, what):
+        self._check(self._lib.bdpt_prepare(self._h, int(what)), "bdpt_prepare")
 
     def splat_buffer(self):
         p = C.c_void_p()

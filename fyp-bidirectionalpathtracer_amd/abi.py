@@ -22,6 +22,8 @@ PARAM_MIS_POWER = 64
 PARAM_MIS_LINEAR = 128
 PARAM_DEFER_TAIL = 256
 PARAM_KEEP_COUNTERS = 512
+PREPARE_PRIMARY = 1
+PREPARE_BMFR = 2
 
 
 class Material(C.Structure):
@@ -122,6 +124,7 @@ PROTOTYPES = {
     "bdpt_gbuffer_execute": (C.c_int, [C.c_void_p, C.POINTER(GBufferParams), C.POINTER(GBuffer), C.c_void_p]),
     "bdpt_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_execute_tail": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
+    "bdpt_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bdpt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -140,6 +143,7 @@ PROTOTYPES = {
     "bdpt_test_bsdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "bdpt_scene_create_cornell": (C.c_void_p, []),
     "bdpt_scene_create_atrium": (C.c_void_p, [C.c_uint32, C.c_uint32]),
+    "bdpt_scene_create_courtyard": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
     "bdpt_scene_create_soup": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
     "bdpt_scene_load": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_uint32]),
     "bdpt_scene_destroy": (None, [C.c_void_p]),

@@ -1,7 +1,12 @@
 // api.cpp — the C ABI of include/bdpt.h: context, scene upload + BVH build, per-tile path
-// buffers, stage launches.  Nothing here allocates or synchronises inside bdpt_execute /
-// bdpt_gbuffer_execute (workspaces are sized by bdpt_set_scene / bdpt_resize), so both can be
-// captured into a hipGraph by the caller.
+// buffers, stage launches.  Workspaces are sized by bdpt_set_scene / bdpt_resize / bdpt_prepare, so
+// bdpt_gbuffer_execute, bdpt_execute and bdpt_bmfr_execute neither allocate nor synchronise and can be
+// captured into a hipGraph.  The one exception is spelled out in bdpt.h: bdpt_execute(in = NULL) and
+// bdpt_bmfr_execute allocate their optional buffers on first use when bdpt_prepare was not called, and
+// refuse (BDPT_E_STATE) to do so while the stream is being captured.
+// Every entry point that launches or allocates makes the context's device current first, so one host
+// thread may drive contexts on several GPUs; per-context launch state (persistent grid sizes, counters
+// read-back) lives in bdpt_ctx, never in statics.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -21,8 +26,8 @@ namespace {
 constexpr int kMaxStages = 64;
 // path-queue counters, their fetch cursors, then the shadow sub-queue counters and cursors
 // (every cursor is sharded: kNumSubQueues words, each on its own 128-byte line — atomics to one line serialise)
-constexpr size_t kCountBlocks = 2 * BDPT_MAX_DEPTH + 2;  // valid list + one per extension step
-constexpr size_t kHeadBlocks = 2 * BDPT_MAX_DEPTH + 2;
+constexpr size_t kCountBlocks = 1;  // lengths of the valid-pixel lists
+constexpr size_t kHeadBlocks = 2;   // fetch cursors of the walk kernel: pixel list x {eye, light}
 constexpr size_t kLazyBlocks = kMaxLazyRounds + 2;
 constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks + 2) * kCursorBlock;
 }
@@ -52,11 +57,11 @@ struct bdpt_ctx {
   const char* stageNames[kMaxStages]{};
   int numStages = 0;
   bool evCreated = false;
-  // the light walk runs beside the eye walk on this stream (fork/join with events; capture-safe)
   int lazyRounds = 3;
-  // channels of the built-in primary stage (bdpt_execute with in == NULL), allocated on first use
+  LaunchGrids grids{};  // persistent-grid sizes for this context's device
+  // channels of the built-in primary stage (bdpt_execute with in == NULL): bdpt_prepare or first use
   bdpt_gbuffer ownGb{};
-  // BMFR history (allocated by the first bdpt_bmfr_execute): [2] = ping-pong pair
+  // BMFR history (bdpt_prepare or the first bdpt_bmfr_execute): [2] = ping-pong pair
   float4* bmfrPos[2] = {nullptr, nullptr};
   float4* bmfrNorm[2] = {nullptr, nullptr};
   float4* bmfrNoisy[2] = {nullptr, nullptr};
@@ -64,6 +69,7 @@ struct bdpt_ctx {
   uint8_t* bmfrAccept = nullptr;
   uint32_t* bmfrPrevPixel = nullptr;
   int bmfrRead = 0;  // which half holds the previous frame
+  // the splat and NEE generators run beside the connection generator on this stream (fork/join with events; capture-safe)
   hipStream_t walkStream = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
@@ -108,6 +114,69 @@ int devUpload(bdpt_ctx* c, std::vector<void*>& pool, const T** out, const T* hos
 void freePool(std::vector<void*>& pool) {
   for (void* p : pool) (void)hipFree(p);
   pool.clear();
+}
+
+// Every entry point that launches or allocates starts here: the context's device becomes current, so one
+// host thread can hold contexts on several GPUs.
+#define ENTER(ctx) HIPCHK(ctx, hipSetDevice((ctx)->device))
+
+bool streamIsCapturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) return false;
+  return cs != hipStreamCaptureStatusNone;
+}
+
+// the six channels of the built-in primary stage; all or nothing
+int allocOwnGbuffer(bdpt_ctx* c) {
+  if (c->ownGb.worldPosition) return BDPT_OK;
+  const size_t n = (size_t)c->W * c->H;
+  const size_t mark = c->frameAllocs.size();
+  bdpt_gbuffer g{};
+  int rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &g.worldPosition, n * 4)) || (rc = devAlloc(c, c->frameAllocs, &g.worldNormal, n * 4)) ||
+      (rc = devAlloc(c, c->frameAllocs, &g.materialDiffuse, n * 4)) || (rc = devAlloc(c, c->frameAllocs, &g.materialSpecRough, n * 4)) ||
+      (rc = devAlloc(c, c->frameAllocs, &g.materialExtraParams, n * 4)) || (rc = devAlloc(c, c->frameAllocs, &g.emissive, n * 4))) {
+    while (c->frameAllocs.size() > mark) {
+      (void)hipFree(c->frameAllocs.back());
+      c->frameAllocs.pop_back();
+    }
+    return rc;
+  }
+  c->ownGb = g;
+  return BDPT_OK;
+}
+
+int allocBmfrHistory(bdpt_ctx* c) {
+  if (c->bmfrAccept) return BDPT_OK;
+  const size_t n = (size_t)c->W * c->H;
+  const size_t mark = c->frameAllocs.size();
+  float4 *pos[2]{}, *norm[2]{}, *noisy[2]{}, *filt[2]{};
+  uint8_t* accept = nullptr;
+  uint32_t* prevPixel = nullptr;
+  int rc = BDPT_OK;
+  for (int k = 0; k < 2 && !rc; k++) {
+    if ((rc = devAlloc(c, c->frameAllocs, &pos[k], n)) || (rc = devAlloc(c, c->frameAllocs, &norm[k], n)) ||
+        (rc = devAlloc(c, c->frameAllocs, &noisy[k], n)) || (rc = devAlloc(c, c->frameAllocs, &filt[k], n)))
+      break;
+  }
+  if (!rc) rc = devAlloc(c, c->frameAllocs, &accept, n);
+  if (!rc) rc = devAlloc(c, c->frameAllocs, &prevPixel, n);
+  if (rc) {
+    while (c->frameAllocs.size() > mark) {
+      (void)hipFree(c->frameAllocs.back());
+      c->frameAllocs.pop_back();
+    }
+    return rc;
+  }
+  for (int k = 0; k < 2; k++) {
+    c->bmfrPos[k] = pos[k];
+    c->bmfrNorm[k] = norm[k];
+    c->bmfrNoisy[k] = noisy[k];
+    c->bmfrFiltered[k] = filt[k];
+  }
+  c->bmfrAccept = accept;
+  c->bmfrPrevPixel = prevPixel;
+  return bdpt_bmfr_reset(c);
 }
 
 void stageMark(bdpt_ctx* c, hipStream_t st, const char* name) {
@@ -191,7 +260,7 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
     const bdpt_material& mm = d->materials[m];
     const int ids[4] = {mm.texBaseColor, mm.texSpecular, mm.texEmissive, mm.texNormal};
     for (int id : ids)
-      if (id >= (int)d->numTextures) {
+      if (id < -1 || id >= (int)d->numTextures) {
         fail(c, "scene: material texture index out of range");
         return BDPT_E_INVALID;
       }
@@ -416,6 +485,10 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     fail(c, "resize: frame too large");
     return BDPT_E_LIMIT;
   }
+  if ((uint64_t)(tile.y1 - tile.y0) * width >= (1ull << 24)) {
+    fail(c, "resize: a tile holds at most 2^24 - 1 pixels (path ids pack the pixel in 24 bits); render in smaller tiles");
+    return BDPT_E_LIMIT;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
   freePool(c->frameAllocs);
@@ -433,8 +506,9 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   P.D1 = std::max<uint32_t>(maxDepth, 1) + 1;
   const size_t np = std::max<uint32_t>(P.Np, 1);
   int rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.v, (size_t)2 * P.D1 * NF * np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.v, (size_t)2 * P.D1 * NF4 * 4 * np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.rayDir, (size_t)6 * np))) return rc;
+  if ((rc = devAlloc(c, c->frameAllocs, &P.seedE, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.seedL, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.eyeLast, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightLast, np))) return rc;
@@ -442,21 +516,13 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   // a path queue = kNumSubQueues lists; workgroup b appends to list b % kNumSubQueues
   P.pathSubCap = (uint32_t)((((np + kWave - 1) / kWave + kNumSubQueues - 1) / kNumSubQueues) * kWave);
   const size_t qcap = (size_t)P.pathSubCap * kNumSubQueues;
-  for (int q = 0; q < 5; q++)
+  for (int q = 0; q < 3; q++)
     if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], qcap))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.qcount, (size_t)kCursorWords))) return rc;
   P.qhead = P.qcount + kCountBlocks * kCursorBlock;
   P.lazyCount = P.qhead + kHeadBlocks * kCursorBlock;
   P.rayCount = P.lazyCount + kLazyBlocks * kCursorBlock;
   P.rayHead = P.rayCount + kCursorBlock;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrim, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitT, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitU, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitV, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitPrimL, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitTL, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitUL, qcap))) return rc;
-  if ((rc = devAlloc(c, c->frameAllocs, &P.hitVL, qcap))) return rc;
   {
     // one shadow ray per NEE term, per splat term and per defined connection pair, at most
     const uint32_t D = std::max<uint32_t>(maxDepth, 1);
@@ -512,6 +578,7 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
     fail(c, "gbuffer_execute: all six channels are required");
     return BDPT_E_INVALID;
   }
+  ENTER(c);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   GBufferDev G{};
   G.cam = c->cam;
@@ -530,22 +597,20 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
 
 namespace {
 // argument checks shared by bdpt_execute and bdpt_execute_tail, and the per-frame constants the kernels take
-int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, FrameDev& F) {
+int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, hipStream_t st, FrameDev& F) {
   if (!c || !p || !out) return BDPT_E_INVALID;
+  ENTER(c);
   if (!in) {  // the context's own channels: the primary stage runs inside bdpt_execute
     if (!c->haveSize) {
       fail(c, "execute: scene, camera and size must be set first");
       return BDPT_E_STATE;
     }
-    if (!c->ownGb.worldPosition) {
-      const size_t n = (size_t)c->W * c->H;
-      int rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.worldPosition, n * 4))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.worldNormal, n * 4))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.materialDiffuse, n * 4))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.materialSpecRough, n * 4))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.materialExtraParams, n * 4))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->ownGb.emissive, n * 4))) return rc;
+    if (!c->ownGb.worldPosition) {  // bdpt_prepare(BDPT_PREPARE_PRIMARY) was not called: allocate now, unless capturing
+      if (streamIsCapturing(st)) {
+        fail(c, "execute: the built-in primary stage needs bdpt_prepare(BDPT_PREPARE_PRIMARY) before stream capture");
+        return BDPT_E_STATE;
+      }
+      if (int rc = allocOwnGbuffer(c)) return rc;
     }
     in = &c->ownGb;
   }
@@ -599,7 +664,7 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
       HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));
       launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
       stageMark(c, st, "lazy_gen");
-      launchTraceShadow(c->S, F, P, c->numCUs, st);
+      launchTraceShadow(c->S, F, P, c->grids, c->numCUs, st);
       stageMark(c, st, "lazy_trace");
       launchLazyCheck(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, next, P.lazyCount + (size_t)(r + 1) * kCursorBlock, st);
     }
@@ -617,8 +682,8 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
 
 int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream) {
   FrameDev F;
-  if (int rc = frameSetup(c, p, in, out, F)) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = frameSetup(c, p, in, out, st, F)) return rc;
   const PathBuf& P = c->P;
   if (!in) {
     // Built-in primary stage: pinhole camera, this frame's jitter and counter, the default constant
@@ -633,7 +698,6 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     gp.envColor[3] = 1.0f;
     if (int rc = bdpt_gbuffer_execute(c, &gp, &c->ownGb, stream)) return rc;
   }
-  const int D = (int)p->maxDepth;
 
   c->numStages = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
@@ -645,60 +709,30 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   launchInitPaths(c->S, F, P, st);
   stageMark(c, st, "init_paths");
 
-  // The two walks are independent until the connection stage, so the light walk (vertices 1..D,
-  // BDPTMain.rt.hlsl:138-145) runs on the context's second stream beside the eye walk (vertices 2..D,
-  // :106-112): the HBM-bound shade launches of one overlap the VALU-bound traversal of the other and
-  // the persistent kernels' tails fill each other.  Separate ping-pong queues and hit records.
-  HIPCHK(c, hipEventRecord(c->evFork, st));
-  HIPCHK(c, hipStreamWaitEvent(c->walkStream, c->evFork, 0));
-  int qc = 1;  // next free cursor block
-  {
-    const uint32_t* qin = P.queue[0];
-    const uint32_t* cin = P.qcount;
-    int ping = 1;
-    for (int k = 1; k <= D - 1; k++) {
-      launchExtend(c->S, F, P, PATH_EYE, k, D, qin, cin, P.qhead + (size_t)qc * kCursorBlock, P.queue[ping],
-                   P.qcount + (size_t)qc * kCursorBlock, c->numCUs, st);
-      qin = P.queue[ping];
-      cin = P.qcount + (size_t)qc * kCursorBlock;
-      qc++;
-      ping = 3 - ping;
-    }
-  }
-  // NEE terms need the eye path only, splat terms the light path only: each generator follows its walk on that
-  // walk's stream and so overlaps the end of the other walk.  (The MIS weights read both paths: sequential then.)
+  // Both walks (eye vertices 2..D, BDPTMain.rt.hlsl:106-112; light vertices 1..D, :138-145) in one persistent
+  // launch: traversal and hit/miss shading alternate inside the kernel, lanes re-arm themselves per bounce.
+  launchWalk(c->S, F, P, c->grids, c->numCUs, st);
+  stageMark(c, st, "walk");
+
+  // The three generators only share the ray queue (atomic appends): the connection generator (the long one)
+  // stays on the caller's stream, NEE and splat terms are generated beside it on the context's second stream.
   const bool mis = (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) != 0;
-  if (!mis) launchGenNee(c->S, F, P, st);
-  {
-    PathBuf PL = P;
-    PL.hitPrim = P.hitPrimL;
-    PL.hitT = P.hitTL;
-    PL.hitU = P.hitUL;
-    PL.hitV = P.hitVL;
-    const uint32_t* qin = P.queue[0];
-    const uint32_t* cin = P.qcount;
-    int ping = 3;
-    for (int k = 0; k <= D - 1; k++) {
-      launchExtend(c->S, F, PL, PATH_LIGHT, k, D, qin, cin, P.qhead + (size_t)qc * kCursorBlock, P.queue[ping],
-                   P.qcount + (size_t)qc * kCursorBlock, c->numCUs, c->walkStream);
-      qin = P.queue[ping];
-      cin = P.qcount + (size_t)qc * kCursorBlock;
-      qc++;
-      ping = 7 - ping;
-    }
-    if (!mis) launchGenSplat(c->S, F, P, c->walkStream);
-  }
-  HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
-  HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
-  stageMark(c, st, "walks");
   if (mis) {
     launchMisPrefix(F, P, st);
     launchGenNee(c->S, F, P, st);
     launchGenSplat(c->S, F, P, st);
+    launchGenConnect(c->S, F, P, st);
+  } else {
+    HIPCHK(c, hipEventRecord(c->evFork, st));
+    HIPCHK(c, hipStreamWaitEvent(c->walkStream, c->evFork, 0));
+    launchGenNee(c->S, F, P, c->walkStream);
+    launchGenSplat(c->S, F, P, c->walkStream);
+    launchGenConnect(c->S, F, P, st);
+    HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
+    HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
   }
-  launchGenConnect(c->S, F, P, st);
   stageMark(c, st, "gen_shadow");
-  launchTraceShadow(c->S, F, P, c->numCUs, st);
+  launchTraceShadow(c->S, F, P, c->grids, c->numCUs, st);
   stageMark(c, st, "trace_shadow");
   launchGather(F, P, P.queue[1], P.lazyCount, st);
   stageMark(c, st, "gather");
@@ -714,8 +748,29 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
 
 int bdpt_execute_tail(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream) {
   FrameDev F;
-  if (int rc = frameSetup(c, p, in, out, F)) return rc;
-  return connectionTail(c, F, reinterpret_cast<hipStream_t>(stream));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = frameSetup(c, p, in, out, st, F)) return rc;
+  return connectionTail(c, F, st);
+}
+
+// Allocate the optional buffers up front so that no later execute allocates (hipGraph capture, latency).
+int bdpt_prepare(bdpt_ctx* c, uint32_t what) {
+  if (!c) return BDPT_E_INVALID;
+  if (!c->haveSize) {
+    fail(c, "prepare: bdpt_resize must be called first");
+    return BDPT_E_STATE;
+  }
+  ENTER(c);
+  if (what & BDPT_PREPARE_PRIMARY)
+    if (int rc = allocOwnGbuffer(c)) return rc;
+  if (what & BDPT_PREPARE_BMFR) {
+    if (c->tile.y0 != 0 || c->tile.y1 != c->H) {
+      fail(c, "prepare: the denoiser works on the whole frame; this context renders a band");
+      return BDPT_E_STATE;
+    }
+    if (int rc = allocBmfrHistory(c)) return rc;
+  }
+  return BDPT_OK;
 }
 
 // BlockwiseMultiOrderFeatureRegression::execute (DenoisePass.cpp:146-204)
@@ -733,19 +788,15 @@ int bdpt_bmfr_execute(bdpt_ctx* c, const bdpt_bmfr_params* p, const bdpt_gbuffer
     fail(c, "bmfr: WorldPosition, WorldNormal and MaterialDiffuse are required");
     return BDPT_E_INVALID;
   }
+  ENTER(c);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t n = (size_t)c->W * c->H;
-  if (!c->bmfrAccept) {
-    int rc;
-    for (int k = 0; k < 2; k++) {
-      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrPos[k], n))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrNorm[k], n))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrNoisy[k], n))) return rc;
-      if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrFiltered[k], n))) return rc;
+  if (!c->bmfrAccept) {  // bdpt_prepare(BDPT_PREPARE_BMFR) was not called: allocate now, unless capturing
+    if (streamIsCapturing(st)) {
+      fail(c, "bmfr: the history needs bdpt_prepare(BDPT_PREPARE_BMFR) before stream capture");
+      return BDPT_E_STATE;
     }
-    if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrAccept, n))) return rc;
-    if ((rc = devAlloc(c, c->frameAllocs, &c->bmfrPrevPixel, n))) return rc;
-    if ((rc = bdpt_bmfr_reset(c))) return rc;
+    if (int rc = allocBmfrHistory(c)) return rc;
   }
   BmfrDev A{};
   A.W = c->W;
@@ -781,6 +832,7 @@ int bdpt_bmfr_execute(bdpt_ctx* c, const bdpt_bmfr_params* p, const bdpt_gbuffer
 int bdpt_bmfr_reset(bdpt_ctx* c) {
   if (!c) return BDPT_E_INVALID;
   if (!c->bmfrAccept) return BDPT_OK;  // nothing allocated yet
+  ENTER(c);
   const size_t n = (size_t)c->W * c->H;
   for (int k = 0; k < 2; k++) {
     HIPCHK(c, hipMemset(c->bmfrPos[k], 0, n * sizeof(float4)));
@@ -824,6 +876,7 @@ int bdpt_resolve(bdpt_ctx* c, const uint64_t* splat, uint32_t splat_row0, float*
     fail(c, "resolve: splat buffer does not cover the tile");
     return BDPT_E_INVALID;
   }
+  ENTER(c);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   launchResolve(reinterpret_cast<const unsigned long long*>(splat), splat_row0, out, c->W, c->tile.y0, c->tile.y1, st);
   HIPCHK(c, hipGetLastError());
@@ -833,6 +886,7 @@ int bdpt_resolve(bdpt_ctx* c, const uint64_t* splat, uint32_t splat_row0, float*
 int bdpt_accumulate(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount,
                     uint64_t numTexels, void* stream) {
   if (!c || !lastFrame || !curFrame) return BDPT_E_INVALID;
+  ENTER(c);
   launchAccumulate(lastFrame, curFrame, accumCount, maxAccumCount, numTexels, reinterpret_cast<hipStream_t>(stream));
   HIPCHK(c, hipGetLastError());
   return BDPT_OK;
@@ -841,8 +895,9 @@ int bdpt_accumulate(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_t acc
 int bdpt_get_counters(bdpt_ctx* c, bdpt_counters* out) {
   if (!c || !out) return BDPT_E_INVALID;
   if (!c->haveSize) return BDPT_E_STATE;
+  ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->lastStream));
-  static DevCounters h;
+  DevCounters h;
   HIPCHK(c, hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
   static_assert(sizeof(bdpt_counters) == 13 * sizeof(uint64_t), "counter fields");
   uint64_t* o = reinterpret_cast<uint64_t*>(out);
@@ -863,6 +918,7 @@ int bdpt_enable_stage_timing(bdpt_ctx* c, int enable) {
 int bdpt_get_stage_times(bdpt_ctx* c, const char** names, float* ms, int cap) {
   if (!c || !names || !ms) return BDPT_E_INVALID;
   if (!c->timing || c->numStages == 0) return 0;
+  ENTER(c);
   HIPCHK(c, hipEventSynchronize(c->ev[c->numStages]));
   int n = std::min(cap, c->numStages);
   for (int i = 0; i < n; i++) {
@@ -876,6 +932,7 @@ int bdpt_get_stage_times(bdpt_ctx* c, const char** names, float* ms, int cap) {
 
 int bdpt_sync(bdpt_ctx* c, void* stream) {
   if (!c) return BDPT_E_INVALID;
+  ENTER(c);
   HIPCHK(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
   return BDPT_OK;
 }
@@ -884,6 +941,7 @@ int bdpt_sync(bdpt_ctx* c, void* stream) {
 int bdpt_test_rng(bdpt_ctx* c, const uint32_t* val0, const uint32_t* val1, uint32_t n, uint32_t draws, uint32_t* out_states,
                   float* out_floats) {
   if (!c || !val0 || !val1 || !out_states || !out_floats) return BDPT_E_INVALID;
+  ENTER(c);
   std::vector<void*> pool;
   const uint32_t *d0, *d1;
   uint32_t* ds;
@@ -909,6 +967,7 @@ int bdpt_test_rng(bdpt_ctx* c, const uint32_t* val0, const uint32_t* val1, uint3
 int bdpt_test_trace(bdpt_ctx* c, const float* rays, uint32_t n, int mode, int32_t* out_prim, float* out_tuv) {
   if (!c || !rays || !out_prim || !out_tuv || mode < 0 || mode > 2) return BDPT_E_INVALID;
   if (!c->haveScene) return BDPT_E_STATE;
+  ENTER(c);
   std::vector<void*> pool;
   const float* dr;
   int32_t* dp;
@@ -933,6 +992,7 @@ int bdpt_test_trace(bdpt_ctx* c, const float* rays, uint32_t n, int mode, int32_
 
 int bdpt_test_bsdf(bdpt_ctx* c, const float* in, uint32_t n, uint32_t matIndex, float* out) {
   if (!c || !in || !out) return BDPT_E_INVALID;
+  ENTER(c);
   std::vector<void*> pool;
   const float* di;
   float* dout;

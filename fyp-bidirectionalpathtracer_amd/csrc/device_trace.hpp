@@ -1,5 +1,5 @@
 // device_trace.hpp — BVH traversal for gfx950: per-lane LDS stack, while-while loop structure,
-// and the persistent trace kernel whose idle lanes are refilled from a ray queue.
+// and the persistent any-hit trace kernel whose idle lanes are refilled from a ray queue.
 //
 // Replaces DXR TraceRay (BDPT/globalIlluminationRay.hlsli:11, BDPT/standardShadowRay.hlsli:20-22,
 // CP lightProbeGBuffer.rt.hlsl:151-158) — fixed-function in the reference's driver.
@@ -240,33 +240,16 @@ struct RayQueue {         // SoA planes, stride = cap: ox oy oz dx dy dz tmax
   const float* rays;
   uint32_t cap;           // plane stride
   uint32_t subCap;        // capacity of one sub-queue (ray id = q*subCap + offset)
-  uint32_t numSub;        // number of sub-queues (1 for the closest-hit path queues)
+  uint32_t numSub;        // number of sub-queues
   const uint32_t* count;  // [numSub] queued rays (device counters written by the producer)
   uint32_t* head;         // [numSub] next unfetched offset
 };
 
-struct ShadowOut {
-  uint8_t* vis;  // 1 = unoccluded, by ray id
-};
-struct ClosestOut {  // by ray id
-  int* prim;
-  float* t;
-  float* u;
-  float* v;
-};
-// Closest-hit rays are read through an indirection: ray id i -> path p = qin[i]; origin = vertex
-// plane, direction = rayDir plane.
-struct ClosestIn {
-  const uint32_t* qin;
-  const float* pos;  // 3 planes, stride Np
-  const float* dir;  // 3 planes, stride Np
-  uint32_t Np;
-  float tmin;
-};
-
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, ClosestIn CI, ShadowOut SO, ClosestOut CO,
-                                                      DevCounters* counters, float shadowTmin) {
+// Any-hit rays (NEE, splat, connection, lazy rounds): visibility byte by ray id, 1 = unoccluded.
+// (Closest-hit rays of the walks never pass through a queue: kernels.hip walk_kernel.)
+template <bool COUNT>
+__global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
+                                                             float shadowTmin) {
   __shared__ int s_stack[kStackEntries * kWave];
   int* stk = s_stack + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63u);
@@ -287,7 +270,7 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
         uint32_t base = nq;
         if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
           // rays per atomic: up to kFetchChunk, but no more than this list's fair share per wave, so
-          // that short queues (late bounces, lazy rounds) still spread over every resident wave
+          // that short queues (lazy rounds) still spread over every resident wave
           uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
           chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
           if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], chunk);
@@ -309,16 +292,9 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
         if (!has && rank < take) {
           const uint32_t idx = q * Q.subCap + chunkPos + rank;
           rid = idx;
-          if (MODE == 2) {
-            const float* r = Q.rays + idx;
-            const size_t c = Q.cap;
-            travInit(T, mk(r[0], r[c], r[2 * c]), mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
-          } else {
-            const uint32_t p = CI.qin[idx];
-            const size_t np = CI.Np;
-            travInit(T, mk(CI.pos[p], CI.pos[np + p], CI.pos[2 * np + p]), mk(CI.dir[p], CI.dir[np + p], CI.dir[2 * np + p]),
-                     CI.tmin, 1.0e38f);
-          }
+          const float* r = Q.rays + idx;
+          const size_t c = Q.cap;
+          travInit(T, mk(r[0], r[c], r[2 * c]), mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
           has = true;
         }
         chunkPos += take;
@@ -333,33 +309,26 @@ __global__ __launch_bounds__(kWave) void trace_kernel(SceneDev S, RayQueue Q, Cl
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<(MODE != 2) || BDPT_ORDERED_ANYHIT>(S, T, stk);
+        nodeStep<BDPT_ORDERED_ANYHIT != 0>(S, T, stk);
       }
       bool finished = (T.cur == kDone);
       if (!finished) {
-        finished = leafStep<MODE, COUNT>(S, T, nTris);
+        finished = leafStep<2, COUNT>(S, T, nTris);
         if (!finished) {
           T.cur = travPop(T, stk);
           finished = (T.cur == kDone);
         }
       }
       if (finished) {
-        if (MODE == 2) {
-          SO.vis[rid] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
-        } else {
-          CO.prim[rid] = T.best.prim;
-          CO.t[rid] = T.best.t;
-          CO.u[rid] = T.best.u;
-          CO.v[rid] = T.best.v;
-        }
+        vis[rid] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
         has = false;
         T.cur = kDone;
       }
     }
   }
   if (COUNT) {
-    waveAddCount(counters, MODE == 2 ? C_NODE_SHADOW : C_NODE_CLOSEST, nNodes);
-    waveAddCount(counters, MODE == 2 ? C_TRI_SHADOW : C_TRI_CLOSEST, nTris);
+    waveAddCount(counters, C_NODE_SHADOW, nNodes);
+    waveAddCount(counters, C_TRI_SHADOW, nTris);
   }
 }
 

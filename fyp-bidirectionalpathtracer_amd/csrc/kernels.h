@@ -29,6 +29,7 @@ constexpr uint32_t kCounterShards = 64;
 // Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45).  pdfForward is only read by the
 // MIS weights (BDPT_PARAM_MIS_*), which the reference defines but never calls.
 enum : int { F_COL = 0, F_POS = 3, F_N = 6, F_V = 9, F_DIF = 12, F_SPEC = 15, F_ROUGH = 18, F_ISSPEC = 19, F_PDF = 20, NF = 21 };
+constexpr int NF4 = 6;  // float4s per stored vertex record (96 B; layout in kernels.hip "Path vertices")
 enum : int { PATH_EYE = 0, PATH_LIGHT = 1 };
 
 struct TexDev {
@@ -72,26 +73,18 @@ inline __host__ __device__ uint32_t numConnectPairs(uint32_t D) {
 
 // Per-tile path state, SoA by tile-local pixel index p in [0, Np).
 struct PathBuf {
-  float* v;            // vertex planes: ((path*D1 + k)*NF + field)*Np + p
+  float* v;            // vertex records: ((path*D1 + k)*Np + p) * NF4 float4s
   float* rayDir;       // planes: (path*3 + axis)*Np + p
+  uint32_t* seedE;     // RNG state the eye walk draws from at every bounce (initRand of the pixel, quirk 1)
   uint32_t* seedL;     // RNG state after sampleLight
   uint8_t* eyeLast;    // last stored eye vertex (ghost included); 0 = pixel has no geometry
   uint8_t* lightLast;  // last stored light vertex (ghost included)
   uint8_t* lightReal;  // number of light vertices produced by hits (takeContribution, BDPTMain.rt.hlsl:144)
-  uint32_t* queue[5];  // sharded path queues (kernels.hip "Path queues"): [0] valid pixels; [1],[2] eye ping-pong; [3],[4] light
+  uint32_t* queue[3];  // sharded pixel queues (kernels.hip "Path queues"): [0] valid pixels; [1],[2] lazy-round ping-pong
   uint32_t pathSubCap; // capacity of one list of a path queue (multiple of 64)
   // cursor blocks: each is kNumSubQueues cursors, one per 128-byte line (kCursorBlock words)
-  uint32_t* qcount;    // block 0 = valid-pixel list lengths; block 1+s = lengths after extension step s
-  uint32_t* qhead;     // block s = fetch cursors of the persistent trace of extension step s
-  // closest-hit records by queue position (the light walk runs on its own stream with the second set)
-  int* hitPrim;
-  float* hitT;
-  float* hitU;
-  float* hitV;
-  int* hitPrimL;
-  float* hitTL;
-  float* hitUL;
-  float* hitVL;
+  uint32_t* qcount;    // block 0 = valid-pixel list lengths
+  uint32_t* qhead;     // blocks 0-1 = fetch cursors of the walk kernel (one per virtual list: pixel list x path)
   // shadow-ray queue (NEE + splat + connection rays of one frame)
   float* rayQ;           // 7 planes, stride rayCap
   float* rayContrib;     // 3 planes, stride rayCap: the clamped contribution the ray gates
@@ -148,14 +141,18 @@ void launchBmfr(const BmfrDev& A, uint32_t flags, hipStream_t st);
 // launchers (kernels.hip)
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
-// one bounce = persistent closest-hit trace over qin + dense shade/compact into qout
-void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
-                  const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st);
+// Persistent-grid sizes of one context's device, filled on first use (occupancy query per kernel variant).
+struct LaunchGrids {
+  uint32_t walk[4] = {0, 0, 0, 0};    // [GGX][COUNT]
+  uint32_t shadow[2] = {0, 0};        // [COUNT]
+};
+// both random walks of the frame: one persistent launch (trace + hit/miss shading in place)
+void launchWalk(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st);
 void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
-void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st);
+void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st);
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st);
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st);
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,

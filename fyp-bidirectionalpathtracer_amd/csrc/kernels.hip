@@ -3,11 +3,11 @@
 // Per frame (all on one HIP stream, no host synchronisation in between):
 //   gbuffer_kernel      primary visibility                      CP lightProbeGBuffer.rt.hlsl:63-159
 //   init_paths_kernel   eye vertex 1 + light vertex 0           BDPTMain.rt.hlsl:51-103, 124-135
-//   per bounce of each sub-path:
-//     trace_kernel<0>   persistent closest-hit traversal        globalIlluminationRay.hlsli:1-12 (TraceRay)
-//     shade_kernel      hit/miss shading + queue compaction     globalIlluminationRay.hlsli:14-45
+//   walk_kernel         both random walks, one persistent launch:
+//                       closest-hit traversal                   globalIlluminationRay.hlsli:1-12 (TraceRay)
+//                       + hit/miss shading in place             globalIlluminationRay.hlsli:14-45
 //   gen_{nee,splat,connect}_kernel  terms -> shadow-ray queue   BDPTMain.rt.hlsl:161-233
-//   trace_kernel<2>     persistent any-hit traversal            standardShadowRay.hlsli:7-49
+//   trace_shadow_kernel persistent any-hit traversal            standardShadowRay.hlsli:7-49
 //   gather_kernel       ordered sums, splat atomics             BDPTMain.rt.hlsl:166, 199, 230
 //   resolve_kernel      fold the splat buffer in                (build definition)
 //   accumulate_kernel   running mean                            CP accumulate.ps.hlsl:28-42
@@ -61,21 +61,26 @@ BD bool queueChunk(const uint32_t* count, uint32_t subCap, bool& act, uint32_t& 
 }
 
 // ------------------------------------------------------------------------------------------------
-// vertex planes
+// Path vertices: one 96-byte record (six float4) per (path, k, pixel), records of one (path, k) contiguous
+// by pixel.  A lane owns a sub-path, so it reads and writes whole records: six 16-byte accesses that use
+// every byte of the lines they touch, whatever pixel the lane holds (the walk kernel's lanes hold unrelated
+// pixels; the dense kernels' lanes hold consecutive ones and so cover 6 KiB contiguously per wave).
+//   q0 = pos.xyz, roughness   q1 = N.xyz, isSpecular   q2 = diffuse.xyz, pdfForward
+//   q3 = specular.xyz, -      q4 = colour.xyz, -       q5 = V.xyz, -
 // ------------------------------------------------------------------------------------------------
-BD float* planePtr(const PathBuf& P, int path, int k, int f) { return P.v + ((size_t)(path * (int)P.D1 + k) * NF + (size_t)f) * P.Np; }
+constexpr int kVtxQ = NF4;
+BD float4* vtxPtr(const PathBuf& P, int path, int k, uint32_t p) {
+  return reinterpret_cast<float4*>(P.v) + ((size_t)(path * (int)P.D1 + k) * P.Np + p) * kVtxQ;
+}
+BD constexpr int fieldQ(int f) { return f == F_POS ? 0 : f == F_N ? 1 : f == F_DIF ? 2 : f == F_SPEC ? 3 : f == F_COL ? 4 : 5; }
 BD f3 ldPlane3(const PathBuf& P, int path, int k, int f, uint32_t p) {
-  const float* b = planePtr(P, path, k, f) + p;
-  return f3{b[0], b[P.Np], b[2 * (size_t)P.Np]};
+  const float4 q = vtxPtr(P, path, k, p)[fieldQ(f)];
+  return f3{q.x, q.y, q.z};
 }
-BD void stPlane3(const PathBuf& P, int path, int k, int f, uint32_t p, f3 v) {
-  float* b = planePtr(P, path, k, f) + p;
-  b[0] = v.x;
-  b[P.Np] = v.y;
-  b[2 * (size_t)P.Np] = v.z;
+BD float ldPlane1(const PathBuf& P, int path, int k, int f, uint32_t p) {  // F_ROUGH, F_ISSPEC, F_PDF: .w of q0, q1, q2
+  const int q = (f == F_ROUGH) ? 0 : (f == F_ISSPEC ? 1 : 2);
+  return reinterpret_cast<const float*>(vtxPtr(P, path, k, p))[q * 4 + 3];
 }
-BD float ldPlane1(const PathBuf& P, int path, int k, int f, uint32_t p) { return planePtr(P, path, k, f)[p]; }
-BD void stPlane1(const PathBuf& P, int path, int k, int f, uint32_t p, float v) { planePtr(P, path, k, f)[p] = v; }
 
 struct Vtx {
   f3 color, pos, N, V, dif, spec;
@@ -92,24 +97,33 @@ BD Vtx zeroVtx() {
   return v;
 }
 BD void storeVtx(const PathBuf& P, int path, int k, uint32_t p, const Vtx& v) {
-  stPlane3(P, path, k, F_COL, p, v.color);
-  stPlane3(P, path, k, F_POS, p, v.pos);
-  stPlane3(P, path, k, F_N, p, v.N);
-  stPlane3(P, path, k, F_V, p, v.V);
-  stPlane3(P, path, k, F_DIF, p, v.dif);
-  stPlane3(P, path, k, F_SPEC, p, v.spec);
-  stPlane1(P, path, k, F_ROUGH, p, v.rough);
-  stPlane1(P, path, k, F_ISSPEC, p, v.isSpec ? 1.0f : 0.0f);
-  stPlane1(P, path, k, F_PDF, p, v.pdf);
+  float4* r = vtxPtr(P, path, k, p);
+  r[0] = make_float4(v.pos.x, v.pos.y, v.pos.z, v.rough);
+  r[1] = make_float4(v.N.x, v.N.y, v.N.z, v.isSpec ? 1.0f : 0.0f);
+  r[2] = make_float4(v.dif.x, v.dif.y, v.dif.z, v.pdf);
+  r[3] = make_float4(v.spec.x, v.spec.y, v.spec.z, 0.0f);
+  r[4] = make_float4(v.color.x, v.color.y, v.color.z, 0.0f);
+  r[5] = make_float4(v.V.x, v.V.y, v.V.z, 0.0f);
 }
-// geometry + material of a stored vertex (no colour, no V)
+// geometry + material of a stored vertex (no colour, no V); GGX = false skips the fields Lambert never reads
+template <bool GGX = true>
 BD void loadSurf(const PathBuf& P, int path, int k, uint32_t p, Vtx& v) {
-  v.pos = ldPlane3(P, path, k, F_POS, p);
-  v.N = ldPlane3(P, path, k, F_N, p);
-  v.dif = ldPlane3(P, path, k, F_DIF, p);
-  v.spec = ldPlane3(P, path, k, F_SPEC, p);
-  v.rough = ldPlane1(P, path, k, F_ROUGH, p);
-  v.isSpec = ldPlane1(P, path, k, F_ISSPEC, p) != 0.0f;
+  const float4* r = vtxPtr(P, path, k, p);
+  const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+  v.pos = mk(q0.x, q0.y, q0.z);
+  v.N = mk(q1.x, q1.y, q1.z);
+  v.dif = mk(q2.x, q2.y, q2.z);
+  v.pdf = q2.w;
+  if (GGX) {
+    const float4 q3 = r[3];
+    v.spec = mk(q3.x, q3.y, q3.z);
+    v.rough = q0.w;
+    v.isSpec = q1.w != 0.0f;
+  } else {
+    v.spec = mk(0);
+    v.rough = 0.0f;
+    v.isSpec = false;
+  }
 }
 
 BD void unpackHalf4(const uint16_t* base, size_t idx, float& a, float& b, float& c, float& d) {
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
       const float roughness = sa * sa;
       const f3 V = normalize(camPos - worldPos);
       uint32_t seed = initRand((uint32_t)pix, F.p.frameCount);
+      P.seedE[p] = seed;  // every eye bounce draws from this state by value (quirk 1)
       f3 outDir;
       float pdf;
       bool isSpec;
@@ -292,70 +307,222 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
 }
 
 // ------------------------------------------------------------------------------------------------
-// shade: second half of one bounce.  The persistent trace kernel has left a closest-hit record per
-// queued path; this dense kernel runs RayClosestHit / RayMiss (globalIlluminationRay.hlsli:14-45,
-// updateRayData RayPathData.hlsli:88-109) and compacts the survivors into the next queue.
+// walk: both random walks of the frame in ONE persistent launch (BDPTMain.rt.hlsl:106-112 eye,
+// :138-145 light; shootRay globalIlluminationRay.hlsli:1-12; RayClosestHit / RayMiss :14-45;
+// updateRayData RayPathData.hlsli:88-109).
+//
+// A wave owns up to 127 sub-paths at a time: 64 traversal slots (one per lane, state in registers,
+// stack in LDS) plus a 128-entry LDS pool holding PARKED hit records (filled from the bottom) and
+// READY next-bounce rays (filled from the top).  Per iteration of the wave:
+//   1. 64 or more parked records -> the hit/miss shader runs for 64 of them with every lane busy
+//      (vertex fetch, material + texture decode, sampleBRDF, vertex k+1 stored to its SoA planes);
+//      survivors become ready rays.  Which lane shades which record has nothing to do with the ray the
+//      lane is traversing: its traversal registers simply stay put meanwhile.
+//   2. empty lanes (kRefillIdle or more) take ready rays, then new sub-paths from the valid-pixel lists;
+//   3. one while-while traversal round; lanes that found their closest hit park the record and are empty.
+// Hit records, per-bounce path queues and the 2(2D-1) launch boundaries of a bounce-synchronous
+// wavefront never exist; shading is dense although traversal lengths diverge.
+//
+// Pool bound: new sub-paths are only fetched when no ray is ready, at which point fewer than 64 records
+// are parked, so traversing + parked + ready <= 127 always.
+// Work list: virtual list vq in [0, 2*kNumSubQueues): pixel list vq % kNumSubQueues of the valid-pixel
+// queue, path vq / kNumSubQueues (eye first).  `head` holds one fetch cursor per virtual list.
 // A miss stores the reference's "ghost" vertex (quirk 2): colour 0, previous payload geometry.
+// A path id packs pixel (24 bits), path (bit 24) and vertex index k (bits 25-29): tiles are < 2^24 pixels.
 // ------------------------------------------------------------------------------------------------
-template <bool GGX>
-__global__ __launch_bounds__(kWave) void shade_kernel(SceneDev S, FrameDev F, PathBuf P, int path, int k, int maxK,
-                                                      const uint32_t* __restrict__ qin, const uint32_t* __restrict__ countIn,
-                                                      uint32_t* __restrict__ qout, uint32_t* __restrict__ countOut) {
-  bool active = false;
-  uint32_t i = 0;
-  if (!queueChunk(countIn, P.pathSubCap, active, i)) return;
-  bool survive = false;
-  uint32_t p = 0;
-  if (active) {
-    p = qin[i];
-    const int prim = P.hitPrim[i];
-    if (prim >= 0) {
-      const f3 o = ldPlane3(P, path, k, F_POS, p);
-      Shading sd = shadeHit<false>(S, (uint32_t)prim, P.hitU[i], P.hitV[i], o);  // V points at WorldRayOrigin()
-      const size_t pix = (size_t)F.y0 * F.W + p;
-      const uint32_t seed = (path == PATH_EYE) ? initRand((uint32_t)pix, F.p.frameCount) : P.seedL[p];
-      f3 L;
-      float pdf;
-      bool isSpec;
-      f3 w = sampleBRDF<GGX>(seed, sd.N, sd.N, sd.V, sd.diffuse, sd.specular, sd.roughness,
-                             (F.p.flags & BDPT_PARAM_SPECULAR_FROM_LOBE) != 0, L, pdf, isSpec);
-      Vtx v;
-      v.color = ldPlane3(P, path, k, F_COL, p) * w;
-      v.pos = sd.posW;
-      v.N = sd.N;
-      v.V = sd.V;
-      v.dif = sd.diffuse;
-      v.spec = sd.specular;
-      v.rough = sd.roughness;
-      v.isSpec = isSpec;
-      v.pdf = pdf;
-      storeVtx(P, path, k + 1, p, v);
-      float* wr = P.rayDir + (size_t)(path * 3) * P.Np + p;
-      wr[0] = L.x;
-      wr[P.Np] = L.y;
-      wr[2 * (size_t)P.Np] = L.z;
-      survive = (k + 1 < maxK);
-    } else {
-      Vtx g = zeroVtx();
-      if (path == PATH_EYE && k == 1) {
-        g.pos = ldPlane3(P, path, k, F_POS, p);  // payload still holds initPayload's values (RayPathData.hlsli:69-86)
-      } else {
-        loadSurf(P, path, k, p, g);
-        g.V = ldPlane3(P, path, k, F_V, p);
-        g.pdf = (path == PATH_LIGHT && k == 0) ? 0.0f : ldPlane1(P, path, k, F_PDF, p);  // initPayload: pdfForward = 0
+constexpr uint32_t kPoolEntries = 128;
+BD uint32_t packPath(uint32_t p, int path, int k) { return p | ((uint32_t)path << 24) | ((uint32_t)k << 25); }
+
+template <bool GGX, bool COUNT>
+__global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, PathBuf P, uint32_t* __restrict__ head) {
+  __shared__ int s_stack[kStackEntries * kWave];
+  __shared__ uint4 s_pool[kPoolEntries];
+  int* stk = s_stack + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned long long laneBelow = (1ull << lane) - 1ull;
+  const int D = (int)F.p.maxDepth;
+  const bool fromLobe = (F.p.flags & BDPT_PARAM_SPECULAR_FROM_LOBE) != 0;
+  // the eye walk extends vertices 1..D-1 (none when D < 2), the light walk vertices 0..D-1
+  const uint32_t firstV = (D >= 2) ? 0u : kNumSubQueues, numV = 2u * kNumSubQueues - firstV;
+  bool trav = false;   // this lane holds a ray
+  uint32_t id = 0;     // its path id
+  TravState T;
+  travInit(T, mk(0), mk(0), F.p.minT, 1.0e38f);
+  T.cur = kDone;
+  uint32_t nNodes = 0, nTris = 0;
+  uint32_t nEye = 0, nLight = 0, nParked = 0, nReady = 0;  // wave-uniform
+  uint32_t vq = firstV + blockIdx.x % numV, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
+  bool exhausted = false;
+  const uint32_t wavesPerList = (gridDim.x + numV - 1) / numV;
+  for (;;) {
+    unsigned long long travMask = __ballot(trav);
+    // ---- 1. hit / miss shaders, one parked record per lane ------------------------------------------
+    // (also when nothing else can make progress: the last records of the wave are shaded short-handed)
+    const bool flush = (travMask == 0ull) && nReady == 0 && exhausted && nParked > 0;
+    if (nParked >= (uint32_t)kWave || flush) {
+      const uint32_t n = nParked < (uint32_t)kWave ? nParked : (uint32_t)kWave;
+      nParked -= n;
+      const bool act = (uint32_t)lane < n;
+      uint4 rec = make_uint4(0, 0, 0, 0);
+      if (act) rec = s_pool[nParked + (uint32_t)lane];
+      __syncthreads();  // the slots may be overwritten by ready rays below
+      const uint32_t p = rec.x & 0xffffffu;
+      const int path = (int)((rec.x >> 24) & 1u), k = (int)(rec.x >> 25);
+      nEye += (uint32_t)__popcll(__ballot(act && path == PATH_EYE));
+      nLight += (uint32_t)__popcll(__ballot(act && path == PATH_LIGHT));
+      bool survive = false;
+      f3 L = mk(0);
+      if (act) {
+        const int prim = (int)rec.y;
+        const f3 o = ldPlane3(P, path, k, F_POS, p);
+        if (prim >= 0) {
+          const uint32_t seed = (path == PATH_EYE) ? P.seedE[p] : P.seedL[p];
+          const f3 thr = ldPlane3(P, path, k, F_COL, p);
+          Shading sd = shadeHit<false>(S, (uint32_t)prim, __uint_as_float(rec.z), __uint_as_float(rec.w), o);  // V points at WorldRayOrigin()
+          float pdf;
+          bool isSpec;
+          f3 w = sampleBRDF<GGX>(seed, sd.N, sd.N, sd.V, sd.diffuse, sd.specular, sd.roughness, fromLobe, L, pdf, isSpec);
+          Vtx v;
+          v.color = thr * w;
+          v.pos = sd.posW;
+          v.N = sd.N;
+          v.V = sd.V;
+          v.dif = sd.diffuse;
+          v.spec = sd.specular;
+          v.rough = sd.roughness;
+          v.isSpec = isSpec;
+          v.pdf = pdf;
+          storeVtx(P, path, k + 1, p, v);
+          survive = (k + 2 <= D);  // k + 1 < maxK
+        } else {
+          Vtx g = zeroVtx();
+          if (path == PATH_EYE && k == 1) {
+            g.pos = o;  // payload still holds initPayload's values (RayPathData.hlsli:69-86)
+          } else {
+            loadSurf(P, path, k, p, g);
+            g.V = ldPlane3(P, path, k, F_V, p);
+            if (path == PATH_LIGHT && k == 0) g.pdf = 0.0f;  // initPayload: pdfForward = 0
+          }
+          g.color = mk(0);
+          storeVtx(P, path, k + 1, p, g);
+          if (path == PATH_EYE) {
+            P.eyeLast[p] = (uint8_t)(k + 1);
+          } else {
+            P.lightLast[p] = (uint8_t)(k + 1);
+            P.lightReal[p] = (uint8_t)k;
+          }
+        }
       }
-      g.color = mk(0);
-      storeVtx(P, path, k + 1, p, g);
-      if (path == PATH_EYE) {
-        P.eyeLast[p] = (uint8_t)(k + 1);
-      } else {
-        P.lightLast[p] = (uint8_t)(k + 1);
-        P.lightReal[p] = (uint8_t)k;
+      // survivors -> ready rays (origin = the stored vertex k+1, re-read at pick-up)
+      const unsigned long long sm = __ballot(survive);
+      if (survive) {
+        const uint32_t slot = kPoolEntries - 1u - nReady - (uint32_t)__popcll(sm & laneBelow);
+        s_pool[slot] = make_uint4(packPath(p, path, k + 1), __float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z));
+      }
+      nReady += (uint32_t)__popcll(sm);
+      // this wave's later loads of the vertices it just stored must see them (same CU: ordering is enough)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+    }
+    // ---- 2. empty lanes take ready rays, then new sub-paths -------------------------------------------
+    const int empty = 64 - __popcll(travMask);
+    if ((empty >= kRefillIdle || travMask == 0ull) && (nReady > 0 || !exhausted)) {
+      const unsigned long long emptyMask = ~travMask;
+      const uint32_t rank = (uint32_t)__popcll(emptyMask & laneBelow);
+      const uint32_t fromReady = ((uint32_t)empty < nReady) ? (uint32_t)empty : nReady;
+      bool got = false;
+      uint32_t nid = 0;
+      f3 dir = mk(0);
+      if (!trav && rank < fromReady) {
+        const uint4 r = s_pool[kPoolEntries - nReady + rank];
+        nid = r.x;
+        dir = mk(__uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+        got = true;
+      }
+      __syncthreads();  // the pool slots just read may be reused by parked records
+      nReady -= fromReady;
+      uint32_t want = (uint32_t)empty - fromReady;  // lanes still empty: new sub-paths (only reached with nReady == 0)
+      uint32_t taken = fromReady;
+      while (want > 0 && !exhausted) {
+        while (chunkPos >= chunkEnd && !exhausted) {  // wave-uniform loop: take a new chunk
+          const uint32_t nq = P.qcount[(vq % kNumSubQueues) * kCursorStride];
+          uint32_t base = nq;
+          if (__hip_atomic_load(&head[vq * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
+            uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
+            chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
+            if (lane == 0) base = atomicAdd(&head[vq * kCursorStride], chunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          }
+          if (base < nq) {
+            chunkPos = base;
+            chunkEnd = (base + chunk < nq) ? base + chunk : nq;
+            tried = 0;
+          } else {
+            vq = (vq + 1 == 2u * kNumSubQueues) ? firstV : vq + 1;
+            if (++tried >= numV) exhausted = true;
+          }
+        }
+        if (exhausted) break;
+        const uint32_t avail = chunkEnd - chunkPos;
+        const uint32_t take = (want < avail) ? want : avail;
+        if (!trav && !got && rank >= taken && rank < taken + take) {
+          const uint32_t p = P.queue[0][(vq % kNumSubQueues) * P.pathSubCap + chunkPos + (rank - taken)];
+          const int path = (int)(vq / kNumSubQueues);
+          const float* rd = P.rayDir + (size_t)(path * 3) * P.Np + p;
+          nid = packPath(p, path, (path == PATH_EYE) ? 1 : 0);
+          dir = mk(rd[0], rd[P.Np], rd[2 * (size_t)P.Np]);
+          got = true;
+        }
+        chunkPos += take;
+        taken += take;
+        want -= take;
+      }
+      if (got) {
+        id = nid;
+        travInit(T, ldPlane3(P, (int)((nid >> 24) & 1u), (int)(nid >> 25), F_POS, nid & 0xffffffu), dir, F.p.minT, 1.0e38f);
+        trav = true;
+      }
+      travMask = __ballot(trav);
+    }
+    if (travMask == 0ull) {
+      if (nParked == 0 && nReady == 0 && exhausted) break;
+      continue;  // parked records are flushed (or ready rays picked up) at the top
+    }
+    // ---- 3. one while-while round of traversal for the lanes that hold a ray ---------------------------
+    bool finished = false;
+    if (trav) {
+      while (T.cur >= 0) {
+        if (COUNT) nNodes++;
+        nodeStep<true>(S, T, stk);
+      }
+      finished = (T.cur == kDone);
+      if (!finished) {
+        finished = leafStep<0, COUNT>(S, T, nTris);
+        if (!finished) {
+          T.cur = travPop(T, stk);
+          finished = (T.cur == kDone);
+        }
       }
     }
+    const unsigned long long finMask = __ballot(finished);
+    if (finMask) {
+      if (finished) {
+        s_pool[nParked + (uint32_t)__popcll(finMask & laneBelow)] =
+            make_uint4(id, (uint32_t)T.best.prim, __float_as_uint(T.best.u), __float_as_uint(T.best.v));
+        trav = false;
+      }
+      nParked += (uint32_t)__popcll(finMask);
+      __syncthreads();
+    }
   }
-  waveAddCount(F.counters, path == PATH_EYE ? C_RAYS_EYE : C_RAYS_LIGHT, active ? 1u : 0u);
-  wavePush(survive, p, qout, countOut, P.pathSubCap);
+  if (lane == 0) {
+    if (nEye) atomicAdd(&F.counters->v[blockIdx.x % kCounterShards][C_RAYS_EYE], (unsigned long long)nEye);
+    if (nLight) atomicAdd(&F.counters->v[blockIdx.x % kCounterShards][C_RAYS_LIGHT], (unsigned long long)nLight);
+  }
+  if (COUNT) {
+    waveAddCount(F.counters, C_NODE_CLOSEST, nNodes);
+    waveAddCount(F.counters, C_TRI_CLOSEST, nTris);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,18 +655,7 @@ BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx
     v = zeroVtx();
     return;
   }
-  v.pos = ldPlane3(P, path, k, F_POS, p);
-  v.N = ldPlane3(P, path, k, F_N, p);
-  v.dif = ldPlane3(P, path, k, F_DIF, p);
-  if (GGX) {
-    v.spec = ldPlane3(P, path, k, F_SPEC, p);
-    v.rough = ldPlane1(P, path, k, F_ROUGH, p);
-    v.isSpec = ldPlane1(P, path, k, F_ISSPEC, p) != 0.0f;
-  } else {
-    v.spec = mk(0);
-    v.rough = 0.0f;
-    v.isSpec = false;
-  }
+  loadSurf<GGX>(P, path, k, p, v);
 }
 
 // Three kernels (NEE, splat, connection) instead of one: each stays under 64 VGPRs, so twice as
@@ -576,7 +732,7 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
       uint32_t target = kNoRay;
       if (act && t < real) {
         Vtx lv;
-        loadSurf(P, PATH_LIGHT, t + 1, p, lv);
+        loadSurf<GGX>(P, PATH_LIGHT, t + 1, p, lv);
         pos = lv.pos;
         dirToCamera = normalize(camPos - lv.pos);
         disToCamera = length(camPos - lv.pos);
@@ -1003,31 +1159,22 @@ void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hip
     hipLaunchKernelGGL(init_paths_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
 }
 
-void launchExtend(const SceneDev& S, const FrameDev& F, const PathBuf& P, int path, int k, int maxK, const uint32_t* qin,
-                  const uint32_t* countIn, uint32_t* head, uint32_t* qout, uint32_t* countOut, int numCUs, hipStream_t st) {
-  if (!P.Np) return;
-  const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
-  RayQueue Q{nullptr, 0, P.pathSubCap, kNumSubQueues, countIn, head};
-  ClosestIn CI{qin, P.v + ((size_t)(path * (int)P.D1 + k) * NF + (size_t)F_POS) * P.Np, P.rayDir + (size_t)(path * 3) * P.Np, P.Np,
-               F.p.minT};
-  ShadowOut SO{nullptr};
-  ClosestOut CO{P.hitPrim, P.hitT, P.hitU, P.hitV};
-  static uint32_t grid0 = 0, grid1 = 0;
-  if (cnt) {
-    if (!grid1) grid1 = persistentGrid(trace_kernel<0, true>, numCUs);
-    const uint32_t g = std::min(grid1, blocksFor(P.Np));
-    hipLaunchKernelGGL((trace_kernel<0, true>), dim3(g), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, 0.0f);
-  } else {
-    if (!grid0) grid0 = persistentGrid(trace_kernel<0, false>, numCUs);
-    const uint32_t g = std::min(grid0, blocksFor(P.Np));
-    hipLaunchKernelGGL((trace_kernel<0, false>), dim3(g), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, 0.0f);
+void launchWalk(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st) {
+  if (!P.Np || F.p.maxDepth < 1) return;
+  const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0, ggx = F.p.matIndex == 0;
+  uint32_t& g = G.walk[(ggx ? 2 : 0) + (cnt ? 1 : 0)];
+  // at most two sub-paths per pixel: a small tile does not need the whole persistent grid
+  const uint32_t need = blocksFor((uint64_t)2 * P.Np);
+#define BDPT_LAUNCH_WALK(GGX, CNT)                                                                        \
+  {                                                                                                      \
+    if (!g) g = persistentGrid(walk_kernel<GGX, CNT>, numCUs);                                            \
+    hipLaunchKernelGGL((walk_kernel<GGX, CNT>), dim3(std::min(g, need)), dim3(kWave), 0, st, S, F, P, P.qhead); \
   }
-  if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(shade_kernel<true>, dim3(queueGrid(P)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
-                       countOut);
-  else
-    hipLaunchKernelGGL(shade_kernel<false>, dim3(queueGrid(P)), dim3(kWave), 0, st, S, F, P, path, k, maxK, qin, countIn, qout,
-                       countOut);
+  if (ggx && cnt) BDPT_LAUNCH_WALK(true, true)
+  else if (ggx) BDPT_LAUNCH_WALK(true, false)
+  else if (cnt) BDPT_LAUNCH_WALK(false, true)
+  else BDPT_LAUNCH_WALK(false, false)
+#undef BDPT_LAUNCH_WALK
 }
 
 void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st) {
@@ -1061,20 +1208,17 @@ void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hi
     hipLaunchKernelGGL(gen_connect_kernel<false>, g, b, 0, st, S, F, P);
 }
 
-void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int numCUs, hipStream_t st) {
+void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st) {
   if (!P.Np) return;
   const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
   RayQueue Q{P.rayQ, P.rayCap, P.raySubCap, kNumSubQueues, P.rayCount, P.rayHead};
-  ClosestIn CI{nullptr, nullptr, nullptr, 0, 0.0f};
-  ShadowOut SO{P.rayVis};
-  ClosestOut CO{nullptr, nullptr, nullptr, nullptr};
-  static uint32_t grid0 = 0, grid1 = 0;
+  uint32_t& g = G.shadow[cnt ? 1 : 0];
   if (cnt) {
-    if (!grid1) grid1 = persistentGrid(trace_kernel<2, true>, numCUs);
-    hipLaunchKernelGGL((trace_kernel<2, true>), dim3(grid1), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, F.p.minT);
+    if (!g) g = persistentGrid(trace_shadow_kernel<true>, numCUs);
+    hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, P.rayVis, F.counters, F.p.minT);
   } else {
-    if (!grid0) grid0 = persistentGrid(trace_kernel<2, false>, numCUs);
-    hipLaunchKernelGGL((trace_kernel<2, false>), dim3(grid0), dim3(kWave), 0, st, S, Q, CI, SO, CO, F.counters, F.p.minT);
+    if (!g) g = persistentGrid(trace_shadow_kernel<false>, numCUs);
+    hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, P.rayVis, F.counters, F.p.minT);
   }
 }
 

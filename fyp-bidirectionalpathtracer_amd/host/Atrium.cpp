@@ -139,7 +139,7 @@ struct Builder {
   }
 };
 
-enum Mat : uint32_t { M_FLOOR = 0, M_BRICK, M_STONE, M_DRAPE, M_GOLD, M_LATTICE, M_RELIEF, M_GLOSS, M_LAMP, M_PEBBLE };
+enum Mat : uint32_t { M_FLOOR = 0, M_BRICK, M_STONE, M_DRAPE, M_GOLD, M_LATTICE, M_RELIEF, M_GLOSS, M_LAMP, M_PEBBLE, M_LEAF };
 
 void buildGeometry(Builder& b) {
   Scene& s = b.s;
@@ -325,6 +325,40 @@ void addPebbles(Scene& s, uint32_t count, uint32_t seed) {
   }
 }
 
+// Foliage for the courtyard variant (San Miguel stand-in, BASELINE config 5): `count` triangles as
+// alpha-masked, double-sided leaf cards (two triangles each) in tree crowns standing in the nave, so that
+// shadow and extension rays crossing the hall run the any-hit alpha test many times per query.
+void addFoliage(Scene& s, uint32_t count, uint32_t seed) {
+  Rng rng(seed + 4242);
+  const int nTrees = 9;
+  uint32_t cards = count / 2;
+  for (uint32_t i = 0; i < cards; i++) {
+    const int tree = (int)(i % (uint32_t)nTrees);
+    const float tx = -12.0f + 3.0f * (float)tree, tz = (tree & 1) ? 1.3f : -1.3f, ty = 3.4f + 0.9f * (float)(tree % 3);
+    // point in an ellipsoidal crown, denser towards the shell
+    float3 d;
+    do {
+      d = {rng.range(-1, 1), rng.range(-1, 1), rng.range(-1, 1)};
+    } while (dt(d, d) > 1.0f || dt(d, d) < 0.05f);
+    const float sh = 0.55f + 0.45f * rng.uni();
+    d = mul(nrm(d), sh);
+    const float3 c{tx + 1.35f * d.x, ty + 1.9f * d.y, tz + 1.35f * d.z};
+    // leaf card: random orientation, slightly drooping
+    float3 ax = nrm(float3{rng.range(-1, 1), rng.range(-0.4f, 0.4f), rng.range(-1, 1)}, {1, 0, 0});
+    float3 up = nrm(float3{rng.range(-0.5f, 0.5f), 1.0f, rng.range(-0.5f, 0.5f)});
+    float3 ay = nrm(crs(crs(ax, up), ax), {0, 1, 0});
+    const float hw = rng.range(0.05f, 0.11f), hh = rng.range(0.08f, 0.17f);
+    const float3 n = nrm(crs(ax, ay));
+    const float3 p0 = add(c, add(mul(ax, -hw), mul(ay, -hh))), p1 = add(c, add(mul(ax, hw), mul(ay, -hh)));
+    const float3 p2 = add(c, add(mul(ax, hw), mul(ay, hh))), p3 = add(c, add(mul(ax, -hw), mul(ay, hh)));
+    const uint32_t i0 = s.addVertex(p0, n, ay, 0, 0), i1 = s.addVertex(p1, n, ay, 1, 0), i2 = s.addVertex(p2, n, ay, 1, 1),
+                   i3 = s.addVertex(p3, n, ay, 0, 1);
+    s.addTriangle(i0, i1, i2, M_LEAF);
+    s.addTriangle(i0, i2, i3, M_LEAF);
+  }
+  if (count & 1u) addPebbles(s, 1, seed + 1);
+}
+
 void addTexturesAndMaterials(Scene& s, uint32_t seed) {
   // 0 marble checker
   s.textures.push_back(makeTexture(512, 512, 1, [&](float u, float v, uint8_t* px) {
@@ -450,10 +484,35 @@ void addTexturesAndMaterials(Scene& s, uint32_t seed) {
   s.materials.push_back(texMaterial(BDPT_SHADING_MODEL_METAL_ROUGH, -1, peb, -1, specRough8, -1, false, false));
 }
 
+// texture 7 + M_LEAF: a leaf silhouette in the alpha channel (about half of the card is cut away)
+void addLeafMaterial(Scene& s, uint32_t seed) {
+  s.textures.push_back(makeTexture(128, 128, 1, [&](float u, float v, uint8_t* px) {
+    const float x = (u - 0.5f) * 2.0f, y = v;
+    const float halfWidth = 0.95f * std::sqrt(std::fmax(0.0f, y * (1.0f - y))) * (1.0f + 0.15f * std::sin(y * 37.0f));
+    const bool leaf = std::fabs(x) < halfWidth || (std::fabs(x) < 0.05f && y < 0.1f);
+    const float vein = 0.85f + 0.15f * fbm(u * 20, v * 20, seed + 71);
+    px[0] = u8(0.16f * vein);
+    px[1] = u8(0.42f * vein);
+    px[2] = u8(0.10f * vein);
+    px[3] = leaf ? 255 : 0;
+  }));
+  const float white[4] = {1, 1, 1, 1};
+  const float specRough7[4] = {0, 0.7f, 0, 0};
+  s.materials.push_back(texMaterial(BDPT_SHADING_MODEL_METAL_ROUGH, (int)s.textures.size() - 1, white, -1, specRough7, -1, true, true));
+}
+
 }  // namespace
 
-Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles) {
+Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles) { return createAtrium(seed, targetTriangles, 0.0f); }
+
+// foliageFraction > 0: the courtyard variant — that share of the triangles are alpha-masked leaf cards.
+Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, float foliageFraction) {
   if (targetTriangles < 4096) targetTriangles = 4096;
+  if (!(foliageFraction > 0.0f)) foliageFraction = 0.0f;
+  if (foliageFraction > 0.9f) foliageFraction = 0.9f;
+  const uint32_t foliage = (uint32_t)((double)targetTriangles * (double)foliageFraction) & ~1u;
+  const uint32_t total = targetTriangles;
+  targetTriangles -= foliage;
   // find the largest tessellation scale whose triangle count stays at or below the target
   float lo = 0.02f, hi = 8.0f;
   for (int it = 0; it < 22; it++) {
@@ -470,7 +529,9 @@ Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles) {
   Builder b{*s, lo, seed};
   buildGeometry(b);
   if (s->getTriangleCount() < targetTriangles) addPebbles(*s, targetTriangles - s->getTriangleCount(), seed);
+  if (foliage) addFoliage(*s, total - s->getTriangleCount(), seed);
   addTexturesAndMaterials(*s, seed);
+  if (foliage) addLeafMaterial(*s, seed);
 
   auto point = [&](float x, float y, float z, float r, float g, float bl) {
     bdpt_light l{};

@@ -284,6 +284,15 @@ void bdpt_msaa_jitter(uint32_t frameCounterBeforeIncrement, float out[2]);
  * [tile.y0, tile.y1) are rendered here, at up to maxDepth. */
 int bdpt_resize(bdpt_ctx* ctx, uint32_t width, uint32_t height, bdpt_tile tile, uint32_t maxDepth);
 
+/* Allocate optional per-frame buffers ahead of time, so that no execute call allocates (hipGraph capture,
+ * first-frame latency): the built-in primary stage's channels and/or the BMFR history.  Call after
+ * bdpt_resize (a resize frees them again).  Replaces the lazy texture creation of
+ * ResourceManager::requestTextureResource / DenoisePass::initialize (SharedUtils/ResourceManager.cpp:210-241,
+ * BidirectionalPathtracing/Passes/DenoisePass.cpp:60-96). */
+#define BDPT_PREPARE_PRIMARY 1u
+#define BDPT_PREPARE_BMFR 2u
+int bdpt_prepare(bdpt_ctx* ctx, uint32_t what);
+
 /* Primary-visibility pass.  Writes the tile rows of all six channels. */
 int bdpt_gbuffer_execute(bdpt_ctx* ctx, const bdpt_gbuffer_params* p, const bdpt_gbuffer* out, void* stream);
 
@@ -292,8 +301,9 @@ int bdpt_gbuffer_execute(bdpt_ctx* ctx, const bdpt_gbuffer_params* p, const bdpt
  * BDPTPass.cpp:73).  Without BDPT_PARAM_DEFER_RESOLVE the splats of this call are
  * folded in before returning control to the stream.
  * `in` may be NULL: the primary stage then runs inside the call into channels the context owns
- * (pinhole, p->pixelJitter, p->frameCount, default constant environment); the first such call
- * allocates them. */
+ * (pinhole, p->pixelJitter, p->frameCount, default constant environment).  They are allocated by
+ * bdpt_prepare(BDPT_PREPARE_PRIMARY), or else by the first such call — which therefore must not be
+ * inside a stream capture (BDPT_E_STATE). */
 int bdpt_execute(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream);
 
 /* Second phase of a bdpt_execute issued with BDPT_PARAM_DEFER_TAIL (same params, channels and out). */
@@ -334,7 +344,8 @@ typedef struct bdpt_bmfr_params {
 
 /* One execute() of the denoise pass on `noisy` (full-frame RGBA32F, in/out: the channel being
  * denoised) with the G-buffer's WorldPosition / WorldNormal / MaterialDiffuse as features.  History
- * (previous position, normal, noisy and filtered frames, accept masks) lives in the context. */
+ * (previous position, normal, noisy and filtered frames, accept masks) lives in the context; it is allocated
+ * by bdpt_prepare(BDPT_PREPARE_BMFR) or by the first call (not inside a stream capture: BDPT_E_STATE). */
 int bdpt_bmfr_execute(bdpt_ctx* ctx, const bdpt_bmfr_params* p, const bdpt_gbuffer* features, float* noisy, void* stream);
 
 /* Forget the history (BlockwiseMultiOrderFeatureRegression::resize / initScene set mAccumCount = 0). */

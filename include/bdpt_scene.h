@@ -30,6 +30,11 @@ bdpt_scene* bdpt_scene_create_cornell(void);
  * and one spot light.  Stand-in for Crytek Sponza at `targetTriangles` (~262k). */
 bdpt_scene* bdpt_scene_create_atrium(uint32_t seed, uint32_t targetTriangles);
 
+/* The atrium with `foliageFraction` (0..0.9) of its triangles as alpha-masked, double-sided leaf cards in
+ * tree crowns standing in the nave: stand-in for San Miguel's alpha-tested foliage,
+ * where most rays run the any-hit alpha test (BDPTUtils.hlsli:115-127) several times. */
+bdpt_scene* bdpt_scene_create_courtyard(uint32_t seed, uint32_t targetTriangles, float foliageFraction);
+
 /* Uniform random triangle soup in the unit cube (intersection KATs). */
 bdpt_scene* bdpt_scene_create_soup(uint32_t seed, uint32_t numTriangles, float maxEdge);
 

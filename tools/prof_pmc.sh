@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/prof_pmc.sh <tag> [bench args...] — rocprofv3 PMC passes (own runs, no trace domains) + kernel-trace stats of
+# `python3 bench.py`, written under gpurun_out/<tag>_*; summaries printed by tools/pmc_summary.py.
+# Run on the GPU box:  gpurun -- 'bash tools/prof_pmc.sh r2x'
+set -e
+tag=$1; shift
+args="--steps 2 --warmup 1 --no-cpu-baseline --no-pipelined-pass $*"
+export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  -d gpurun_out/${tag}_pmc_sq -o run --output-format csv -- python3 bench.py $args > gpurun_out/${tag}_pmc_sq.log 2>&1
+rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum \
+  -d gpurun_out/${tag}_pmc_cache -o run --output-format csv -- python3 bench.py $args > gpurun_out/${tag}_pmc_cache.log 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY \
+  -d gpurun_out/${tag}_pmc_mix -o run --output-format csv -- python3 bench.py $args > gpurun_out/${tag}_pmc_mix.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_sq gpurun_out/${tag}_pmc_cache gpurun_out/${tag}_pmc_mix

@@ -125,6 +125,7 @@ PROTOTYPES = {
     "bdpt_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_execute_tail": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bdpt_bvh_build_hash": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_uint64), C.POINTER(BvhInfo)]),
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bdpt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bdpt.h"
@@ -75,6 +77,24 @@ struct bdpt_ctx {
 };
 
 namespace {
+
+// [0, n) in contiguous chunks over the builder's host threads (bvhBuildThreads)
+template <class F>
+void hostParallelFor(size_t n, const F& f) {
+  const int threads = bvhBuildThreads();
+  if (threads <= 1 || n < 65536) {
+    f((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 1; t < threads; t++) {
+    const size_t a = std::min(n, chunk * (size_t)t), b = std::min(n, a + chunk);
+    if (a < b) pool.emplace_back([&f, a, b] { f(a, b); });
+  }
+  f((size_t)0, std::min(n, chunk));
+  for (std::thread& th : pool) th.join();
+}
 
 bool fail(bdpt_ctx* c, const std::string& m) {
   if (c) c->err = m;
@@ -245,16 +265,23 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
     fail(c, "scene: triangle count exceeds the 2^28 leaf-reference limit");
     return BDPT_E_LIMIT;
   }
-  for (uint32_t t = 0; t < d->numTriangles; t++) {
-    if (d->triMaterial[t] >= d->numMaterials) {
+  {
+    std::atomic<int> bad{0};  // 1 = material id, 2 = vertex index
+    hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
+      for (size_t t = t0; t < t1; t++) {
+        if (d->triMaterial[t] >= d->numMaterials) bad.store(1);
+        for (int k = 0; k < 3; k++)
+          if (d->indices[t * 3 + (size_t)k] >= d->numVertices) bad.store(2);
+      }
+    });
+    if (bad.load() == 1) {
       fail(c, "scene: triMaterial out of range");
       return BDPT_E_INVALID;
     }
-    for (int k = 0; k < 3; k++)
-      if (d->indices[(size_t)t * 3 + k] >= d->numVertices) {
-        fail(c, "scene: vertex index out of range");
-        return BDPT_E_INVALID;
-      }
+    if (bad.load() == 2) {
+      fail(c, "scene: vertex index out of range");
+      return BDPT_E_INVALID;
+    }
   }
   for (uint32_t m = 0; m < d->numMaterials; m++) {
     const bdpt_material& mm = d->materials[m];
@@ -274,11 +301,13 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   // per-triangle traversal flags: BLAS OPAQUE iff AlphaModeOpaque (Falcor Raytracing/RtModel.cpp:221-224),
   // TRIANGLE_CULL_DISABLE iff double-sided (Raytracing/RtScene.cpp:175-178)
   std::vector<uint32_t> triFlags(d->numTriangles);
-  for (uint32_t t = 0; t < d->numTriangles; t++) {
-    const uint32_t f = d->materials[d->triMaterial[t]].flags;
-    triFlags[t] = (BDPT_FLAG_ALPHA_MODE(f) != BDPT_ALPHA_MODE_OPAQUE ? kTriNonOpaque : 0u) |
-                  (BDPT_FLAG_DOUBLE_SIDED(f) ? kTriDoubleSided : 0u);
-  }
+  hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
+    for (size_t t = t0; t < t1; t++) {
+      const uint32_t f = d->materials[d->triMaterial[t]].flags;
+      triFlags[t] = (BDPT_FLAG_ALPHA_MODE(f) != BDPT_ALPHA_MODE_OPAQUE ? kTriNonOpaque : 0u) |
+                    (BDPT_FLAG_DOUBLE_SIDED(f) ? kTriDoubleSided : 0u);
+    }
+  });
   Bvh bvh;
   buildBvh(d->positions, d->indices, d->numTriangles, triFlags.data(), bvh);
   if (bvh.maxStack > (uint32_t)kBvhMaxStack) {
@@ -295,25 +324,27 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
 
   // per-primitive shading records: 3 x (position, normal, uv) + material id, 112 B
   std::vector<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4, 0.0f);
-  for (uint32_t t = 0; t < d->numTriangles; t++) {
-    float* r = &shade[(size_t)t * kShadeRecF4 * 4];
-    for (int k = 0; k < 3; k++) {
-      const uint32_t vi = d->indices[(size_t)t * 3 + k];
-      const float* p = d->positions + (size_t)vi * 3;
-      const float* nn = d->normals + (size_t)vi * 3;
-      float* q = r + k * 8;
-      q[0] = p[0];
-      q[1] = p[1];
-      q[2] = p[2];
-      q[3] = nn[0];
-      q[4] = nn[1];
-      q[5] = nn[2];
-      q[6] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
-      q[7] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
+  hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
+    for (size_t t = t0; t < t1; t++) {
+      float* r = &shade[t * kShadeRecF4 * 4];
+      for (int k = 0; k < 3; k++) {
+        const uint32_t vi = d->indices[t * 3 + (size_t)k];
+        const float* p = d->positions + (size_t)vi * 3;
+        const float* nn = d->normals + (size_t)vi * 3;
+        float* q = r + k * 8;
+        q[0] = p[0];
+        q[1] = p[1];
+        q[2] = p[2];
+        q[3] = nn[0];
+        q[4] = nn[1];
+        q[5] = nn[2];
+        q[6] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
+        q[7] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
+      }
+      uint32_t mid = d->triMaterial[t];
+      std::memcpy(r + 24, &mid, 4);
     }
-    uint32_t mid = d->triMaterial[t];
-    std::memcpy(r + 24, &mid, 4);
-  }
+  });
 
   int rc;
   const BvhNode* dNodes;
@@ -454,6 +485,34 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   if (!ok) return say(why);
   for (uint32_t i = 0; i < d->numTriangles; i++)
     if (!covered[i]) return say("a leaf-order triangle is not referenced by any leaf");
+  return BDPT_OK;
+}
+
+int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info) {
+  if (!d || !out_hash || !d->positions || !d->indices) return BDPT_E_INVALID;
+  Bvh bvh;
+  buildBvh(d->positions, d->indices, d->numTriangles, nullptr, bvh, threads);
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over the node array, the leaf-ordered triangles and the summary
+  auto mix = [&](const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+  mix(bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri));
+  mix(&bvh.maxDepth, sizeof(bvh.maxDepth));
+  mix(&bvh.maxStack, sizeof(bvh.maxStack));
+  mix(&bvh.sahCost, sizeof(bvh.sahCost));
+  *out_hash = h;
+  if (out_info) {
+    out_info->numNodes = (uint32_t)bvh.nodes.size();
+    out_info->numTriangles = d->numTriangles;
+    out_info->maxDepth = bvh.maxDepth;
+    out_info->nodeBytes = sizeof(BvhNode);
+    out_info->triBytes = sizeof(BvhTri);
+    out_info->sahCost = bvh.sahCost;
+    out_info->maxStack = bvh.maxStack;
+    out_info->reserved = (uint32_t)bvhBuildThreads();
+  }
   return BDPT_OK;
 }
 

@@ -56,7 +56,11 @@ struct Bvh {
 };
 
 // positions: 3 floats per vertex; indices: 3 per triangle; triFlags: per triangle (may be null).
-void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTriangles, const uint32_t* triFlags, Bvh& out);
+// threads <= 0: bvhBuildThreads().  The tree does not depend on the thread count, bit for bit.
+void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTriangles, const uint32_t* triFlags, Bvh& out,
+              int threads = 0);
+// host threads the builder uses by default: BDPT_BUILD_THREADS, else the affinity mask capped by the cgroup CPU quota
+int bvhBuildThreads();
 
 // Decode one quantised plane exactly as the device does.
 inline float bvhDecodePlane(const BvhNode& n, int axis, uint8_t q) {

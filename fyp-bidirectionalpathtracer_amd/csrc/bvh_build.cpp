@@ -1,9 +1,23 @@
 // bvh_build.cpp — binned-SAH top-down builder producing the flat 64-byte-node layout of bvh.h.
+//
+// Threaded (std::thread): the top of the tree is split by one thread with the binning of large nodes shared
+// among all, then the subtrees below a grain size are built concurrently on disjoint ranges of the
+// triangle order; the per-triangle and per-node passes run as parallel loops.  The result does not depend on
+// the thread count, bit for bit: bin bounds and counts are order-independent (min / max / integer sums), every
+// partition is the same serial std::partition on the same range, the four-wide collapse only looks at the tree's
+// shape, and the one floating-point sum (the SAH cost) is taken in node order by one thread.
 #include "bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
+
+#include <sched.h>
 
 namespace bdpt {
 namespace {
@@ -51,9 +65,270 @@ inline uint32_t ceilLog2(uint32_t x) {
   return l;
 }
 
+// [0, n) in `threads` contiguous chunks, one std::thread each (the caller's thread takes chunk 0)
+template <class F>
+void parallelFor(size_t n, int threads, const F& f) {
+  if (threads <= 1 || n < 4096) {
+    f((size_t)0, n, 0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 1; t < threads; t++) {
+    const size_t a = std::min(n, chunk * (size_t)t), b = std::min(n, a + chunk);
+    if (a < b) pool.emplace_back([&f, a, b, t] { f(a, b, t); });
+  }
+  f((size_t)0, std::min(n, chunk), 0);
+  for (std::thread& th : pool) th.join();
+}
+
+struct BuildData {
+  const std::vector<Box>& boxes;
+  const std::vector<float>& cent;
+  std::vector<uint32_t>& order;
+};
+
+struct Bins {
+  Box bb[3][kBins];
+  uint32_t bc[3][kBins];
+  void reset() {
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < kBins; b++) {
+        bb[a][b].reset();
+        bc[a][b] = 0;
+      }
+  }
+};
+
+// Bounds of a node and the position of its split (0 = leaf).  `threads` > 1 shares the two O(count) scans.
+uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t depth, int threads, Box& nodeBox) {
+  const std::vector<Box>& boxes = B.boxes;
+  const std::vector<float>& cent = B.cent;
+  std::vector<uint32_t>& order = B.order;
+  Box nb, cb;
+  nb.reset();
+  cb.reset();
+  if (threads > 1 && count >= (1u << 16)) {
+    std::vector<Box> pn((size_t)threads), pc((size_t)threads);
+    for (int t = 0; t < threads; t++) {
+      pn[(size_t)t].reset();
+      pc[(size_t)t].reset();
+    }
+    parallelFor(count, threads, [&](size_t a, size_t b, int t) {
+      Box n0, c0;
+      n0.reset();
+      c0.reset();
+      for (size_t k = a; k < b; k++) {
+        const uint32_t tr = order[first + k];
+        n0.grow(boxes[tr]);
+        c0.grow(&cent[(size_t)tr * 3]);
+      }
+      pn[(size_t)t] = n0;
+      pc[(size_t)t] = c0;
+    });
+    for (int t = 0; t < threads; t++) {
+      nb.grow(pn[(size_t)t]);
+      cb.grow(pc[(size_t)t]);
+    }
+  } else {
+    for (uint32_t k = 0; k < count; k++) {
+      const uint32_t t = order[first + k];
+      nb.grow(boxes[t]);
+      cb.grow(&cent[(size_t)t * 3]);
+    }
+  }
+  nodeBox = nb;
+  if (count <= kLeafMax) return 0;
+
+  // Depth budget: once the remaining levels are only just enough for a balanced split of
+  // `count` triangles into leaves, stop trusting SAH and split at the median.
+  const bool forceMedian = depth + ceilLog2((count + kLeafMax - 1) / kLeafMax) + 1 >= (uint32_t)kBinaryMaxDepth;
+
+  int bestAxis = -1, bestSplit = -1;
+  float bestCost = 1e30f;
+  if (!forceMedian) {
+    float lo[3], scale[3];
+    bool use[3];
+    for (int axis = 0; axis < 3; axis++) {
+      const float ext = cb.hi[axis] - cb.lo[axis];
+      lo[axis] = cb.lo[axis];
+      use[axis] = ext > 0.0f;
+      scale[axis] = use[axis] ? (float)kBins / ext : 0.0f;
+    }
+    auto binRange = [&](size_t a, size_t b, Bins& bins) {
+      for (size_t k = a; k < b; k++) {
+        const uint32_t t = order[first + k];
+        for (int axis = 0; axis < 3; axis++) {
+          if (!use[axis]) continue;
+          int bi = (int)((cent[(size_t)t * 3 + axis] - lo[axis]) * scale[axis]);
+          bi = std::min(std::max(bi, 0), kBins - 1);
+          bins.bb[axis][bi].grow(boxes[t]);
+          bins.bc[axis][bi]++;
+        }
+      }
+    };
+    Bins bins;
+    bins.reset();
+    if (threads > 1 && count >= (1u << 16)) {
+      std::vector<Bins> part((size_t)threads);
+      for (Bins& pb : part) pb.reset();
+      parallelFor(count, threads, [&](size_t a, size_t b, int t) { binRange(a, b, part[(size_t)t]); });
+      for (const Bins& pb : part)
+        for (int axis = 0; axis < 3; axis++)
+          for (int b = 0; b < kBins; b++) {
+            bins.bb[axis][b].grow(pb.bb[axis][b]);
+            bins.bc[axis][b] += pb.bc[axis][b];
+          }
+    } else {
+      binRange(0, count, bins);
+    }
+    for (int axis = 0; axis < 3; axis++) {
+      if (!use[axis]) continue;
+      const Box* bb = bins.bb[axis];
+      const uint32_t* bc = bins.bc[axis];
+      float rightArea[kBins];
+      uint32_t rightCnt[kBins];
+      Box acc;
+      acc.reset();
+      uint32_t cnt = 0;
+      for (int b = kBins - 1; b > 0; b--) {
+        acc.grow(bb[b]);
+        cnt += bc[b];
+        rightArea[b] = acc.area();
+        rightCnt[b] = cnt;
+      }
+      acc.reset();
+      cnt = 0;
+      for (int b = 0; b < kBins - 1; b++) {
+        acc.grow(bb[b]);
+        cnt += bc[b];
+        if (cnt == 0 || rightCnt[b + 1] == 0) continue;
+        const float cost = acc.area() * (float)cnt + rightArea[b + 1] * (float)rightCnt[b + 1];
+        if (cost < bestCost) {
+          bestCost = cost;
+          bestAxis = axis;
+          bestSplit = b;
+        }
+      }
+    }
+  }
+  uint32_t mid = 0;
+  if (bestAxis >= 0) {
+    const float lo = cb.lo[bestAxis], ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+    const float scale = (float)kBins / ext;
+    auto goesLeft = [&](uint32_t t) {
+      int b = (int)((cent[(size_t)t * 3 + bestAxis] - lo) * scale);
+      b = std::min(std::max(b, 0), kBins - 1);
+      return b <= bestSplit;
+    };
+    // Two-pointer partition (the bidirectional algorithm of std::partition, spelled out so that the permutation is
+    // this file's own definition): every element is tested exactly once, at its original position.  For large nodes
+    // the tests — a cache-missing gather per triangle — are evaluated up front by all threads; the swaps stay serial.
+    uint32_t* lo_p = order.data() + first;
+    uint32_t* hi_p = lo_p + count;
+    uint32_t* const base = lo_p;
+    std::vector<uint8_t> flags;
+    if (threads > 1 && count >= (1u << 16)) {
+      flags.resize(count);
+      parallelFor(count, threads, [&](size_t a, size_t b, int) {
+        for (size_t k = a; k < b; k++) flags[k] = goesLeft(base[k]) ? 1 : 0;
+      });
+    }
+    const bool pre = !flags.empty();
+    auto test = [&](const uint32_t* q) { return pre ? flags[(size_t)(q - base)] != 0 : goesLeft(*q); };
+    for (;;) {
+      while (lo_p != hi_p && test(lo_p)) ++lo_p;
+      if (lo_p == hi_p) break;
+      --hi_p;
+      while (lo_p != hi_p && !test(hi_p)) --hi_p;
+      if (lo_p == hi_p) break;
+      std::swap(*lo_p, *hi_p);  // flags stay indexed by ORIGINAL position: both elements have been tested already
+      ++lo_p;
+    }
+    auto it = order.begin() + (lo_p - order.data());
+    mid = (uint32_t)(it - (order.begin() + first));
+  }
+  if (mid == 0 || mid == count) {
+    // median split on the widest centroid axis (also the degenerate all-equal case)
+    int axis = 0;
+    const float e0 = cb.hi[0] - cb.lo[0], e1 = cb.hi[1] - cb.lo[1], e2 = cb.hi[2] - cb.lo[2];
+    if (e1 > e0 && e1 >= e2) axis = 1;
+    if (e2 > e0 && e2 > e1) axis = 2;
+    mid = count / 2;
+    std::nth_element(order.begin() + first, order.begin() + first + mid, order.begin() + first + count, [&](uint32_t a, uint32_t b) {
+      const float ka = cent[(size_t)a * 3 + axis], kb = cent[(size_t)b * 3 + axis];
+      return ka < kb || (ka == kb && a < b);
+    });
+  }
+  return mid;
+}
+
+// Whole subtree under nodes[root] (its first / count / depth already set), depth first, appended to `nodes`.
+// Children are always created after their parent.
+void buildSubtree(const BuildData& B, std::vector<TmpNode>& nodes, uint32_t root, uint32_t splitBelow, int threads,
+                  std::vector<uint32_t>* deferred) {
+  std::vector<uint32_t> todo{root};
+  while (!todo.empty()) {
+    const uint32_t ni = todo.back();
+    todo.pop_back();
+    const uint32_t first = nodes[ni].first, count = nodes[ni].count, depth = nodes[ni].depth;
+    if (deferred && ni != root && count <= splitBelow) {  // small enough: some thread builds it later
+      deferred->push_back(ni);
+      continue;
+    }
+    Box nb;
+    const uint32_t mid = splitNode(B, first, count, depth, threads, nb);
+    nodes[ni].box = nb;
+    if (mid == 0) continue;
+    TmpNode l, r;
+    l.first = first;
+    l.count = mid;
+    l.depth = depth + 1;
+    r.first = first + mid;
+    r.count = count - mid;
+    r.depth = depth + 1;
+    const uint32_t li = (uint32_t)nodes.size();
+    nodes.push_back(l);
+    nodes.push_back(r);
+    nodes[ni].left = (int32_t)li;
+    nodes[ni].right = (int32_t)li + 1;
+    nodes[ni].count = 0;
+    todo.push_back(li + 1);
+    todo.push_back(li);
+  }
+}
+
 }  // namespace
 
-void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const uint32_t* triFlags, Bvh& out) {
+int bvhBuildThreads() {
+  if (const char* e = std::getenv("BDPT_BUILD_THREADS")) {
+    const int v = std::atoi(e);
+    if (v >= 1) return std::min(v, 256);
+  }
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // container CPU quota: "<quota> <period>" or "max <period>"
+    char q[64];
+    double period = 0;
+    if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+      n = std::min(n, std::max(1, (int)(std::atof(q) / period + 0.5)));
+    std::fclose(f);
+  }
+  return std::max(1, std::min(n, 64));
+}
+
+void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const uint32_t* triFlags, Bvh& out, int threads) {
+  if (threads <= 0) threads = bvhBuildThreads();
+  const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto tStart = now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    auto t = now();
+    std::fprintf(stderr, "[bvh] %-12s %.3f s\n", what, std::chrono::duration<double>(t - tStart).count());
+    tStart = t;
+  };
   out.nodes.clear();
   out.tris.clear();
   out.maxDepth = 0;
@@ -66,32 +341,42 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
   std::vector<float> cent((size_t)n * 3);
   Box scene;
   scene.reset();
-  for (uint32_t t = 0; t < n; t++) {
-    const float* a = positions + (size_t)indices[(size_t)t * 3] * 3;
-    const float* b = positions + (size_t)indices[(size_t)t * 3 + 1] * 3;
-    const float* c = positions + (size_t)indices[(size_t)t * 3 + 2] * 3;
-    BvhTri& r = recs[t];
-    float p1[3], p2[3];
-    for (int k = 0; k < 3; k++) {
-      r.v0[k] = a[k];
-      r.e1[k] = b[k] - a[k];
-      r.e2[k] = c[k] - a[k];
-      p1[k] = r.v0[k] + r.e1[k];
-      p2[k] = r.v0[k] + r.e2[k];
-    }
-    r.prim = t;
-    r.flags = triFlags ? triFlags[t] : 0u;
-    r.pad = 0;
-    Box bx;
-    bx.reset();
-    bx.grow(r.v0);
-    bx.grow(p1);
-    bx.grow(p2);
-    bx.grow(b);
-    bx.grow(c);
-    boxes[t] = bx;
-    for (int k = 0; k < 3; k++) cent[(size_t)t * 3 + k] = 0.5f * (bx.lo[k] + bx.hi[k]);
-    scene.grow(bx);
+  {
+    std::vector<Box> part((size_t)threads);
+    for (Box& b : part) b.reset();
+    parallelFor(n, threads, [&](size_t t0, size_t t1, int th) {
+      Box acc;
+      acc.reset();
+      for (size_t t = t0; t < t1; t++) {
+        const float* a = positions + (size_t)indices[t * 3] * 3;
+        const float* b = positions + (size_t)indices[t * 3 + 1] * 3;
+        const float* c = positions + (size_t)indices[t * 3 + 2] * 3;
+        BvhTri& r = recs[t];
+        float p1[3], p2[3];
+        for (int k = 0; k < 3; k++) {
+          r.v0[k] = a[k];
+          r.e1[k] = b[k] - a[k];
+          r.e2[k] = c[k] - a[k];
+          p1[k] = r.v0[k] + r.e1[k];
+          p2[k] = r.v0[k] + r.e2[k];
+        }
+        r.prim = (uint32_t)t;
+        r.flags = triFlags ? triFlags[t] : 0u;
+        r.pad = 0;
+        Box bx;
+        bx.reset();
+        bx.grow(r.v0);
+        bx.grow(p1);
+        bx.grow(p2);
+        bx.grow(b);
+        bx.grow(c);
+        boxes[t] = bx;
+        for (int k = 0; k < 3; k++) cent[t * 3 + (size_t)k] = 0.5f * (bx.lo[k] + bx.hi[k]);
+        acc.grow(bx);
+      }
+      part[(size_t)th].grow(acc);
+    });
+    for (const Box& b : part) scene.grow(b);
   }
   float diag = 0.0f;
   if (n) {
@@ -104,127 +389,74 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
 
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; i++) order[i] = i;
+  const BuildData B{boxes, cent, order};
+  lap("records");
 
+  // Phase 1: one thread splits the top of the tree (large nodes share their scans among all threads) and
+  // defers every subtree of at most `grain` triangles.  Phase 2: the deferred subtrees are built concurrently,
+  // largest first, each into its own node list.  Phase 3: the lists are appended; children stay after parents.
   std::vector<TmpNode> tmp;
   tmp.reserve((size_t)n / 2 + 16);
-  std::vector<uint32_t> todo;
   {
     TmpNode root;
     root.first = 0;
     root.count = n;
     root.depth = 0;
     tmp.push_back(root);
-    todo.push_back(0);
   }
-  while (!todo.empty()) {
-    uint32_t ni = todo.back();
-    todo.pop_back();
-    uint32_t first = tmp[ni].first, count = tmp[ni].count, depth = tmp[ni].depth;
-    Box nb, cb;
-    nb.reset();
-    cb.reset();
-    for (uint32_t k = 0; k < count; k++) {
-      uint32_t t = order[first + k];
-      nb.grow(boxes[t]);
-      cb.grow(&cent[(size_t)t * 3]);
-    }
-    tmp[ni].box = nb;
-    if (count <= kLeafMax) continue;
-
-    // Depth budget: once the remaining levels are only just enough for a balanced split of
-    // `count` triangles into leaves, stop trusting SAH and split at the median.
-    bool forceMedian = depth + ceilLog2((count + kLeafMax - 1) / kLeafMax) + 1 >= (uint32_t)kBinaryMaxDepth;
-
-    int bestAxis = -1, bestSplit = -1;
-    float bestCost = 1e30f;
-    if (!forceMedian) {
-      for (int axis = 0; axis < 3; axis++) {
-        float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
-        if (!(ext > 0.0f)) continue;
-        Box bb[kBins];
-        uint32_t bc[kBins];
-        for (int b = 0; b < kBins; b++) {
-          bb[b].reset();
-          bc[b] = 0;
+  if (threads <= 1 || n < (1u << 15)) {
+    buildSubtree(B, tmp, 0, 0, 1, nullptr);
+  } else {
+    const uint32_t grain = std::max<uint32_t>(4096, n / (uint32_t)(threads * 8));
+    std::vector<uint32_t> deferred;
+    buildSubtree(B, tmp, 0, grain, threads, &deferred);
+    lap("top");
+    std::sort(deferred.begin(), deferred.end(), [&](uint32_t a, uint32_t b) {
+      return tmp[a].count > tmp[b].count || (tmp[a].count == tmp[b].count && a < b);
+    });
+    std::vector<std::vector<TmpNode>> local(deferred.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&] {
+      for (;;) {
+        const size_t j = next.fetch_add(1);
+        if (j >= deferred.size()) return;
+        std::vector<TmpNode>& L = local[j];
+        L.reserve((size_t)tmp[deferred[j]].count / 2 + 4);
+        L.push_back(tmp[deferred[j]]);
+        buildSubtree(B, L, 0, 0, 1, nullptr);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+    worker();
+    for (std::thread& th : pool) th.join();
+    lap("subtrees");
+    for (size_t j = 0; j < deferred.size(); j++) {
+      const std::vector<TmpNode>& L = local[j];
+      const int32_t off = (int32_t)tmp.size() - 1;  // local index i >= 1 -> off + i
+      TmpNode rootNode = L[0];
+      if (rootNode.left >= 0) {
+        rootNode.left += off;
+        rootNode.right += off;
+      }
+      tmp[deferred[j]] = rootNode;
+      for (size_t i = 1; i < L.size(); i++) {
+        TmpNode nd = L[i];
+        if (nd.left >= 0) {
+          nd.left += off;
+          nd.right += off;
         }
-        float scale = (float)kBins / ext;
-        for (uint32_t k = 0; k < count; k++) {
-          uint32_t t = order[first + k];
-          int b = (int)((cent[(size_t)t * 3 + axis] - lo) * scale);
-          b = std::min(std::max(b, 0), kBins - 1);
-          bb[b].grow(boxes[t]);
-          bc[b]++;
-        }
-        float rightArea[kBins];
-        uint32_t rightCnt[kBins];
-        Box acc;
-        acc.reset();
-        uint32_t cnt = 0;
-        for (int b = kBins - 1; b > 0; b--) {
-          acc.grow(bb[b]);
-          cnt += bc[b];
-          rightArea[b] = acc.area();
-          rightCnt[b] = cnt;
-        }
-        acc.reset();
-        cnt = 0;
-        for (int b = 0; b < kBins - 1; b++) {
-          acc.grow(bb[b]);
-          cnt += bc[b];
-          if (cnt == 0 || rightCnt[b + 1] == 0) continue;
-          float cost = acc.area() * (float)cnt + rightArea[b + 1] * (float)rightCnt[b + 1];
-          if (cost < bestCost) {
-            bestCost = cost;
-            bestAxis = axis;
-            bestSplit = b;
-          }
-        }
+        tmp.push_back(nd);
       }
     }
-    uint32_t mid = 0;
-    if (bestAxis >= 0) {
-      float lo = cb.lo[bestAxis], ext = cb.hi[bestAxis] - cb.lo[bestAxis];
-      float scale = (float)kBins / ext;
-      auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-        int b = (int)((cent[(size_t)t * 3 + bestAxis] - lo) * scale);
-        b = std::min(std::max(b, 0), kBins - 1);
-        return b <= bestSplit;
-      });
-      mid = (uint32_t)(it - (order.begin() + first));
-    }
-    if (mid == 0 || mid == count) {
-      // median split on the widest centroid axis (also the degenerate all-equal case)
-      int axis = 0;
-      float e0 = cb.hi[0] - cb.lo[0], e1 = cb.hi[1] - cb.lo[1], e2 = cb.hi[2] - cb.lo[2];
-      if (e1 > e0 && e1 >= e2) axis = 1;
-      if (e2 > e0 && e2 > e1) axis = 2;
-      mid = count / 2;
-      std::nth_element(order.begin() + first, order.begin() + first + mid, order.begin() + first + count,
-                       [&](uint32_t a, uint32_t b) {
-                         float ka = cent[(size_t)a * 3 + axis], kb = cent[(size_t)b * 3 + axis];
-                         return ka < kb || (ka == kb && a < b);
-                       });
-    }
-    TmpNode l, r;
-    l.first = first;
-    l.count = mid;
-    l.depth = depth + 1;
-    r.first = first + mid;
-    r.count = count - mid;
-    r.depth = depth + 1;
-    uint32_t li = (uint32_t)tmp.size();
-    tmp.push_back(l);
-    tmp.push_back(r);
-    tmp[ni].left = (int32_t)li;
-    tmp[ni].right = (int32_t)li + 1;
-    tmp[ni].count = 0;
-    todo.push_back(li + 1);
-    todo.push_back(li);
   }
 
+  lap("append");
   // Leaf-ordered triangle list.
   out.tris.resize(n);
-  for (uint32_t i = 0; i < n; i++) out.tris[i] = recs[order[i]];
+  parallelFor(n, threads, [&](size_t a, size_t b, int) {
+    for (size_t i = a; i < b; i++) out.tris[i] = recs[order[i]];
+  });
 
   // ---- collapse the binary tree into four-wide nodes and quantise the child boxes ----------------
   auto leafRef = [](uint32_t first, uint32_t count) -> int32_t { return -1 - (int32_t)((first << 3) | (count - 1)); };
@@ -308,12 +540,13 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
         if (tmp[w.kids[k]].left >= 0) jobs.push_back(Job{w.kids[k], j.depth + 1, need, (int32_t)self, k});
     }
   }
+  lap("collapse");
   out.maxDepth = wDepth;
   out.maxStack = wStack;
   out.nodes.resize(wide.size());
   const float rootArea = tmp[0].box.area();
-  double cost = 0.0;
-  for (size_t wi = 0; wi < wide.size(); wi++) {
+  parallelFor(wide.size(), threads, [&](size_t w0, size_t w1, int) {
+  for (size_t wi = w0; wi < w1; wi++) {
     const Wide& w = wide[wi];
     BvhNode nd;
     std::memset(&nd, 0, sizeof(nd));
@@ -363,12 +596,20 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
     for (int k = 0; k < w.nk; k++) {
       const TmpNode& c = tmp[w.kids[k]];
       if (c.left < 0) nd.child[k] = leafRef(c.first, c.count);  // interior refs are patched below
-      if (rootArea > 0) cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
     }
     out.nodes[wi] = nd;
   }
+  });
+  double cost = 0.0;  // one thread, node order: the sum's rounding does not depend on the thread count
+  if (rootArea > 0)
+    for (size_t wi = 0; wi < wide.size(); wi++)
+      for (int k = 0; k < wide[wi].nk; k++) {
+        const TmpNode& c = tmp[wide[wi].kids[k]];
+        cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
+      }
   for (size_t wi = 1; wi < wide.size(); wi++) out.nodes[(size_t)slots[wi].first].child[slots[wi].second] = (int32_t)wi;
   out.sahCost = (float)cost + kCostTraverse;
+  lap("quantise");
 }
 
 }  // namespace bdpt

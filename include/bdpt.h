@@ -271,6 +271,12 @@ int bdpt_set_camera(bdpt_ctx* ctx, const bdpt_camera* cam);
  * first violated invariant in msg (msgCap bytes, may be NULL). */
 int bdpt_bvh_build_check(const bdpt_scene_desc* scene, bdpt_bvh_info* out, char* msg, uint32_t msgCap);
 
+/* Host-only test hook: build with `threads` host threads (0 = default: BDPT_BUILD_THREADS, else the CPUs this
+ * process may use) and return a 64-bit FNV-1a hash of the node array, the leaf-ordered triangle list and the
+ * summary; the tree must not depend on the thread count.  out_info may be NULL (its `reserved` field returns the
+ * default thread count). */
+int bdpt_bvh_build_hash(const bdpt_scene_desc* scene, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info);
+
 /* Camera::calculateCameraParameters (Graphics/Camera/Camera.cpp:129-136) with
  * fovY = focalLengthToFovY (Utils/Math/FalcorMath.h:148-151).  Host-only helper. */
 int bdpt_camera_look_at(const float pos[3], const float target[3], const float up[3], float focalLengthMm,

@@ -378,3 +378,24 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle/" not in txt and "oracle_binding" not in txt, os.path.join(dp, fn)
+
+
+@pytest.mark.parametrize("which", ["soup", "atrium", "courtyard", "cornell"])
+def test_bvh_build_does_not_depend_on_thread_count(pkg, which):
+    """The threaded host builder (bvh_build.cpp) must give the same tree — node array, leaf-ordered triangles, depth,
+    stack need, SAH cost — bit for bit whatever the number of threads; the hashes of the two full-size bench scenes'
+    trees are also pinned (they are what the committed profiles and visit counts were measured on)."""
+    lib = pkg.load_library()
+    scene = {"soup": lambda: pkg.Scene.soup(3, 90000, 0.05), "atrium": lambda: pkg.Scene.atrium(1, 262144),
+             "courtyard": lambda: pkg.Scene.courtyard(2, 300000, 0.5), "cornell": pkg.Scene.cornell}[which]()
+    hashes, infos = [], []
+    for threads in (1, 2, 3, 8):
+        h = C.c_uint64()
+        info = pkg.abi.BvhInfo()
+        assert lib.bdpt_bvh_build_hash(C.byref(scene.desc), threads, C.byref(h), C.byref(info)) == 0
+        hashes.append(h.value)
+        infos.append((info.numNodes, info.maxDepth, info.maxStack, info.sahCost))
+    assert len(set(hashes)) == 1 and len(set(infos)) == 1, (hashes, infos)
+    if which == "atrium":
+        assert hashes[0] == 0xa0fe769e7ca828eb and infos[0][0] == 39084
+    scene.close()

@@ -69,29 +69,32 @@ def load_traffic(scene, W, H, D, world):
 
 class TileRenderer:
     """This rank's share of the frame loop: one context for a whole frame, or — on the tiled path — several
-    contexts over the same row band, each with one frame in flight on its own stream."""
+    contexts over the same tile (interleaved stripes of rows), each with one frame in flight on its own stream."""
 
     def __init__(self, pkg, scene, W, H, D, mat, local_rank, world, rank, dist, tiled, inflight=0):
         import torch
         self.torch, self.pkg, self.dist, self.tiled = torch, pkg, dist, tiled
-        self.W, self.H = W, H
+        self.W, self.H, self.world, self.rank = W, H, world, rank
         self.dev = torch.device("cuda", local_rank)
-        # tile = contiguous band of rows; bands padded to equal height so reduce-scatter chunks are equal
-        rows = pkg.tiling.band_rows(H, world)
-        self.y0, self.y1 = pkg.tiling.band(H, world, rank)
-        # Frames in flight: a band leaves the chip underfilled (DESIGN.md section 5), so the tiled path keeps
+        # Frames in flight: a tile leaves the chip underfilled (DESIGN.md section 5), so the tiled path keeps
         # several frames going on separate streams/contexts; frames stay independent until the running mean,
         # which is applied in frame order.  One GPU rendering the whole frame is already full: one frame there.
         self.inflight = (inflight if inflight > 0 else 3) if tiled else 1
-        self.pipes = [pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, tile=(self.y0, self.y1),
+        # tile = this rank's stripes (pkg.tiling); the untiled N = 1 path renders the frame as one band
+        stripes = (pkg.tiling.stripe_rows(H, world), world, rank) if tiled else None
+        self.pipes = [pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, stripes=stripes,
                                         accum_limit=10000) for _ in range(self.inflight)]
         self.pipe = self.pipes[0]
         self.ctx = self.pipe.ctx
+        self.rows = self.pipe.rows
+        self.num_pixels = sum(b - a for a, b in self.rows) * W
         self.state = {"frame": 0, "accum": 0, "accum_event": None}
         if tiled:
+            info = self.ctx.tile_info()
+            self.exchange_bytes = int(info.splatU64) * 8  # what one rank hands to the reduce-scatter per frame
             self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.inflight)]
-            self.splat_full = [torch.zeros(rows * world * W * 4, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
-            self.splat_mine = [torch.zeros(rows * W * 4, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
+            self.splat_full = [torch.zeros(info.splatU64, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
+            self.splat_mine = [torch.zeros(info.chunkU64, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
             for pp, sf in zip(self.pipes, self.splat_full):
                 pp.ctx.set_splat_buffer(C.c_void_p(sf.data_ptr()), sf.numel())
         self.last_frame = self.pipe.last_frame  # the running mean is shared by all frames in flight
@@ -106,7 +109,6 @@ class TileRenderer:
             return
         i = f % self.inflight
         pp, s = self.pipes[i], self.streams[i]
-        y0, y1 = self.y0, self.y1
         pp.gbuffer_frame, pp.bdpt_frame = 0xdeadbeef + f, 0x1337 + f
         with torch.cuda.stream(s):
             # phase 1: everything that writes the splat buffer; then the exchange starts on RCCL's stream while
@@ -117,13 +119,12 @@ class TileRenderer:
             pp.ctx.execute_tail(p, pp.gb, C.c_void_p(pp.output.data_ptr()), st)
             if work is not None:
                 work.wait()
-            pp.ctx.resolve(C.c_void_p(self.splat_mine[i].data_ptr()), y0, C.c_void_p(pp.output.data_ptr()), st)
+            pp.ctx.resolve_tile(C.c_void_p(self.splat_mine[i].data_ptr()), C.c_void_p(pp.output.data_ptr()), st)
             if state["accum_event"] is not None:
                 s.wait_event(state["accum_event"])  # running mean in frame order
             n = state["accum"]
             state["accum"] += 1
-            pp.ctx.accumulate(C.c_void_p(self.last_frame[y0:y1].data_ptr()), C.c_void_p(pp.output[y0:y1].data_ptr()), n,
-                              pp.accum_limit, (y1 - y0) * self.W, st)
+            pp.ctx.accumulate_tile(C.c_void_p(self.last_frame.data_ptr()), C.c_void_p(pp.output.data_ptr()), n, pp.accum_limit, st)
             ev = torch.cuda.Event()
             ev.record(s)
             state["accum_event"] = ev
@@ -205,7 +206,7 @@ def main():
 
     R = TileRenderer(pkg, scene, W, H, D, mat, local_rank, world, rank, dist, tiled, args.inflight)
     pipes, pipe, ctx, inflight, state = R.pipes, R.pipe, R.ctx, R.inflight, R.state
-    y0, y1 = R.y0, R.y1
+    n_pix_tile = R.num_pixels
     step, barrier, rewind = R.step, R.barrier, R.rewind
     info = ctx.bvh_info()
     dev = R.dev
@@ -214,17 +215,7 @@ def main():
         for _ in range(args.dump_frames):
             step()
         barrier()
-        band = R.last_frame[y0:y1].contiguous()
-        if dist is not None:
-            rows = pkg.tiling.band_rows(H, world)
-            gdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # gloo gathers host tensors
-            padded = torch.zeros(rows, W, 4, dtype=torch.float32, device=gdev)
-            padded[: y1 - y0] = band.to(gdev)
-            parts = [torch.zeros_like(padded) for _ in range(world)]
-            dist.all_gather(parts, padded)
-            full = torch.cat(parts, 0)[:H]
-        else:
-            full = band
+        full = pkg.tiling.gather_frame(dist, torch, R.last_frame, H, world, rank) if tiled else R.last_frame
         if rank == 0:
             import numpy as np
             np.save(args.dump_path, full.cpu().numpy())
@@ -298,7 +289,7 @@ def main():
             if used == 0:
                 continue
             c = pp.ctx.counters().as_dict()
-            rays_total += sum(c[k] for k in RAY_KEYS) + used * (y1 - y0) * W
+            rays_total += sum(c[k] for k in RAY_KEYS) + used * n_pix_tile
 
     # ---- informational second pass at N = 1: the same K frames with three frames in flight (the tiled loop on one
     # band = the whole frame).  `value` stays the one-frame-in-flight figure the roofline durations belong to.
@@ -347,7 +338,7 @@ def main():
         # ---- roofline per kernel and for the whole frame.  Algorithmic bytes from the device tallies
         # of one frame of the same sequence; durations = HIP events on the launch stream around each kernel's launches
         # (bdpt_get_stage_times), summed over the frame, averaged over the frames named in stage_timing.
-        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), (y1 - y0) * W, info.nodeBytes, info.triBytes)
+        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, info.nodeBytes, info.triBytes)
         ms = {k: v / stage_frames for k, v in stage_ms.items()}
         kernel_ms = {
             "walk_kernel": ms.get("walk", 0.0),
@@ -400,8 +391,11 @@ def main():
                 if args.scene == "atrium" else "Cornell box, 32 triangles, Lambertian",
                 "resolution": [W, H], "max_depth": D, "spp_per_step": 1, "mat_index": mat,
                 "parallelism": "tile%d" % world,
+                "tiling": None if not tiled else {"stripe_rows": pkg.tiling.stripe_rows(H, world), "rows_this_rank": n_pix_tile // W,
+                                                  "exchange": "reduce_scatter_tensor(int64 SUM) of the owner-major splat buffer",
+                                                  "exchange_bytes_per_rank_per_frame": R.exchange_bytes},
                 "rays_per_frame": int(rays_all / K),
-                "rays_reference_equivalent_per_frame": int(stat["pixelsValid"] * ((D + 1) ** 2 - 1) + (y1 - y0) * W)
+                "rays_reference_equivalent_per_frame": int(stat["pixelsValid"] * ((D + 1) ** 2 - 1) + n_pix_tile)
                 if world == 1 else None,
                 "bvh": {"nodes": info.numNodes, "node_bytes": info.nodeBytes, "tri_bytes": info.triBytes,
                         "max_depth": info.maxDepth, "sah_cost": round(info.sahCost, 2)},

@@ -10,7 +10,7 @@ There is no CPU fallback anywhere in this package.
 import ctypes as C
 
 from . import abi, tiling
-from .abi import (Camera, Counters, GBuffer, GBufferParams, Params, SceneDesc, Tile, load_library)
+from .abi import (Camera, Counters, GBuffer, GBufferParams, Params, SceneDesc, Stripes, Tile, TileInfo, load_library)
 
 __all__ = ["abi", "tiling", "Scene", "Context", "FramePipeline", "load_library"]
 
@@ -129,6 +129,28 @@ class Context:
     def resize(self, width, height, y0, y1, max_depth):
         self._check(self._lib.bdpt_resize(self._h, width, height, Tile(y0, y1), max_depth), "bdpt_resize")
 
+    def resize_stripes(self, width, height, stripe_rows, num_owners, owner, max_depth):
+        self._check(self._lib.bdpt_resize_stripes(self._h, width, height, Stripes(stripe_rows, num_owners, owner), max_depth),
+                    "bdpt_resize_stripes")
+
+    def tile_info(self):
+        info = TileInfo()
+        self._check(self._lib.bdpt_get_tile_info(self._h, C.byref(info)), "bdpt_get_tile_info")
+        return info
+
+    def row_ranges(self):
+        n = self.tile_info().numRowRanges
+        buf = (C.c_uint32 * (2 * max(n, 1)))()
+        got = self._check(self._lib.bdpt_tile_row_ranges(self._h, buf, n), "bdpt_tile_row_ranges")
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(got)]
+
+    def resolve_tile(self, tile_splat_ptr, out_ptr, stream=None):
+        self._check(self._lib.bdpt_resolve_tile(self._h, tile_splat_ptr, out_ptr, stream), "bdpt_resolve_tile")
+
+    def accumulate_tile(self, last_ptr, cur_ptr, accum_count, max_count, stream=None):
+        self._check(self._lib.bdpt_accumulate_tile(self._h, last_ptr, cur_ptr, accum_count, max_count, stream),
+                    "bdpt_accumulate_tile")
+
     def gbuffer_execute(self, gparams, gbuffer, stream=None):
         self._check(self._lib.bdpt_gbuffer_execute(self._h, C.byref(gparams), C.byref(gbuffer), stream),
                     "bdpt_gbuffer_execute")
@@ -234,7 +256,7 @@ class FramePipeline:
     """
 
     def __init__(self, scene, width, height, max_depth=3, mat_index=0, device=0, tile=None, clamp_upper=0.9, min_t=1e-4,
-                 accum_limit=100, flags=0):
+                 accum_limit=100, flags=0, stripes=None):
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -250,7 +272,13 @@ class FramePipeline:
         self.ctx.set_scene(scene.desc)
         self.cam = scene.camera(self.W / self.H)
         self.ctx.set_camera(self.cam)
-        self.ctx.resize(self.W, self.H, self.y0, self.y1, self.max_depth)
+        # tile = (y0, y1): a contiguous band; stripes = (stripe_rows, num_owners, owner): interleaved stripes
+        self.stripes = stripes
+        if stripes is None:
+            self.ctx.resize(self.W, self.H, self.y0, self.y1, self.max_depth)
+        else:
+            self.ctx.resize_stripes(self.W, self.H, int(stripes[0]), int(stripes[1]), int(stripes[2]), self.max_depth)
+        self.rows = self.ctx.row_ranges()
         with torch.cuda.device(self.dev):
             self.channels = {"WorldPosition": torch.zeros(self.H, self.W, 4, dtype=torch.float32, device=self.dev)}
             for name in GBUFFER_CHANNELS[1:]:
@@ -315,8 +343,12 @@ class FramePipeline:
             n = self.accum_count if self.accum_count < self.accum_limit else self.accum_limit
             if self.accum_count < self.accum_limit:
                 self.accum_count += 1
-            self.ctx.accumulate(C.c_void_p(self.last_frame.data_ptr()), C.c_void_p(self.output.data_ptr()), n,
-                                self.accum_limit, self.W * self.H, st)
+            if self.stripes is None:
+                self.ctx.accumulate(C.c_void_p(self.last_frame.data_ptr()), C.c_void_p(self.output.data_ptr()), n,
+                                    self.accum_limit, self.W * self.H, st)
+            else:
+                self.ctx.accumulate_tile(C.c_void_p(self.last_frame.data_ptr()), C.c_void_p(self.output.data_ptr()), n,
+                                         self.accum_limit, st)
         self.last_params = (gp, p)
         return gp, p
 

@@ -88,6 +88,15 @@ class Tile(C.Structure):
     _fields_ = [("y0", C.c_uint32), ("y1", C.c_uint32)]
 
 
+class Stripes(C.Structure):
+    _fields_ = [("stripeRows", C.c_uint32), ("numOwners", C.c_uint32), ("owner", C.c_uint32)]
+
+
+class TileInfo(C.Structure):
+    _fields_ = [("numRows", C.c_uint32), ("numPixels", C.c_uint32), ("chunkRows", C.c_uint32), ("numRowRanges", C.c_uint32),
+                ("splatU64", C.c_uint64), ("chunkU64", C.c_uint64)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect",
@@ -125,6 +134,11 @@ PROTOTYPES = {
     "bdpt_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_execute_tail": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bdpt_resize_stripes": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, Stripes, C.c_uint32]),
+    "bdpt_get_tile_info": (C.c_int, [C.c_void_p, C.POINTER(TileInfo)]),
+    "bdpt_tile_row_ranges": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
+    "bdpt_resolve_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdpt_accumulate_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "bdpt_bvh_build_hash": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_uint64), C.POINTER(BvhInfo)]),
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

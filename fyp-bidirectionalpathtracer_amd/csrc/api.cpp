@@ -46,7 +46,12 @@ struct bdpt_ctx {
   bdpt_camera cam{};
   // frame
   uint32_t W = 0, H = 0, maxDepth = 0;
-  bdpt_tile tile{0, 0};
+  // the tile: which frame rows this context renders (a contiguous band, or the stripes of one owner) and where
+  // splat accumulators live (SplatLayout); rows in ascending order
+  std::vector<std::pair<uint32_t, uint32_t>> rowRanges;  // [first, last) runs of rows
+  uint32_t tileRows = 0;
+  SplatLayout sl{1, 1, 0};
+  bdpt_stripes stripes{0, 1, 0};  // stripeRows == 0: contiguous band (bdpt_resize)
   PathBuf P{};
   std::vector<void*> frameAllocs;
   unsigned long long* splat = nullptr;     // buffer in use (own or caller-provided)
@@ -530,21 +535,79 @@ int bdpt_set_camera(bdpt_ctx* c, const bdpt_camera* cam) {
   return BDPT_OK;
 }
 
+namespace {
+int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth);
+}
+
 int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, uint32_t maxDepth) {
   if (!c) return BDPT_E_INVALID;
   if (!width || !height || tile.y0 > tile.y1 || tile.y1 > height) {
     fail(c, "resize: bad frame or tile");
     return BDPT_E_INVALID;
   }
+  c->rowRanges.clear();
+  if (tile.y1 > tile.y0) c->rowRanges.push_back({tile.y0, tile.y1});
+  c->tileRows = tile.y1 - tile.y0;
+  c->stripes = bdpt_stripes{0, 1, 0};
+  c->sl = SplatLayout{1, 1, height};  // frame order
+  return resizeRows(c, width, height, maxDepth);
+}
+
+// Interleaved stripes: rows are dealt to `numOwners` contexts in stripes of `stripeRows`; this one
+// renders the stripes s with s % numOwners == owner.  The splat buffer becomes owner-major (bdpt_get_tile_info).
+int bdpt_resize_stripes(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_stripes st, uint32_t maxDepth) {
+  if (!c) return BDPT_E_INVALID;
+  if (!width || !height || !st.stripeRows || !st.numOwners || st.owner >= st.numOwners) {
+    fail(c, "resize_stripes: bad frame or stripe description");
+    return BDPT_E_INVALID;
+  }
+  c->rowRanges.clear();
+  c->tileRows = 0;
+  const uint32_t numStripes = (height + st.stripeRows - 1) / st.stripeRows;
+  for (uint32_t s = st.owner; s < numStripes; s += st.numOwners) {
+    const uint32_t a = s * st.stripeRows, b = std::min(height, a + st.stripeRows);
+    c->rowRanges.push_back({a, b});
+    c->tileRows += b - a;
+  }
+  c->stripes = st;
+  c->sl = SplatLayout{st.stripeRows, st.numOwners, ((numStripes + st.numOwners - 1) / st.numOwners) * st.stripeRows};
+  return resizeRows(c, width, height, maxDepth);
+}
+
+int bdpt_get_tile_info(const bdpt_ctx* c, bdpt_tile_info* out) {
+  if (!c || !out) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  out->numRows = c->tileRows;
+  out->numPixels = c->P.Np;
+  out->chunkRows = c->sl.chunkRows;
+  out->numRowRanges = (uint32_t)c->rowRanges.size();
+  out->splatU64 = (uint64_t)c->sl.owners * c->sl.chunkRows * c->W * 4;
+  out->chunkU64 = (uint64_t)c->sl.chunkRows * c->W * 4;
+  return BDPT_OK;
+}
+
+int bdpt_tile_row_ranges(const bdpt_ctx* c, uint32_t* out_first_last, uint32_t cap) {
+  if (!c || !out_first_last) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  const uint32_t n = std::min<uint32_t>(cap, (uint32_t)c->rowRanges.size());
+  for (uint32_t i = 0; i < n; i++) {
+    out_first_last[2 * i] = c->rowRanges[i].first;
+    out_first_last[2 * i + 1] = c->rowRanges[i].second;
+  }
+  return (int)n;
+}
+
+namespace {
+int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) {
   if (maxDepth > BDPT_MAX_DEPTH) {
     fail(c, "resize: maxDepth exceeds BDPT_MAX_DEPTH");
     return BDPT_E_LIMIT;
   }
-  if ((uint64_t)width * height >= (1ull << 32)) {
+  if ((uint64_t)width * height >= (1ull << 32) || (uint64_t)c->sl.owners * c->sl.chunkRows * width >= (1ull << 32)) {
     fail(c, "resize: frame too large");
     return BDPT_E_LIMIT;
   }
-  if ((uint64_t)(tile.y1 - tile.y0) * width >= (1ull << 24)) {
+  if ((uint64_t)c->tileRows * width >= (1ull << 24)) {
     fail(c, "resize: a tile holds at most 2^24 - 1 pixels (path ids pack the pixel in 24 bits); render in smaller tiles");
     return BDPT_E_LIMIT;
   }
@@ -558,13 +621,20 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   c->haveSize = false;
   c->W = width;
   c->H = height;
-  c->tile = tile;
   c->maxDepth = maxDepth;
   PathBuf P{};
-  P.Np = (tile.y1 - tile.y0) * width;
+  P.Np = c->tileRows * width;
   P.D1 = std::max<uint32_t>(maxDepth, 1) + 1;
   const size_t np = std::max<uint32_t>(P.Np, 1);
   int rc;
+  {
+    std::vector<uint32_t> pix;
+    pix.reserve(np);
+    for (const auto& rr : c->rowRanges)
+      for (uint32_t y = rr.first; y < rr.second; y++)
+        for (uint32_t x = 0; x < width; x++) pix.push_back(y * width + x);
+    if ((rc = devUpload(c, c->frameAllocs, &P.pix, pix.data(), pix.size()))) return rc;
+  }
   if ((rc = devAlloc(c, c->frameAllocs, &P.v, (size_t)2 * P.D1 * NF4 * 4 * np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.rayDir, (size_t)6 * np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.seedE, np))) return rc;
@@ -612,10 +682,11 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyCursor, np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyRay, (size_t)std::max<uint32_t>(batch, 1) * np))) return rc;
   }
-  if ((rc = devAlloc(c, c->frameAllocs, &c->ownSplat, (size_t)width * height * 4))) return rc;
+  const size_t splatU64 = (size_t)c->sl.owners * c->sl.chunkRows * width * 4;
+  if ((rc = devAlloc(c, c->frameAllocs, &c->ownSplat, splatU64))) return rc;
   c->splat = c->ownSplat;
   if ((rc = devAlloc(c, c->frameAllocs, &c->counters, 1))) return rc;
-  HIPCHK(c, hipMemset(c->splat, 0, (size_t)width * height * 4 * sizeof(unsigned long long)));
+  HIPCHK(c, hipMemset(c->splat, 0, splatU64 * sizeof(unsigned long long)));
   HIPCHK(c, hipMemset(c->counters, 0, sizeof(DevCounters)));
   c->P = P;
   if (!c->evCreated) {
@@ -625,6 +696,7 @@ int bdpt_resize(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_tile tile, ui
   c->haveSize = true;
   return BDPT_OK;
 }
+}  // namespace
 
 int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_gbuffer* out, void* stream) {
   if (!c || !gp || !out) return BDPT_E_INVALID;
@@ -644,8 +716,8 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
   G.gp = *gp;
   G.W = c->W;
   G.H = c->H;
-  G.y0 = c->tile.y0;
-  G.y1 = c->tile.y1;
+  G.Np = c->P.Np;
+  G.pix = c->P.pix;
   G.gb = *out;
   G.counters = nullptr;  // primary rays are tallied analytically by bdpt_get_counters (one per tile pixel)
   launchGBuffer(c->S, G, st);
@@ -694,8 +766,7 @@ int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float*
   F.p = *p;
   F.W = c->W;
   F.H = c->H;
-  F.y0 = c->tile.y0;
-  F.y1 = c->tile.y1;
+  F.sl = c->sl;
   F.out = out;
   F.splat = c->splat;
   F.gb = *in;
@@ -730,7 +801,7 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
     stageMark(c, st, "lazy_check");
   }
   if (!(p->flags & BDPT_PARAM_DEFER_RESOLVE)) {
-    launchResolve(c->splat, 0, F.out, c->W, c->tile.y0, c->tile.y1, st);
+    launchResolve(c->splat, false, 0, c->sl, F.out, c->W, c->P.pix, c->P.Np, st);
     stageMark(c, st, "resolve");
   }
   HIPCHK(c, hipGetLastError());
@@ -761,7 +832,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   c->numStages = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
   HIPCHK(c, hipMemsetAsync(P.qcount, 0, (size_t)kCursorWords * sizeof(uint32_t), st));
-  HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->W * c->H * 4 * sizeof(unsigned long long), st));
+  HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->sl.owners * c->sl.chunkRows * c->W * 4 * sizeof(unsigned long long), st));
   if (!(p->flags & BDPT_PARAM_KEEP_COUNTERS)) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(DevCounters), st));
   stageMark(c, st, "clear");
 
@@ -823,7 +894,7 @@ int bdpt_prepare(bdpt_ctx* c, uint32_t what) {
   if (what & BDPT_PREPARE_PRIMARY)
     if (int rc = allocOwnGbuffer(c)) return rc;
   if (what & BDPT_PREPARE_BMFR) {
-    if (c->tile.y0 != 0 || c->tile.y1 != c->H) {
+    if (c->tileRows != c->H) {
       fail(c, "prepare: the denoiser works on the whole frame; this context renders a band");
       return BDPT_E_STATE;
     }
@@ -839,7 +910,7 @@ int bdpt_bmfr_execute(bdpt_ctx* c, const bdpt_bmfr_params* p, const bdpt_gbuffer
     fail(c, "bmfr: bdpt_resize must be called first");
     return BDPT_E_STATE;
   }
-  if (c->tile.y0 != 0 || c->tile.y1 != c->H) {
+  if (c->tileRows != c->H) {
     fail(c, "bmfr: the denoiser works on the whole frame; this context renders a band");
     return BDPT_E_STATE;
   }
@@ -909,7 +980,7 @@ int bdpt_splat_buffer(bdpt_ctx* c, uint64_t** out_ptr, uint64_t* out_n) {
   if (!c || !out_ptr) return BDPT_E_INVALID;
   if (!c->haveSize) return BDPT_E_STATE;
   *out_ptr = reinterpret_cast<uint64_t*>(c->splat);
-  if (out_n) *out_n = (uint64_t)c->W * c->H * 4;
+  if (out_n) *out_n = (uint64_t)c->sl.owners * c->sl.chunkRows * c->W * 4;
   return BDPT_OK;
 }
 
@@ -920,8 +991,8 @@ int bdpt_set_splat_buffer(bdpt_ctx* c, uint64_t* device_ptr, uint64_t num_u64) {
     c->splat = c->ownSplat;
     return BDPT_OK;
   }
-  if (num_u64 < (uint64_t)c->W * c->H * 4) {
-    fail(c, "set_splat_buffer: buffer smaller than width*height*4");
+  if (num_u64 < (uint64_t)c->sl.owners * c->sl.chunkRows * c->W * 4) {
+    fail(c, "set_splat_buffer: buffer smaller than bdpt_get_tile_info's splatU64");
     return BDPT_E_INVALID;
   }
   c->splat = reinterpret_cast<unsigned long long*>(device_ptr);
@@ -931,13 +1002,24 @@ int bdpt_set_splat_buffer(bdpt_ctx* c, uint64_t* device_ptr, uint64_t num_u64) {
 int bdpt_resolve(bdpt_ctx* c, const uint64_t* splat, uint32_t splat_row0, float* out, void* stream) {
   if (!c || !splat || !out) return BDPT_E_INVALID;
   if (!c->haveSize) return BDPT_E_STATE;
-  if (splat_row0 > c->tile.y0) {
+  const uint32_t firstRow = c->rowRanges.empty() ? 0 : c->rowRanges.front().first;
+  if (splat_row0 > firstRow || (splat_row0 != 0 && c->sl.owners != 1)) {
     fail(c, "resolve: splat buffer does not cover the tile");
     return BDPT_E_INVALID;
   }
   ENTER(c);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  launchResolve(reinterpret_cast<const unsigned long long*>(splat), splat_row0, out, c->W, c->tile.y0, c->tile.y1, st);
+  launchResolve(reinterpret_cast<const unsigned long long*>(splat), false, splat_row0, c->sl, out, c->W, c->P.pix, c->P.Np, st);
+  HIPCHK(c, hipGetLastError());
+  return BDPT_OK;
+}
+
+int bdpt_resolve_tile(bdpt_ctx* c, const uint64_t* tile_splat, float* out, void* stream) {
+  if (!c || !tile_splat || !out) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  ENTER(c);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  launchResolve(reinterpret_cast<const unsigned long long*>(tile_splat), true, 0, c->sl, out, c->W, c->P.pix, c->P.Np, st);
   HIPCHK(c, hipGetLastError());
   return BDPT_OK;
 }
@@ -947,6 +1029,15 @@ int bdpt_accumulate(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_t acc
   if (!c || !lastFrame || !curFrame) return BDPT_E_INVALID;
   ENTER(c);
   launchAccumulate(lastFrame, curFrame, accumCount, maxAccumCount, numTexels, reinterpret_cast<hipStream_t>(stream));
+  HIPCHK(c, hipGetLastError());
+  return BDPT_OK;
+}
+
+int bdpt_accumulate_tile(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount, void* stream) {
+  if (!c || !lastFrame || !curFrame) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  ENTER(c);
+  launchAccumulateTile(lastFrame, curFrame, accumCount, maxAccumCount, c->P.pix, c->P.Np, reinterpret_cast<hipStream_t>(stream));
   HIPCHK(c, hipGetLastError());
   return BDPT_OK;
 }

@@ -75,6 +75,7 @@ inline __host__ __device__ uint32_t numConnectPairs(uint32_t D) {
 struct PathBuf {
   float* v;            // vertex records: ((path*D1 + k)*Np + p) * NF4 float4s
   float* rayDir;       // planes: (path*3 + axis)*Np + p
+  const uint32_t* pix; // tile-local pixel p -> full-frame pixel index y*W + x (the tile's rows, row-major)
   uint32_t* seedE;     // RNG state the eye walk draws from at every bounce (initRand of the pixel, quirk 1)
   uint32_t* seedL;     // RNG state after sampleLight
   uint8_t* eyeLast;    // last stored eye vertex (ghost included); 0 = pixel has no geometry
@@ -103,12 +104,25 @@ struct PathBuf {
   uint32_t Np, D1;
 };
 
+// Where a frame pixel's splat accumulator lives: owner-major, so that one reduce-scatter over ranks hands every
+// rank the accumulators of its own rows as one contiguous chunk.  Rows are dealt to `owners` ranks in stripes of
+// `stripeRows`; owner o's chunk holds its rows in order, padded to chunkRows.  owners == 1 is plain frame order.
+struct SplatLayout {
+  uint32_t stripeRows, owners, chunkRows;
+};
+inline __host__ __device__ size_t splatIndex(const SplatLayout& L, uint32_t W, uint32_t x, uint32_t y) {
+  const uint32_t s = y / L.stripeRows;
+  const uint32_t owner = s % L.owners, row = (s / L.owners) * L.stripeRows + (y - s * L.stripeRows);
+  return ((size_t)owner * L.chunkRows + row) * W + x;
+}
+
 struct FrameDev {
   bdpt_camera cam;
   bdpt_params p;
-  uint32_t W, H, y0, y1;
+  uint32_t W, H;
+  SplatLayout sl;
   float* out;                 // full-frame RGBA32F
-  unsigned long long* splat;  // full-frame 4 x u64
+  unsigned long long* splat;  // 4 x u64 per pixel, SplatLayout order
   bdpt_gbuffer gb;
   DevCounters* counters;
 };
@@ -116,7 +130,8 @@ struct FrameDev {
 struct GBufferDev {
   bdpt_camera cam;
   bdpt_gbuffer_params gp;
-  uint32_t W, H, y0, y1;
+  uint32_t W, H, Np;
+  const uint32_t* pix;  // the tile's pixels (PathBuf::pix)
   bdpt_gbuffer gb;
   DevCounters* counters;
 };
@@ -159,9 +174,13 @@ void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, 
                      uint32_t* nextList, uint32_t* nextCount, hipStream_t st);
 constexpr int kLazyBatchDiv = 8;    // a front round examines ceil(pairs / 8) candidates per pending pixel
 constexpr int kMaxLazyRounds = 8;   // cursor blocks reserved for lazy rounds  // rounds per frame; batch = ceil(pairs / rounds)
-void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
-                   hipStream_t st);
+// out[pix] = saturate(out[pix] + splat) for the tile's pixels.  tileLocal: `splat` holds the tile's accumulators in
+// tile-local order (a reduce-scattered chunk); otherwise SplatLayout order, starting at frame row splatRow0 (owners == 1).
+void launchResolve(const unsigned long long* splat, bool tileLocal, uint32_t splatRow0, const SplatLayout& L, float* out, uint32_t W,
+                   const uint32_t* pix, uint32_t Np, hipStream_t st);
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);
+void launchAccumulateTile(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, const uint32_t* pix, uint32_t Np,
+                          hipStream_t st);
 void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t draws, uint32_t* states, float* floats,
                    hipStream_t st);
 void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode, int32_t* prim, float* tuv, hipStream_t st);

@@ -160,11 +160,10 @@ BD float atan2_WAR(float y, float x) {  // CP lightProbeGBufferUtils.hlsli:45-58
 template <bool COUNT>
 __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G) {
   __shared__ int s_stack[kStackEntries * kWave];
-  const uint32_t Np = (G.y1 - G.y0) * G.W;
   const uint32_t p = blockIdx.x * kWave + threadIdx.x;
-  if (p >= Np) return;
-  const uint32_t x = p % G.W, y = G.y0 + p / G.W;
-  const size_t pix = (size_t)y * G.W + x;
+  if (p >= G.Np) return;
+  const size_t pix = G.pix[p];
+  const uint32_t y = (uint32_t)(pix / G.W), x = (uint32_t)(pix - (size_t)y * G.W);
 
   const f3 U = ld3(G.cam.cameraU), V = ld3(G.cam.cameraV), Wv = ld3(G.cam.cameraW), camPos = ld3(G.cam.posW);
   float pcx = ((float)x + G.gp.pixelJitter[0]) / (float)G.W;
@@ -229,7 +228,7 @@ template <bool GGX>
 __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev F, PathBuf P) {
   const uint32_t p = blockIdx.x * kWave + threadIdx.x;
   const bool inTile = p < P.Np;
-  const size_t pix = (size_t)F.y0 * F.W + p;
+  const size_t pix = inTile ? P.pix[p] : 0;
   bool geom = false;
   float4* out4 = reinterpret_cast<float4*>(F.out);
   if (inTile) {
@@ -747,7 +746,7 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
           float fy = rintf(py * (float)F.H - F.p.pixelJitter[1]);
           const bool inside = (fx >= 0.0f && fx < (float)F.W && fy >= 0.0f && fy < (float)F.H);
           if (inside) {
-            target = (uint32_t)(int)fy * F.W + (uint32_t)(int)fx;
+            target = (uint32_t)splatIndex(F.sl, F.W, (uint32_t)(int)fx, (uint32_t)(int)fy);
             float theta1 = saturate(fabsf(dot(dirToCamera, cameraN)));
             float theta2 = saturate(fabsf(dot(dirToCamera, lv.N)));
             float invDisToCamera = 1.0f / disToCamera;
@@ -862,7 +861,7 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
 // ------------------------------------------------------------------------------------------------
 BD bool gatherLane(const FrameDev& F, const PathBuf& P, uint32_t p, uint32_t& nSplat) {
   bool pending = false;
-  const size_t pix = (size_t)F.y0 * F.W + p;
+  const size_t pix = P.pix[p];
   float4* out4 = reinterpret_cast<float4*>(F.out);
   float4 acc = out4[pix];
   const int D = (int)F.p.maxDepth;
@@ -1013,7 +1012,7 @@ __global__ __launch_bounds__(kWave) void lazy_check_kernel(FrameDev F, PathBuf P
       if (id != kNoRay && P.rayVis[id]) vis = true;
     }
     if (vis) {
-      const size_t pix = (size_t)F.y0 * F.W + p;
+      const size_t pix = P.pix[p];
       float4* out4 = reinterpret_cast<float4*>(F.out);
       float4 acc = out4[pix];
       acc.x = saturate(acc.x + 0.0f);
@@ -1030,14 +1029,17 @@ __global__ __launch_bounds__(kWave) void lazy_check_kernel(FrameDev F, PathBuf P
 }
 
 // out = saturate(out + splat) where at least one splat landed
-__global__ void resolve_kernel(const unsigned long long* __restrict__ splat, uint32_t splatRow0, float4* __restrict__ out, uint32_t W,
-                               uint32_t y0, uint32_t y1) {
-  const size_t nTile = (size_t)(y1 - y0) * W;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < nTile; p += (size_t)gridDim.x * blockDim.x) {
-    const size_t pix = (size_t)y0 * W + p;
-    const size_t sidx = (pix - (size_t)splatRow0 * W) * 4;
-    const ulonglong2 a = reinterpret_cast<const ulonglong2*>(splat + sidx)[0];
-    const ulonglong2 b = reinterpret_cast<const ulonglong2*>(splat + sidx)[1];
+__global__ void resolve_kernel(const unsigned long long* __restrict__ splat, bool tileLocal, uint32_t splatRow0, SplatLayout L,
+                               float4* __restrict__ out, uint32_t W, const uint32_t* __restrict__ pixOf, uint32_t Np) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < Np; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = pixOf[p];
+    size_t sidx = p;
+    if (!tileLocal) {
+      const uint32_t y = (uint32_t)(pix / W), x = (uint32_t)(pix - (size_t)y * W);
+      sidx = splatIndex(L, W, x, y) - (size_t)splatRow0 * W;
+    }
+    const ulonglong2 a = reinterpret_cast<const ulonglong2*>(splat + sidx * 4)[0];
+    const ulonglong2 b = reinterpret_cast<const ulonglong2*>(splat + sidx * 4)[1];
     if (b.y == 0ull) continue;
     float4 o = out[pix];
     o.x = saturate(o.x + (float)a.x * 2.3283064365386963e-10f);
@@ -1052,6 +1054,27 @@ __global__ void resolve_kernel(const unsigned long long* __restrict__ splat, uin
 __global__ void accumulate_kernel(float4* __restrict__ last, float4* __restrict__ cur, uint32_t accumCount, uint32_t maxAccum,
                                   uint64_t numTexels) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numTexels; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float4 c = cur[i], pv = last[i];
+    float4 r;
+    if (accumCount < maxAccum) {
+      const float a = (float)accumCount, b = (float)(accumCount + 1);
+      r.x = (a * pv.x + c.x) / b;
+      r.y = (a * pv.y + c.y) / b;
+      r.z = (a * pv.z + c.z) / b;
+      r.w = (a * pv.w + c.w) / b;
+    } else {
+      r = pv;
+    }
+    cur[i] = r;
+    last[i] = r;
+  }
+}
+
+// the same running mean over a tile's pixels only (full-frame buffers, tile-local pixel list)
+__global__ void accumulate_tile_kernel(float4* __restrict__ last, float4* __restrict__ cur, uint32_t accumCount, uint32_t maxAccum,
+                                       const uint32_t* __restrict__ pixOf, uint32_t Np) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < Np; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = pixOf[p];
     const float4 c = cur[i], pv = last[i];
     float4 r;
     if (accumCount < maxAccum) {
@@ -1143,7 +1166,7 @@ static uint32_t persistentGrid(K kernel, int numCUs) {
 }
 
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st) {
-  const uint32_t Np = (G.y1 - G.y0) * G.W;
+  const uint32_t Np = G.Np;
   if (!Np) return;
   if (G.counters)
     hipLaunchKernelGGL(gbuffer_kernel<true>, dim3(blocksFor(Np)), dim3(kWave), 0, st, S, G);
@@ -1236,18 +1259,25 @@ void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, 
   hipLaunchKernelGGL(lazy_check_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, list, listCount, batch, nextList, nextCount);
 }
 
-void launchResolve(const unsigned long long* splat, uint32_t splatRow0, float* out, uint32_t W, uint32_t y0, uint32_t y1,
-                   hipStream_t st) {
-  const uint64_t n = (uint64_t)(y1 - y0) * W;
-  if (!n) return;
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, st, splat, splatRow0, reinterpret_cast<float4*>(out), W, y0, y1);
+void launchResolve(const unsigned long long* splat, bool tileLocal, uint32_t splatRow0, const SplatLayout& L, float* out, uint32_t W,
+                   const uint32_t* pix, uint32_t Np, hipStream_t st) {
+  if (!Np) return;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)Np + 255) / 256, 2048);
+  hipLaunchKernelGGL(resolve_kernel, dim3(grid), dim3(256), 0, st, splat, tileLocal, splatRow0, L, reinterpret_cast<float4*>(out), W, pix,
+                     Np);
 }
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st) {
   if (!numTexels) return;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((numTexels + 255) / 256, 2048);
   hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4*>(last),
                      reinterpret_cast<float4*>(cur), accumCount, maxAccum, numTexels);
+}
+void launchAccumulateTile(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, const uint32_t* pix, uint32_t Np,
+                          hipStream_t st) {
+  if (!Np) return;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)Np + 255) / 256, 2048);
+  hipLaunchKernelGGL(accumulate_tile_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4*>(last), reinterpret_cast<float4*>(cur),
+                     accumCount, maxAccum, pix, Np);
 }
 void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t draws, uint32_t* states, float* floats,
                    hipStream_t st) {

@@ -228,6 +228,24 @@ typedef struct bdpt_tile {
   uint32_t y1;
 } bdpt_tile;
 
+/* Interleaved stripes for multi-GPU hosts: the frame's rows are dealt to numOwners contexts in
+ * stripes of stripeRows rows; context `owner` renders stripes owner, owner + numOwners, ...  Cost that varies by
+ * row (sky above, geometry below) then spreads over all owners, which contiguous bands do not give. */
+typedef struct bdpt_stripes {
+  uint32_t stripeRows;
+  uint32_t numOwners;
+  uint32_t owner;
+} bdpt_stripes;
+
+typedef struct bdpt_tile_info {
+  uint32_t numRows;      /* rows this context renders */
+  uint32_t numPixels;    /* numRows * width */
+  uint32_t chunkRows;    /* rows of one owner's chunk of the splat buffer (its rows in order, zero-padded) */
+  uint32_t numRowRanges; /* contiguous row runs (stripes) of this tile */
+  uint64_t splatU64;     /* uint64 words of the whole splat buffer = numOwners * chunkU64 */
+  uint64_t chunkU64;     /* uint64 words of one owner's chunk = chunkRows * width * 4 */
+} bdpt_tile_info;
+
 typedef struct bdpt_counters {
   uint64_t raysPrimary;
   uint64_t raysEyeExtend;
@@ -290,6 +308,15 @@ void bdpt_msaa_jitter(uint32_t frameCounterBeforeIncrement, float out[2]);
  * [tile.y0, tile.y1) are rendered here, at up to maxDepth. */
 int bdpt_resize(bdpt_ctx* ctx, uint32_t width, uint32_t height, bdpt_tile tile, uint32_t maxDepth);
 
+/* bdpt_resize for a tile made of interleaved stripes.  The splat buffer of such a context is OWNER-MAJOR: chunk o
+ * (chunkU64 words, bdpt_tile_info) holds the accumulators of owner o's rows in row order, so a reduce-scatter over
+ * the numOwners ranks leaves every rank with the summed accumulators of exactly its own pixels, in tile-local
+ * order, ready for bdpt_resolve_tile.  (With bdpt_resize the buffer is in plain frame order.) */
+int bdpt_resize_stripes(bdpt_ctx* ctx, uint32_t width, uint32_t height, bdpt_stripes stripes, uint32_t maxDepth);
+int bdpt_get_tile_info(const bdpt_ctx* ctx, bdpt_tile_info* out);
+/* The tile's rows as [first, last) pairs in ascending order; writes up to cap pairs, returns how many. */
+int bdpt_tile_row_ranges(const bdpt_ctx* ctx, uint32_t* out_first_last, uint32_t cap);
+
 /* Allocate optional per-frame buffers ahead of time, so that no execute call allocates (hipGraph capture,
  * first-frame latency): the built-in primary stage's channels and/or the BMFR history.  Call after
  * bdpt_resize (a resize frees them again).  Replaces the lazy texture creation of
@@ -316,7 +343,8 @@ int bdpt_execute(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, fl
 int bdpt_execute_tail(bdpt_ctx* ctx, const bdpt_params* p, const bdpt_gbuffer* in, float* out, void* stream);
 
 /* Full-frame fixed-point splat accumulator: uint64[4] per pixel (r,g,b in
- * 2^-32 units, splat count), zeroed by every bdpt_execute before its splat stage.
+ * 2^-32 units, splat count) in frame order (bdpt_resize) or owner-major order (bdpt_resize_stripes),
+ * zeroed by every bdpt_execute before its splat stage.
  * Exposed so a multi-GPU host can sum it across ranks (integer sum: exact and
  * order-independent) before bdpt_resolve. */
 int bdpt_splat_buffer(bdpt_ctx* ctx, uint64_t** out_device_ptr, uint64_t* out_num_u64);
@@ -330,10 +358,18 @@ int bdpt_set_splat_buffer(bdpt_ctx* ctx, uint64_t* device_ptr, uint64_t num_u64)
  * tile rows at the same full-frame indexing (splat_row0 = first row it holds). */
 int bdpt_resolve(bdpt_ctx* ctx, const uint64_t* splat, uint32_t splat_row0, float* out, void* stream);
 
+/* The same for a buffer that holds the tile's accumulators in tile-local order (4 uint64 per tile pixel): one
+ * owner's chunk after the reduce-scatter of an owner-major splat buffer. */
+int bdpt_resolve_tile(bdpt_ctx* ctx, const uint64_t* tile_splat, float* out, void* stream);
+
 /* Running mean of accumulate.ps.hlsl:28-42 over `numTexels` RGBA32F texels:
  *   cur = accumCount < maxAccumCount ? (accumCount*last + cur)/(accumCount+1) : last;  last = cur. */
 int bdpt_accumulate(bdpt_ctx* ctx, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount,
                     uint64_t numTexels, void* stream);
+
+/* The same running mean restricted to this context's tile: lastFrame / curFrame are full-frame RGBA32F buffers, only
+ * the tile's pixels are read and written (one launch, whatever the number of stripes). */
+int bdpt_accumulate_tile(bdpt_ctx* ctx, float* lastFrame, float* curFrame, uint32_t accumCount, uint32_t maxAccumCount, void* stream);
 
 /* ---- BMFR denoiser (DenoisePass.*).  Works on the full frame: the context's tile must cover it. ---- */
 #define BDPT_BMFR_PREPROCESS 1u        /* mBMFR_preprocess, default on (DenoisePass.h:72) */

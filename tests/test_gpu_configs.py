@@ -241,3 +241,64 @@ def test_rccl_exchange_path_single_rank_reproduces_plain_run(pkg, tmp_path):
     a, b = np.load(plain), np.load(tiled)
     assert a.shape == (270, 480, 4) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.isfinite(a).all() and a[..., :3].mean() > 0.01
+
+
+def _stripes_equal_full(pkg, scene, W, H, depth, mat, world):
+    """`world` contexts rendering interleaved stripes (bdpt_resize_stripes) with owner-major splat buffers; the
+    integer sum of the buffers (what the reduce-scatter computes), each owner's chunk resolved with
+    bdpt_resolve_tile, reproduces the single-context frame bit for bit."""
+    import torch
+    full = pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat)
+    full.render_frame()
+    torch.cuda.synchronize()
+    ref = full.output.cpu().numpy()
+    full.close()
+    R = pkg.tiling.stripe_rows(H, world)
+    pipes = [pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat, stripes=(R, world, r)) for r in range(world)]
+    total = None
+    for r, pp in enumerate(pipes):
+        assert pp.rows == pkg.tiling.stripes_of(H, world, r)
+        info = pp.ctx.tile_info()
+        assert info.chunkRows == pkg.tiling.chunk_rows(H, world) and info.splatU64 == world * info.chunkU64
+        buf = torch.zeros(info.splatU64, dtype=torch.int64, device="cuda")
+        pp.ctx.set_splat_buffer(C.c_void_p(buf.data_ptr()), buf.numel())
+        _, p = pp.render_frame(extra_flags=pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
+        torch.cuda.synchronize()
+        snap = buf.clone()
+        pp.ctx.execute_tail(p, pp.gb, C.c_void_p(pp.output.data_ptr()), pp._stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(snap, buf)  # phase 2 must not touch the splat buffer
+        total = snap if total is None else total + snap
+        pp._keep = buf
+    img = np.zeros_like(ref)
+    for r, pp in enumerate(pipes):
+        n = pp.ctx.tile_info().chunkU64
+        chunk = total[r * n:(r + 1) * n].contiguous()
+        pp.ctx.resolve_tile(C.c_void_p(chunk.data_ptr()), C.c_void_p(pp.output.data_ptr()))
+        torch.cuda.synchronize()
+        out = pp.output.cpu().numpy()
+        for a, b in pp.rows:
+            img[a:b] = out[a:b]
+        pp.close()
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{(img != ref).any(axis=-1).sum()} pixels differ"
+    return ref
+
+
+def test_striped_tiles_equal_full_frame(pkg):
+    """Interleaved stripes incl. a partial last stripe, more owners than stripes (an owner with an EMPTY tile), and
+    the 8-owner split of a 1080p-shaped frame."""
+    cornell, atrium = pkg.Scene.cornell(), pkg.Scene.atrium(2, 20000)
+    _stripes_equal_full(pkg, cornell, 40, 37, 4, 0, 3)
+    _stripes_equal_full(pkg, cornell, 24, 3, 3, 1, 4)       # 3 rows, 4 owners: owner 3 renders nothing
+    _stripes_equal_full(pkg, atrium, 192, 108, 5, 0, 8)
+    cornell.close()
+    atrium.close()
+
+
+def test_config4_full_size_stripes_equal_full_frame(pkg):
+    """configs[3] shape (Bistro-class: 2.8 M triangles, 3840x2160, depth 12) tiled the way the 8-GPU run tiles it:
+    eight owners' interleaved stripes + the exact integer sum of their owner-major splat buffers == the full frame."""
+    scene = pkg.Scene.atrium(1, 2_800_000)
+    img = _stripes_equal_full(pkg, scene, 3840, 2160, 12, 0, 8)
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.01
+    scene.close()

@@ -1,9 +1,9 @@
-"""world_size-2 gloo test of the N>1 path on CPU: tile split, splat exchange, resolve.
+"""world_size-2 (and 3, 5) gloo test of the N>1 path on CPU: stripe tiles, owner-major splat exchange, resolve, gather.
 
-Each rank renders its row band with the ORACLE (there is no GPU here; the oracle is the checker
-and, in this test only, also the stand-in renderer), sums the fixed-point splat buffers through
-the package's tiling.exchange_splats over torch.distributed (gloo), resolves its band, and the
-gathered frame must be bit-identical to the single-rank golden image.
+Each rank renders its interleaved stripes with the ORACLE (there is no GPU here; the oracle is the checker
+and, in this test only, also the stand-in renderer), lays its fixed-point splats out owner-major, sums them through
+the package's tiling.exchange_splats over torch.distributed (gloo), resolves its stripes, and the frame assembled
+by tiling.gather_frame must be bit-identical to the single-rank golden image.
 """
 import os
 import sys
@@ -35,35 +35,53 @@ def _worker(rank, world, port, q):
     scene = pkg.Scene.cornell()
     cam = mg.camera_from_array(pkg, gold["cornell_camera"])
     gp, p = mg.frame_params(pkg, 0, 3, 0)
-    rows = pkg.tiling.band_rows(H, world)
-    y0, y1 = pkg.tiling.band(H, world, rank)
-    orc = ob.OracleRender(pkg.abi, scene.desc, W, H, y0, y1)
-    orc.gbuffer(cam, gp, threads=2)
-    orc.bdpt(cam, p, threads=2)
-    full = torch.zeros(rows * world * W * 4, dtype=torch.int64)
-    full[: W * H * 4] = torch.from_numpy(orc.splat.reshape(-1).view(np.int64).copy())
-    mine = torch.zeros(rows * W * 4, dtype=torch.int64)
+    # this rank's tile = interleaved stripes (what bench.py's N > 1 path renders); the oracle takes one row range at a
+    # time, so there is one OracleRender per stripe and their frame-order splat buffers add up
+    t = pkg.tiling
+    mine_rows = t.stripes_of(H, world, rank)
+    chunk = t.chunk_rows(H, world) * W * 4
+    orcs = []
+    frame_splat = np.zeros((W * H, 4), np.uint64)
+    for (ya, yb) in mine_rows:
+        orc = ob.OracleRender(pkg.abi, scene.desc, W, H, ya, yb)
+        orc.gbuffer(cam, gp, threads=2)
+        orc.bdpt(cam, p, threads=2)
+        frame_splat += orc.splat
+        orcs.append(orc)
+    # frame order -> owner-major (the layout bdpt_resize_stripes gives the HIP path's splat buffer)
+    full = torch.zeros(world * chunk, dtype=torch.int64)
+    fs = torch.from_numpy(frame_splat.reshape(H, W * 4).view(np.int64).copy())
+    for r in range(world):
+        at = r * chunk
+        for (ya, yb) in t.stripes_of(H, world, r):
+            n = (yb - ya) * W * 4
+            full[at:at + n] = fs[ya:yb].reshape(-1)
+            at += n
+    mine = torch.zeros(chunk, dtype=torch.int64)
     if world == 3:  # the entry point bench.py uses; synchronous on gloo, so it returns no handle
-        assert pkg.tiling.exchange_splats_async(dist, full, mine) is None
+        assert t.exchange_splats_async(dist, full, mine) is None
     else:
-        pkg.tiling.exchange_splats(dist, full, mine)
-    n = (y1 - y0) * W * 4
-    orc.splat.reshape(-1)[y0 * W * 4: y0 * W * 4 + n] = mine.numpy().view(np.uint64)[:n]
-    orc.resolve()
-    band = torch.zeros(rows, W, 4, dtype=torch.float32)
-    band[: y1 - y0] = torch.from_numpy(orc.image()[y0:y1].copy())
-    parts = [torch.zeros_like(band) for _ in range(world)]
-    dist.all_gather(parts, band)  # "tile framebuffers gathered"
+        t.exchange_splats(dist, full, mine)
+    image = torch.zeros(H, W, 4, dtype=torch.float32)
+    at = 0
+    for orc, (ya, yb) in zip(orcs, mine_rows):
+        n = (yb - ya) * W * 4
+        orc.splat[:] = 0
+        orc.splat.reshape(-1)[ya * W * 4: ya * W * 4 + n] = mine.numpy().view(np.uint64)[at:at + n]
+        at += n
+        orc.resolve()
+        image[ya:yb] = torch.from_numpy(orc.image()[ya:yb].copy())
+        orc.close()
+    gathered = t.gather_frame(dist, torch, image, H, world, rank)  # "tile framebuffers gathered"
     if rank == 0:
-        img = torch.cat(parts, 0)[:H].numpy()
+        img = gathered.numpy()
         ok = np.array_equal(img.view(np.uint32), gold["cornell64_d3_ggx_image"].view(np.uint32))
         q.put(bool(ok))
-    orc.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_two_rank_tiled_frame_equals_single_rank(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -342,8 +342,9 @@ def main():
         ms = {k: v / stage_frames for k, v in stage_ms.items()}
         kernel_ms = {
             "walk_kernel": ms.get("walk", 0.0),
-            "trace_shadow_kernel": ms.get("trace_shadow", 0.0) + ms.get("lazy_trace", 0.0),
-            "gen_kernels": ms.get("gen_shadow", 0.0) + ms.get("lazy_gen", 0.0),
+            # trace_terms runs beside gen_connect_kernel (second stream); trace_pairs starts when both are done
+            "trace_shadow_kernel": ms.get("trace_terms", 0.0) + ms.get("trace_pairs", 0.0) + ms.get("lazy_trace", 0.0),
+            "gen_kernels": ms.get("gen_terms", 0.0) + ms.get("lazy_gen", 0.0),
             "per_pixel_kernels": ms.get("clear", 0.0) + ms.get("init_paths", 0.0) + ms.get("gather", 0.0) +
                                  ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0),
         }

@@ -31,7 +31,7 @@ constexpr int kMaxStages = 64;
 constexpr size_t kCountBlocks = 1;  // lengths of the valid-pixel lists
 constexpr size_t kHeadBlocks = 2;   // fetch cursors of the walk kernel: pixel list x {eye, light}
 constexpr size_t kLazyBlocks = kMaxLazyRounds + 2;
-constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks + 2) * kCursorBlock;
+constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks + 4) * kCursorBlock;  // + ray count / head blocks of two classes
 }
 
 struct bdpt_ctx {
@@ -460,13 +460,14 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
       return b;
     }
     const BvhNode& n = bvh.nodes[(size_t)ref];
-    if (n.numChildren < 1 || n.numChildren > 4 || stackAbove + n.numChildren - 1 > (uint32_t)kBvhMaxStack) {
+    const uint32_t numChildren = (uint32_t)bvhNumChildren(n);
+    if (numChildren < 1 || numChildren > 4 || stackAbove + numChildren - 1 > (uint32_t)kBvhMaxStack) {
       ok = false;
       why = "bad child count or stack bound";
       return b;
     }
     for (int c = 0; c < 4; c++) {
-      if (c >= n.numChildren) {
+      if (c >= (int)numChildren) {
         for (int k = 0; k < 3; k++)
           if (!(n.lo[k][c] == 255 && n.hi[k][c] == 0)) {
             ok = false;
@@ -474,7 +475,7 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
           }
         continue;
       }
-      Bounds cb = walk(n.child[c], depth + 1, stackAbove + n.numChildren - 1);
+      Bounds cb = walk(n.child[c], depth + 1, stackAbove + numChildren - 1);
       for (int k = 0; k < 3; k++) {
         if (cb.lo[k] < bvhDecodePlane(n, k, n.lo[k][c]) || cb.hi[k] > bvhDecodePlane(n, k, n.hi[k][c])) {
           ok = false;
@@ -651,20 +652,24 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
   P.qhead = P.qcount + kCountBlocks * kCursorBlock;
   P.lazyCount = P.qhead + kHeadBlocks * kCursorBlock;
   P.rayCount = P.lazyCount + kLazyBlocks * kCursorBlock;
-  P.rayHead = P.rayCount + kCursorBlock;
+  P.rayHead = P.rayCount + 2 * kCursorBlock;
   {
     // one shadow ray per NEE term, per splat term and per defined connection pair, at most
     const uint32_t D = std::max<uint32_t>(maxDepth, 1);
     const uint64_t slots = (uint64_t)2 * D + numConnectPairs(D);
     // workgroup b appends to sub-queue b % kNumSubQueues: size each for the workgroups it serves
     const uint64_t blocks = (np + kWave - 1) / kWave;
-    const uint64_t subCap = ((blocks + kNumSubQueues - 1) / kNumSubQueues) * kWave * slots;
-    const uint64_t cap = subCap * kNumSubQueues;
-    P.raySubCap = (uint32_t)subCap;
+    const uint64_t perSub = ((blocks + kNumSubQueues - 1) / kNumSubQueues) * kWave;  // pixels one sub-queue serves
+    const uint64_t subCapTerms = perSub * 2 * D, subCapPairs = perSub * std::max<uint32_t>(numConnectPairs(D), 1);
+    const uint64_t cap = (subCapTerms + subCapPairs) * kNumSubQueues;
     if (cap >= (1ull << 32) - 1) {
       fail(c, "resize: shadow-ray queue would exceed 2^32 entries; render in smaller tiles");
       return BDPT_E_LIMIT;
     }
+    P.raySubCap[RAY_TERMS] = (uint32_t)subCapTerms;
+    P.raySubCap[RAY_PAIRS] = (uint32_t)subCapPairs;
+    P.rayBase[RAY_TERMS] = 0;
+    P.rayBase[RAY_PAIRS] = (uint32_t)(subCapTerms * kNumSubQueues);
     P.rayCap = (uint32_t)cap;
     if ((rc = devAlloc(c, c->frameAllocs, &P.rayQ, (size_t)7 * cap))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.rayContrib, (size_t)3 * cap))) return rc;
@@ -791,10 +796,11 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
       left -= batch;
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
-      HIPCHK(c, hipMemsetAsync(P.rayCount, 0, (size_t)2 * kCursorBlock * sizeof(uint32_t), st));
+      HIPCHK(c, hipMemsetAsync(P.rayCount + (size_t)RAY_PAIRS * kCursorBlock, 0, kCursorBlock * sizeof(uint32_t), st));
+      HIPCHK(c, hipMemsetAsync(P.rayHead + (size_t)RAY_PAIRS * kCursorBlock, 0, kCursorBlock * sizeof(uint32_t), st));
       launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
       stageMark(c, st, "lazy_gen");
-      launchTraceShadow(c->S, F, P, c->grids, c->numCUs, st);
+      launchTraceShadow(c->S, F, P, RAY_PAIRS, c->grids, c->numCUs, st);
       stageMark(c, st, "lazy_trace");
       launchLazyCheck(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, next, P.lazyCount + (size_t)(r + 1) * kCursorBlock, st);
     }
@@ -844,26 +850,32 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   launchWalk(c->S, F, P, c->grids, c->numCUs, st);
   stageMark(c, st, "walk");
 
-  // The three generators only share the ray queue (atomic appends): the connection generator (the long one)
-  // stays on the caller's stream, NEE and splat terms are generated beside it on the context's second stream.
+  // NEE and splat terms are generated on the caller's stream and traced at once (ray class RAY_TERMS) while the
+  // connection generator — the long one — fills the RAY_PAIRS queue on the context's second stream; the connection
+  // rays are traced when both are done.  (The MIS weights read both paths: everything sequential then.)
   const bool mis = (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) != 0;
   if (mis) {
     launchMisPrefix(F, P, st);
     launchGenNee(c->S, F, P, st);
     launchGenSplat(c->S, F, P, st);
     launchGenConnect(c->S, F, P, st);
+    stageMark(c, st, "gen_terms");
+    launchTraceShadow(c->S, F, P, RAY_TERMS, c->grids, c->numCUs, st);
+    stageMark(c, st, "trace_terms");
   } else {
     HIPCHK(c, hipEventRecord(c->evFork, st));
     HIPCHK(c, hipStreamWaitEvent(c->walkStream, c->evFork, 0));
-    launchGenNee(c->S, F, P, c->walkStream);
-    launchGenSplat(c->S, F, P, c->walkStream);
-    launchGenConnect(c->S, F, P, st);
+    launchGenConnect(c->S, F, P, c->walkStream);
     HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
+    launchGenNee(c->S, F, P, st);
+    launchGenSplat(c->S, F, P, st);
+    stageMark(c, st, "gen_terms");
+    launchTraceShadow(c->S, F, P, RAY_TERMS, c->grids, c->numCUs, st);
+    stageMark(c, st, "trace_terms");
     HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
   }
-  stageMark(c, st, "gen_shadow");
-  launchTraceShadow(c->S, F, P, c->grids, c->numCUs, st);
-  stageMark(c, st, "trace_shadow");
+  launchTraceShadow(c->S, F, P, RAY_PAIRS, c->grids, c->numCUs, st);
+  stageMark(c, st, "trace_pairs");
   launchGather(F, P, P.queue[1], P.lazyCount, st);
   stageMark(c, st, "gather");
   // Everything that touches the splat buffer is enqueued by now: a tiled host may start its exchange here

@@ -9,22 +9,28 @@
 namespace bdpt {
 
 // 64-byte four-child node with child boxes quantised to 8 bits per plane relative to the node's
-// own box: plane = origin[axis] + q * 2^(exp[axis]-127).  Quantisation rounds outward, so a
+// own box: plane = origin[axis] + q * scale[axis], scale a power of two.  Quantisation rounds outward, so a
 // decoded child box always contains the (already padded) exact one.  One node = four 16-byte
 // loads per lane, the same as a two-child fp32 node, for half the dependent fetches per ray.
 //   ref >= 0 : interior node index
 //   ref <  0 : leaf, -1 - ((firstTriangle << 3) | (count - 1)), count in 1..8
 // Unused child slots have lo = 255, hi = 0 on every axis (never entered: the slab test picks
 // near/far planes by ray direction sign, so an inverted box has tnear > tfar).
+// (The scales are stored as ready-to-use floats, not as exponent bytes: the node visit is bound by VALU issue and the
+// decode cost six instructions per visit; the child count is implied by the inverted boxes of unused slots.)
 struct alignas(16) BvhNode {
   float origin[3];
-  uint8_t exp[3];
-  uint8_t numChildren;
+  float scale[3];    // 2^e per axis
   uint8_t lo[3][4];  // [axis][child]
   uint8_t hi[3][4];
-  uint32_t pad[2];
   int32_t child[4];
 };
+inline int bvhNumChildren(const BvhNode& n) {
+  int k = 0;
+  for (int c = 0; c < 4; c++)
+    if (!(n.lo[0][c] == 255 && n.hi[0][c] == 0 && n.lo[1][c] == 255 && n.hi[1][c] == 0 && n.lo[2][c] == 255 && n.hi[2][c] == 0)) k = c + 1;
+  return k;
+}
 static_assert(sizeof(BvhNode) == 64, "node must be 64 bytes");
 
 // 48-byte leaf triangle as intersected: v0, e1 = v1 - v0, e2 = v2 - v0 (+ ids in the w lanes).
@@ -63,13 +69,6 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTrian
 int bvhBuildThreads();
 
 // Decode one quantised plane exactly as the device does.
-inline float bvhDecodePlane(const BvhNode& n, int axis, uint8_t q) {
-  union {
-    uint32_t u;
-    float f;
-  } s;
-  s.u = (uint32_t)n.exp[axis] << 23;
-  return n.origin[axis] + (float)q * s.f;
-}
+inline float bvhDecodePlane(const BvhNode& n, int axis, uint8_t q) { return n.origin[axis] + (float)q * n.scale[axis]; }
 
 }  // namespace bdpt

@@ -475,7 +475,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
         nd.hi[a][c] = 0;
       }
     for (int c = 0; c < 4; c++) nd.child[c] = -1;
-    nd.exp[0] = nd.exp[1] = nd.exp[2] = 127;
+    nd.scale[0] = nd.scale[1] = nd.scale[2] = 1.0f;
     out.nodes.push_back(nd);
     return;
   }
@@ -569,7 +569,14 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
       int biased = e + 127;
       if (biased < 1) biased = 1;
       if (biased > 254) biased = 254;
-      nd.exp[a] = (uint8_t)biased;
+      {
+        union {
+          uint32_t u;
+          float f;
+        } sc0;
+        sc0.u = (uint32_t)biased << 23;
+        nd.scale[a] = sc0.f;
+      }
       for (int k = 0; k < 4; k++) {
         if (k >= w.nk) {
           nd.lo[a][k] = 255;
@@ -591,7 +598,6 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
         nd.hi[a][k] = (uint8_t)qh;
       }
     }
-    nd.numChildren = (uint8_t)w.nk;
     for (int k = 0; k < 4; k++) nd.child[k] = -1;
     for (int k = 0; k < w.nk; k++) {
       const TmpNode& c = tmp[w.kids[k]];

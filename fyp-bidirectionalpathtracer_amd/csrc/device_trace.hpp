@@ -68,24 +68,23 @@ BD void travPush(TravState& T, int* stk, int ref) {
 
 BD float ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  // v_cvt_f32_ubyteN
 
-// One visit of a four-wide node with 8-bit quantised child boxes (bvh.h): plane = origin + q*scale,
-// so t = fma(q, scale*idir, (origin - o)*idir) — one convert and one fma per plane.  Near/far plane
+// One visit of a four-wide node with 8-bit quantised child boxes (bvh.h): plane = origin + q*scale (scale stored as
+// a float), so t = fma(q, scale*idir, (origin - o)*idir) — one convert and one fma per plane.  Near/far plane
 // bytes are picked per axis by the ray's direction sign (one select per axis for all four children).
-// ORDERED (closest hit): children are entered nearest first; otherwise in slot order.
-template <bool ORDERED>
+// ORDER 1 (closest hit): children are entered nearest first, the rest stacked far to near; ORDER 2: the nearest is
+// entered, the rest stacked in slot order; ORDER 0 (any hit): slot order.
+template <int ORDER>
 BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
   const uint4* np = reinterpret_cast<const uint4*>(S.nodes) + (size_t)T.cur * 4;
-  const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-  const uint4 q3 = np[3];
-  const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23),
-              sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
-  const float ax = sx * T.idir.x, ay = sy * T.idir.y, az = sz * T.idir.z;
+  const uint4 q0 = np[0], q1 = np[1], q2 = np[2];  // origin.xyz scale.x | scale.yz lo.x lo.y | lo.z hi.xyz
+  const uint4 q3 = np[3];                          // child refs
+  const float ax = __uint_as_float(q0.w) * T.idir.x, ay = __uint_as_float(q1.x) * T.idir.y, az = __uint_as_float(q1.y) * T.idir.z;
   const float bx = (__uint_as_float(q0.x) - T.o.x) * T.idir.x, by = (__uint_as_float(q0.y) - T.o.y) * T.idir.y,
               bz = (__uint_as_float(q0.z) - T.o.z) * T.idir.z;
   const bool nx = (T.neg & 1u) != 0, ny = (T.neg & 2u) != 0, nz = (T.neg & 4u) != 0;
-  const uint32_t nearX = nx ? q1.w : q1.x, farX = nx ? q1.x : q1.w;
-  const uint32_t nearY = ny ? q2.x : q1.y, farY = ny ? q1.y : q2.x;
-  const uint32_t nearZ = nz ? q2.y : q1.z, farZ = nz ? q1.z : q2.y;
+  const uint32_t nearX = nx ? q2.y : q1.z, farX = nx ? q1.z : q2.y;
+  const uint32_t nearY = ny ? q2.z : q1.w, farY = ny ? q1.w : q2.z;
+  const uint32_t nearZ = nz ? q2.w : q2.x, farZ = nz ? q2.x : q2.w;
   float tn[4];
   bool hit[4];
 #pragma unroll
@@ -99,7 +98,27 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
     tn[c] = n;
   }
   int r0 = (int)q3.x, r1 = (int)q3.y, r2 = (int)q3.z, r3 = (int)q3.w;
-  if (ORDERED) {
+  if (ORDER == 2) {
+    // nearest hit child by a 3-comparator min tree over (t, slot); every other hit child goes on the stack in slot
+    // order with unconditional stores (a slot above sp is scratch) and a conditional stack-pointer bump
+    const float t0 = hit[0] ? tn[0] : 3.0e38f, t1 = hit[1] ? tn[1] : 3.0e38f, t2 = hit[2] ? tn[2] : 3.0e38f, t3 = hit[3] ? tn[3] : 3.0e38f;
+    const bool s01 = t1 < t0, s23 = t3 < t2;
+    const float ta = s01 ? t1 : t0, tb = s23 ? t3 : t2;
+    const int ia = s01 ? 1 : 0, ib = s23 ? 3 : 2;
+    const bool sab = tb < ta;
+    const int near = sab ? ib : ia;
+    const bool any = (sab ? tb : ta) < 3.0e38f;
+    int sp = T.sp;
+#pragma unroll
+    for (int c = 3; c >= 0; c--) {
+      const int rc = (c == 3) ? r3 : ((c == 2) ? r2 : ((c == 1) ? r1 : r0));
+      stk[sp * kWave] = rc;
+      sp += (hit[c] && c != near) ? 1 : 0;
+    }
+    T.sp = sp;
+    const int rn = (near == 3) ? r3 : ((near == 2) ? r2 : ((near == 1) ? r1 : r0));
+    T.cur = any ? rn : travPop(T, stk);
+  } else if (ORDER == 1) {
     float t0 = hit[0] ? tn[0] : 3.0e38f, t1 = hit[1] ? tn[1] : 3.0e38f, t2 = hit[2] ? tn[2] : 3.0e38f, t3 = hit[3] ? tn[3] : 3.0e38f;
     r0 = hit[0] ? r0 : kDone;
     r1 = hit[1] ? r1 : kDone;
@@ -204,7 +223,7 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
   while (T.cur != kDone) {
     while (T.cur >= 0) {
       if (COUNT) nNodes++;
-      nodeStep<(MODE != 2) || BDPT_ORDERED_ANYHIT>(S, T, stk);
+      nodeStep<((MODE != 2) || BDPT_ORDERED_ANYHIT) ? 1 : 0>(S, T, stk);
     }
     if (T.cur == kDone) break;
     if (leafStep<MODE, COUNT>(S, T, nTris)) break;
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_ORDERED_ANYHIT != 0>(S, T, stk);
+        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0>(S, T, stk);
       }
       bool finished = (T.cur == kDone);
       if (!finished) {

@@ -31,6 +31,7 @@ constexpr uint32_t kCounterShards = 64;
 enum : int { F_COL = 0, F_POS = 3, F_N = 6, F_V = 9, F_DIF = 12, F_SPEC = 15, F_ROUGH = 18, F_ISSPEC = 19, F_PDF = 20, NF = 21 };
 constexpr int NF4 = 6;  // float4s per stored vertex record (96 B; layout in kernels.hip "Path vertices")
 enum : int { PATH_EYE = 0, PATH_LIGHT = 1 };
+enum : int { RAY_TERMS = 0, RAY_PAIRS = 1 };
 
 struct TexDev {
   const uint8_t* px;
@@ -90,9 +91,12 @@ struct PathBuf {
   float* rayQ;           // 7 planes, stride rayCap
   float* rayContrib;     // 3 planes, stride rayCap: the clamped contribution the ray gates
   uint8_t* rayVis;       // visibility by ray id
-  uint32_t* rayCount;    // [kNumSubQueues] rays queued per sub-queue
-  uint32_t* rayHead;     // [kNumSubQueues] fetch cursors
-  uint32_t raySubCap;    // capacity of one sub-queue; ray id = subQueue*raySubCap + offset
+  // Two ray classes share the planes: RAY_TERMS (NEE + splat rays) and RAY_PAIRS (connection rays, lazy rounds), each
+  // with its own sub-queues and cursors, so the first can be traced while the second is still being generated.
+  uint32_t* rayCount;    // cursor blocks [class]: rays queued per sub-queue
+  uint32_t* rayHead;     // cursor blocks [class]: fetch cursors
+  uint32_t raySubCap[2]; // capacity of one sub-queue of the class
+  uint32_t rayBase[2];   // first ray id of the class; ray id = rayBase[c] + subQueue*raySubCap[c] + offset
   uint32_t* slotRay;     // planes: slot*Np + p -> ray id or kNoRay.  slots: [0,D) NEE, [D,2D) splat, [2D,..) pairs
   uint32_t* splatPix;    // planes: t*Np + p -> full-frame pixel index of splat t
   float* misE;           // planes: k*Np + p, k in [0, D]: eye-side prefix product of getWeightPower/Linear
@@ -167,7 +171,7 @@ void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
-void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st);
+void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int rayClass, LaunchGrids& G, int numCUs, hipStream_t st);
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st);
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st);
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,

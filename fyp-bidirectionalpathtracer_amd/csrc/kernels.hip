@@ -330,6 +330,12 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
 // A path id packs pixel (24 bits), path (bit 24) and vertex index k (bits 25-29): tiles are < 2^24 pixels.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kPoolEntries = 128;
+#ifndef BDPT_WALK_ORDER
+#define BDPT_WALK_ORDER 1  // child order of the walk's closest-hit traversal (device_trace.hpp nodeStep)
+#endif
+#ifndef BDPT_WALK_REFILL
+#define BDPT_WALK_REFILL BDPT_REFILL_IDLE  // empty lanes before the walk kernel refills
+#endif
 BD uint32_t packPath(uint32_t p, int path, int k) { return p | ((uint32_t)path << 24) | ((uint32_t)k << 25); }
 
 template <bool GGX, bool COUNT>
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
     }
     // ---- 2. empty lanes take ready rays, then new sub-paths -------------------------------------------
     const int empty = 64 - __popcll(travMask);
-    if ((empty >= kRefillIdle || travMask == 0ull) && (nReady > 0 || !exhausted)) {
+    if ((empty >= BDPT_WALK_REFILL || travMask == 0ull) && (nReady > 0 || !exhausted)) {
       const unsigned long long emptyMask = ~travMask;
       const uint32_t rank = (uint32_t)__popcll(emptyMask & laneBelow);
       const uint32_t fromReady = ((uint32_t)empty < nReady) ? (uint32_t)empty : nReady;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
     if (trav) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<true>(S, T, stk);
+        nodeStep<BDPT_WALK_ORDER>(S, T, stk);
       }
       finished = (T.cur == kDone);
       if (!finished) {
@@ -619,7 +625,7 @@ BD f3 applyStrategyWeight(const FrameDev& F, const PathBuf& P, uint32_t p, f3 v,
   return v / (float)k;
 }
 
-BD uint32_t emitRay(const PathBuf& P, bool active, f3 o, f3 d, float tmax, f3 contrib) {
+BD uint32_t emitRay(const PathBuf& P, int cls, bool active, f3 o, f3 d, float tmax, f3 contrib) {
   const unsigned long long mask = __ballot(active);
   uint32_t id = kNoRay;
   if (mask == 0ull) return id;
@@ -627,10 +633,10 @@ BD uint32_t emitRay(const PathBuf& P, bool active, f3 o, f3 d, float tmax, f3 co
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
   const uint32_t q = blockIdx.x % kNumSubQueues;
-  if (lane == leader) base = atomicAdd(&P.rayCount[q * kCursorStride], (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(&P.rayCount[(size_t)cls * kCursorBlock + q * kCursorStride], (uint32_t)__popcll(mask));
   base = (uint32_t)__shfl((int)base, leader);
   if (active) {
-    id = q * P.raySubCap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    id = P.rayBase[cls] + q * P.raySubCap[cls] + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     const size_t c = P.rayCap;
     float* r = P.rayQ + id;
     r[0] = o.x;
@@ -657,197 +663,231 @@ BD void loadConnVtx(const PathBuf& P, int path, int k, int last, uint32_t p, Vtx
   loadSurf<GGX>(P, path, k, p, v);
 }
 
-// Three kernels (NEE, splat, connection) instead of one: each stays under 64 VGPRs, so twice as
-// many waves are resident to hide the latency of the vertex-plane loads.
-template <bool GGX>
+// Three kernels (NEE, splat, connection).  A lane owns one (pixel, vertex) pair: G = 8 (depth <= 8) or 16 lanes
+// per pixel, lane g of the group handling term / camera length g.  A lane reads whole 96-byte vertex records, every
+// record is fetched once per kernel, and no lane runs a loop of dependent (load -> evaluate -> append) rounds over a
+// pixel's vertices: with one lane per pixel the three kernels took 2.2 / 0.6 / 2.6 ms on the bench frame
+// (profiles/README.md), bound by those serial rounds and by re-reading the light vertices once per camera vertex.
+template <int G>
+BD bool queueGroup(const uint32_t* count, uint32_t subCap, bool& act, uint32_t& idx, int& g) {
+  constexpr uint32_t kPix = kWave / G;  // pixels per wave
+  const uint32_t q = blockIdx.x % kNumSubQueues, c0 = (blockIdx.x / kNumSubQueues) * kPix;
+  const uint32_t n = count[q * kCursorStride];
+  if (c0 >= n) return false;
+  const uint32_t i = c0 + threadIdx.x / G;
+  g = (int)(threadIdx.x % G);
+  act = i < n;
+  idx = q * subCap + i;
+  return true;
+}
+
+template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  bool act = false;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  bool act = false;  // inactive lanes still take part in the wave-collective emitRay
   uint32_t i = 0;
-  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
-  const uint32_t p = act ? P.queue[0][i] : 0u;
+  int t = 0;
+  if (!queueGroup<G>(P.qcount, P.pathSubCap, act, i, t)) return;
   const int D = (int)F.p.maxDepth;
+  const bool firstOfPixel = act && t == 0;
+  act = act && t < D;
+  const uint32_t p = act ? P.queue[0][i] : 0u;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0;
   const int lightsCount = (int)S.numLights;
-  uint32_t nNee = 0;
-  // ---- NEE ------------------------------------------------------------------------------------
-  {
-    uint32_t seed = act ? P.seedL[p] : 0u;
-    f3 prevColor = mk(1.0f);  // cameraPath[0].color
-    for (int t = 0; t < D; t++) {
-      const float r = nextRand(seed);  // drawn for every term, also for vertices that do not exist (App. A item 8)
-      bool emit = false;
-      f3 pos = mk(0), L = mk(0), shade = mk(0);
-      float distToLight = 0.0f;
-      if (act && (t + 1) <= eyeLast) {
-        int lightToSample = (int)(r * (float)lightsCount);
-        if (lightToSample > lightsCount - 1) lightToSample = lightsCount - 1;
-        pos = ldPlane3(P, PATH_EYE, t + 1, F_POS, p);
-        const f3 N = ldPlane3(P, PATH_EYE, t + 1, F_N, p);
-        const f3 dif = ldPlane3(P, PATH_EYE, t + 1, F_DIF, p);
-        f3 V = mk(0), spec = mk(0);
-        float rough = 0.0f;
-        if (GGX) {
-          V = ldPlane3(P, PATH_EYE, t + 1, F_V, p);
-          spec = ldPlane3(P, PATH_EYE, t + 1, F_SPEC, p);
-          rough = ldPlane1(P, PATH_EYE, t + 1, F_ROUGH, p);
-        }
-        f3 lightIntensity;
-        getLightData(S.sc->lights[lightToSample], pos, L, lightIntensity, distToLight);
-        f3 direct = directIfVisible<GGX>((float)lightsCount, L, lightIntensity, N, V, dif, spec, rough);
-        shade = clampVec(applyStrategyWeight(F, P, p, prevColor * direct, t + 2, t + 1, 0), F.p.clampUpper);
-        emit = !allZero(shade);
-        prevColor = ldPlane3(P, PATH_EYE, t + 1, F_COL, p);
-      } else {
-        prevColor = mk(0);
-      }
-      const uint32_t id = emitRay(P, emit, pos, L, distToLight, shade);
-      if (act) P.slotRay[(size_t)t * P.Np + p] = id;
-      nNee += emit ? 1u : 0u;
-    }
+  // term t uses the (t+1)-th draw after sampleLight: one draw per term, also for vertices that do not exist (App. A item 8)
+  uint32_t seed = act ? P.seedL[p] : 0u;
+  float r = 0.0f;
+  for (int k = 0; k <= t; k++) r = nextRand(seed);
+  bool emit = false;
+  f3 pos = mk(0), L = mk(0), shade = mk(0);
+  float distToLight = 0.0f;
+  if (act && (t + 1) <= eyeLast) {
+    int lightToSample = (int)(r * (float)lightsCount);
+    if (lightToSample > lightsCount - 1) lightToSample = lightsCount - 1;
+    Vtx v;
+    loadSurf<GGX>(P, PATH_EYE, t + 1, p, v);
+    pos = v.pos;
+    f3 V = mk(0);
+    if (GGX) V = ldPlane3(P, PATH_EYE, t + 1, F_V, p);
+    const f3 prevColor = (t == 0) ? mk(1.0f) : ldPlane3(P, PATH_EYE, t, F_COL, p);  // cameraPath[t].color; [0] = 1
+    f3 lightIntensity;
+    getLightData(S.sc->lights[lightToSample], pos, L, lightIntensity, distToLight);
+    f3 direct = directIfVisible<GGX>((float)lightsCount, L, lightIntensity, v.N, V, v.dif, v.spec, v.rough);
+    shade = clampVec(applyStrategyWeight(F, P, p, prevColor * direct, t + 2, t + 1, 0), F.p.clampUpper);
+    emit = !allZero(shade);
   }
-
-  waveAddCount(F.counters, C_RAYS_NEE, nNee);
-  waveAddCount(F.counters, C_PIX_VALID, act ? 1u : 0u);
+  const uint32_t id = emitRay(P, RAY_TERMS, emit, pos, L, distToLight, shade);
+  if (act) P.slotRay[(size_t)t * P.Np + p] = id;
+  waveAddCount(F.counters, C_RAYS_NEE, emit ? 1u : 0u);
+  waveAddCount(F.counters, C_PIX_VALID, firstOfPixel ? 1u : 0u);
 }
 
-template <bool GGX>
+template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  bool act = false;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  bool act = false;
   uint32_t i = 0;
-  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
-  const uint32_t p = act ? P.queue[0][i] : 0u;
+  int t = 0;
+  if (!queueGroup<G>(P.qcount, P.pathSubCap, act, i, t)) return;
   const int D = (int)F.p.maxDepth;
+  act = act && t < D;
+  const uint32_t p = act ? P.queue[0][i] : 0u;
   const int real = act ? (int)P.lightReal[p] : 0;
   const f3 camPos = ld3(F.cam.posW);
-  uint32_t nSplat = 0;
-  // ---- light tracing (splats) -------------------------------------------------------------------
-  if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
-    const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
-    const f3 cameraN = normalize(Wc);
-    for (int t = 0; t < D; t++) {
-      bool emit = false;
-      f3 pos = mk(0), dirToCamera = mk(0), shade = mk(0);
-      float disToCamera = 0.0f;
-      uint32_t target = kNoRay;
-      if (act && t < real) {
-        Vtx lv;
-        loadSurf<GGX>(P, PATH_LIGHT, t + 1, p, lv);
-        pos = lv.pos;
-        dirToCamera = normalize(camPos - lv.pos);
-        disToCamera = length(camPos - lv.pos);
-        if (dot(cameraN, dirToCamera) < 0) {
-          emit = true;  // the reference traces this ray whatever the value (its write saturates the target pixel)
-          float d1 = dot(dirToCamera, U) / dot(U, U);
-          float d2 = dot(dirToCamera, Vc) / dot(Vc, Vc);
-          float d3 = dot(dirToCamera, Wc) / dot(Wc, Wc);
-          float nx = d1 / d3, ny = -d2 / d3;
-          float px = nx * 0.5f + 0.5f, py = ny * 0.5f + 0.5f;
-          float fx = rintf(px * (float)F.W - F.p.pixelJitter[0]);
-          float fy = rintf(py * (float)F.H - F.p.pixelJitter[1]);
-          const bool inside = (fx >= 0.0f && fx < (float)F.W && fy >= 0.0f && fy < (float)F.H);
-          if (inside) {
-            target = (uint32_t)splatIndex(F.sl, F.W, (uint32_t)(int)fx, (uint32_t)(int)fy);
-            float theta1 = saturate(fabsf(dot(dirToCamera, cameraN)));
-            float theta2 = saturate(fabsf(dot(dirToCamera, lv.N)));
-            float invDisToCamera = 1.0f / disToCamera;
-            float G = theta1 * theta2 * invDisToCamera * invDisToCamera;
-            f3 vV = mk(0);
-            if (GGX) vV = ldPlane3(P, PATH_LIGHT, t + 1, F_V, p);
-            f3 fr = evalBRDF<GGX>(vV, normalize(camPos - lv.pos), lv.N, lv.N, lv.dif, lv.spec, lv.rough, lv.isSpec);
-            f3 prevColor = ldPlane3(P, PATH_LIGHT, t, F_COL, p);
-            shade = clampVec(applyStrategyWeight(F, P, p, (prevColor * fr) * G, t + 2, 0, t + 1), F.p.clampUpper);
-            if (isnan3(shade)) shade = mk(0);
-          }
-        }
+  const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
+  const f3 cameraN = normalize(Wc);
+  bool emit = false;
+  f3 pos = mk(0), dirToCamera = mk(0), shade = mk(0);
+  float disToCamera = 0.0f;
+  uint32_t target = kNoRay;
+  if (act && t < real) {
+    Vtx lv;
+    loadSurf<GGX>(P, PATH_LIGHT, t + 1, p, lv);
+    pos = lv.pos;
+    dirToCamera = normalize(camPos - lv.pos);
+    disToCamera = length(camPos - lv.pos);
+    if (dot(cameraN, dirToCamera) < 0) {
+      emit = true;  // the reference traces this ray whatever the value (its write saturates the target pixel)
+      float d1 = dot(dirToCamera, U) / dot(U, U);
+      float d2 = dot(dirToCamera, Vc) / dot(Vc, Vc);
+      float d3 = dot(dirToCamera, Wc) / dot(Wc, Wc);
+      float nx = d1 / d3, ny = -d2 / d3;
+      float px = nx * 0.5f + 0.5f, py = ny * 0.5f + 0.5f;
+      float fx = rintf(px * (float)F.W - F.p.pixelJitter[0]);
+      float fy = rintf(py * (float)F.H - F.p.pixelJitter[1]);
+      const bool inside = (fx >= 0.0f && fx < (float)F.W && fy >= 0.0f && fy < (float)F.H);
+      if (inside) {
+        target = (uint32_t)splatIndex(F.sl, F.W, (uint32_t)(int)fx, (uint32_t)(int)fy);
+        float theta1 = saturate(fabsf(dot(dirToCamera, cameraN)));
+        float theta2 = saturate(fabsf(dot(dirToCamera, lv.N)));
+        float invDisToCamera = 1.0f / disToCamera;
+        float Gt = theta1 * theta2 * invDisToCamera * invDisToCamera;
+        f3 vV = mk(0);
+        if (GGX) vV = ldPlane3(P, PATH_LIGHT, t + 1, F_V, p);
+        f3 fr = evalBRDF<GGX>(vV, normalize(camPos - lv.pos), lv.N, lv.N, lv.dif, lv.spec, lv.rough, lv.isSpec);
+        f3 prevColor = ldPlane3(P, PATH_LIGHT, t, F_COL, p);
+        shade = clampVec(applyStrategyWeight(F, P, p, (prevColor * fr) * Gt, t + 2, 0, t + 1), F.p.clampUpper);
+        if (isnan3(shade)) shade = mk(0);
       }
-      const uint32_t id = emitRay(P, emit, pos, dirToCamera, disToCamera, shade);
-      if (act) {
-        P.slotRay[(size_t)(D + t) * P.Np + p] = id;
-        P.splatPix[(size_t)t * P.Np + p] = target;
-      }
-      nSplat += emit ? 1u : 0u;
     }
   }
-
-  waveAddCount(F.counters, C_RAYS_SPLAT, nSplat);
+  const uint32_t id = emitRay(P, RAY_TERMS, emit, pos, dirToCamera, disToCamera, shade);
+  if (act) {
+    P.slotRay[(size_t)(D + t) * P.Np + p] = id;
+    P.splatPix[(size_t)t * P.Np + p] = target;
+  }
+  waveAddCount(F.counters, C_RAYS_SPLAT, emit ? 1u : 0u);
 }
 
-// Connection pairs are generated camera-vertex-major (the eye end vertex, its predecessor and the
-// two throughputs indexed by cameraLength are loaded once per cameraLength); the slot index keeps the
-// reference's (totalLength, cameraLength) numbering, which is all the gather stage needs.
-template <bool GGX>
+// Connections: lane g of a pixel's group owns camera length g + 1 and walks the light lengths.  The group first
+// puts the pixel's light vertices (lane g loads light vertex g) and eye positions into LDS, so every vertex record
+// leaves memory once; the slot index keeps the reference's (totalLength, cameraLength) numbering, which is all the
+// gather stage needs.
+template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
-  bool act = false;  // inactive lanes run the loops with nothing to emit (emitRay is wave-collective)
+  constexpr int kPix = kWave / G;
+  __shared__ float4 s_light[kPix][G][4];  // q0..q3 of light vertex g (zeros past the end of the sub-path)
+  __shared__ float4 s_eyePos[kPix][G];    // position of eye vertex g + 1 (zero past the end)
+  bool act = false;
   uint32_t i = 0;
-  if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
+  int g = 0;
+  if (!queueGroup<G>(P.qcount, P.pathSubCap, act, i, g)) return;
+  const int e = (int)(threadIdx.x / G);
   const uint32_t p = act ? P.queue[0][i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0;
   const int lightLast = act ? (int)P.lightLast[p] : -1;
   const f3 camPos = ld3(F.cam.posW);
+  const int cameraLength = g + 1;
+  const bool camAct = act && cameraLength <= D - 1;
+  {
+    float4 l0 = make_float4(0, 0, 0, 0), l1 = l0, l2 = l0, l3 = l0;
+    if (act && g <= lightLast && g < D) {
+      const float4* r = vtxPtr(P, PATH_LIGHT, g, p);
+      l0 = r[0];
+      l1 = r[1];
+      l2 = r[2];
+      if (GGX) l3 = r[3];
+    }
+    s_light[e][g][0] = l0;
+    s_light[e][g][1] = l1;
+    s_light[e][g][2] = l2;
+    s_light[e][g][3] = l3;
+  }
+  Vtx ce = zeroVtx();
+  f3 aE = mk(0), aL = mk(0);
+  if (camAct) {
+    loadConnVtx<GGX>(P, PATH_EYE, cameraLength, eyeLast, p, ce);
+    if (cameraLength - 1 == 0)
+      aE = mk(1.0f);
+    else if (cameraLength - 1 <= eyeLast)
+      aE = ldPlane3(P, PATH_EYE, cameraLength - 1, F_COL, p);
+    aL = (cameraLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, cameraLength - 1, F_COL, p) : mk(0);  // sic, BDPTUtils.hlsli:198
+  }
+  s_eyePos[e][g] = make_float4(ce.pos.x, ce.pos.y, ce.pos.z, 0.0f);
+  __syncthreads();
+  f3 cprevPos = camPos;
+  if (g > 0) {
+    const float4 q = s_eyePos[e][g - 1];  // eye vertex cameraLength - 1, zero when it does not exist
+    cprevPos = mk(q.x, q.y, q.z);
+  }
+  const f3 woE = normalize(cprevPos - ce.pos);
   uint32_t nConn = 0;
-  for (int cameraLength = 1; cameraLength <= D - 1; cameraLength++) {
-    Vtx ce = zeroVtx();
-    f3 aE = mk(0), aL = mk(0), woE = mk(0);
-    if (act) {
-      loadConnVtx<GGX>(P, PATH_EYE, cameraLength, eyeLast, p, ce);
-      f3 cprevPos;
-      if (cameraLength - 1 == 0) {
-        cprevPos = camPos;
-        aE = mk(1.0f);
-      } else if (cameraLength - 1 <= eyeLast) {
-        cprevPos = ldPlane3(P, PATH_EYE, cameraLength - 1, F_POS, p);
-        aE = ldPlane3(P, PATH_EYE, cameraLength - 1, F_COL, p);
+  for (int lightLength = 0; lightLength <= D - 1; lightLength++) {
+    const int totalLength = cameraLength + lightLength;  // 2..D; pairs of smaller totals come first: (t-1)t/2 - 1 of them
+    const bool pairAct = camAct && totalLength <= D && !(cameraLength == 1 && lightLength == 0);
+    const int slot = 2 * D + ((totalLength - 1) * totalLength) / 2 - 1 + (cameraLength - 1);
+    bool emit = false;
+    f3 dirAB = mk(0), shade = mk(0);
+    float lengthAB = 0.0f;
+    if (pairAct && lightLength != 0) {
+      const float4 q0 = s_light[e][lightLength][0], q1 = s_light[e][lightLength][1], q2 = s_light[e][lightLength][2];
+      Vtx le;
+      le.pos = mk(q0.x, q0.y, q0.z);
+      le.N = mk(q1.x, q1.y, q1.z);
+      le.dif = mk(q2.x, q2.y, q2.z);
+      if (GGX) {
+        const float4 q3 = s_light[e][lightLength][3];
+        le.spec = mk(q3.x, q3.y, q3.z);
+        le.rough = q0.w;
+        le.isSpec = q1.w != 0.0f;
       } else {
-        cprevPos = mk(0);
-        aE = mk(0);
+        le.spec = mk(0);
+        le.rough = 0.0f;
+        le.isSpec = false;
       }
-      woE = normalize(cprevPos - ce.pos);
-      aL = (cameraLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, cameraLength - 1, F_COL, p) : mk(0);  // sic, BDPTUtils.hlsli:198
-    }
-    for (int lightLength = (cameraLength == 1) ? 1 : 0; cameraLength + lightLength <= D; lightLength++) {
-      const int totalLength = cameraLength + lightLength;  // 2..D; pairs of smaller totals come first: (t-1)t/2 - 1 of them
-      const int slot = 2 * D + ((totalLength - 1) * totalLength) / 2 - 1 + (cameraLength - 1);
-      bool emit = false;
-      f3 dirAB = mk(0), shade = mk(0);
-      float lengthAB = 0.0f;
-      if (act && lightLength != 0) {
-        Vtx le;
-        loadConnVtx<GGX>(P, PATH_LIGHT, lightLength, lightLast, p, le);
-        const f3 vecAB = le.pos - ce.pos;
-        const float invLengthAB = 1.0f / length(vecAB);
-        const f3 dirG = vecAB * invLengthAB;
-        const float cosA = fabsf(dot(ce.N, dirG));
-        const float cosB = fabsf(dot(le.N, dirG));
-        const float G = cosA * cosB * invLengthAB * invLengthAB;
-        const f3 connectDir = normalize(ce.pos - le.pos);
-        const f3 lprev = (lightLength - 1 <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength - 1, F_POS, p) : mk(0);
-        const f3 woL = normalize(lprev - le.pos);
-        f3 c;
-        const f3 fsL = evalBRDF<GGX>(connectDir, woL, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
-        if (allZero(fsL)) {
-          c = fsL;
+      const float4 qp = s_light[e][lightLength - 1][0];  // light vertex lightLength - 1 (zero past the end)
+      const f3 lprev = mk(qp.x, qp.y, qp.z);
+      const f3 vecAB = le.pos - ce.pos;
+      const float invLengthAB = 1.0f / length(vecAB);
+      const f3 dirG = vecAB * invLengthAB;
+      const float cosA = fabsf(dot(ce.N, dirG));
+      const float cosB = fabsf(dot(le.N, dirG));
+      const float Gt = cosA * cosB * invLengthAB * invLengthAB;
+      const f3 connectDir = normalize(ce.pos - le.pos);
+      const f3 woL = normalize(lprev - le.pos);
+      f3 c;
+      const f3 fsL = evalBRDF<GGX>(connectDir, woL, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
+      if (allZero(fsL)) {
+        c = fsL;
+      } else {
+        const f3 fsE = evalBRDF<GGX>(-connectDir, woE, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
+        if (allZero(fsE)) {
+          c = fsE;
         } else {
-          const f3 fsE = evalBRDF<GGX>(-connectDir, woE, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
-          if (allZero(fsE)) {
-            c = fsE;
-          } else {
-            const f3 cst = (fsL * G) * fsE;
-            c = (aL * cst) * aE;
-          }
-        }
-        shade = clampVec(applyStrategyWeight(F, P, p, c, totalLength, cameraLength, lightLength), F.p.clampUpper);
-        if (isnan3(shade)) shade = mk(0);
-        if (!allZero(shade)) {
-          emit = true;
-          lengthAB = length(le.pos - ce.pos);
-          dirAB = (le.pos - ce.pos) / lengthAB;
+          const f3 cst = (fsL * Gt) * fsE;
+          c = (aL * cst) * aE;
         }
       }
-      const uint32_t id = emitRay(P, emit, ce.pos, dirAB, lengthAB, shade);
-      if (act) P.slotRay[(size_t)slot * P.Np + p] = id;
-      nConn += emit ? 1u : 0u;
+      shade = clampVec(applyStrategyWeight(F, P, p, c, totalLength, cameraLength, lightLength), F.p.clampUpper);
+      if (isnan3(shade)) shade = mk(0);
+      if (!allZero(shade)) {
+        emit = true;
+        lengthAB = length(le.pos - ce.pos);
+        dirAB = (le.pos - ce.pos) / lengthAB;
+      }
     }
+    const uint32_t id = emitRay(P, RAY_PAIRS, emit, ce.pos, dirAB, lengthAB, shade);
+    if (pairAct) P.slotRay[(size_t)slot * P.Np + p] = id;
+    nConn += emit ? 1u : 0u;
   }
   waveAddCount(F.counters, C_RAYS_CONNECT, nConn);
 }
@@ -987,7 +1027,7 @@ __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, 
       dirAB = (posB - posA) / lengthAB;
       ord++;
     }
-    const uint32_t id = emitRay(P, emit, posA, dirAB, lengthAB, mk(0));
+    const uint32_t id = emitRay(P, RAY_PAIRS, emit, posA, dirAB, lengthAB, mk(0));
     if (act) P.lazyRay[(size_t)b * P.Np + p] = id;
     nRays += emit ? 1u : 0u;
   }
@@ -1204,44 +1244,45 @@ void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
   hipLaunchKernelGGL(mis_prefix_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P);
 }
-// The three generators only share the ray queue (atomic appends), so the host may launch them on different
-// streams: NEE needs the eye path, the splats the light path, the connections both.
+// The three generators only share the ray queues (atomic appends), so the host may launch them on different streams.
+// G lanes per pixel: 8 up to depth 8, else 16.
+#define BDPT_LAUNCH_GEN(KERNEL)                                                                   \
+  {                                                                                               \
+    const bool ggx = F.p.matIndex == 0, wide = F.p.maxDepth > 8;                                  \
+    const dim3 b(kWave);                                                                          \
+    if (ggx && !wide) hipLaunchKernelGGL((KERNEL<true, 8>), dim3(queueGrid(P) * 8), b, 0, st, S, F, P);    \
+    else if (ggx) hipLaunchKernelGGL((KERNEL<true, 16>), dim3(queueGrid(P) * 16), b, 0, st, S, F, P);      \
+    else if (!wide) hipLaunchKernelGGL((KERNEL<false, 8>), dim3(queueGrid(P) * 8), b, 0, st, S, F, P);     \
+    else hipLaunchKernelGGL((KERNEL<false, 16>), dim3(queueGrid(P) * 16), b, 0, st, S, F, P);              \
+  }
 void launchGenNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
-  const dim3 g(queueGrid(P)), b(kWave);
-  if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(gen_nee_kernel<true>, g, b, 0, st, S, F, P);
-  else
-    hipLaunchKernelGGL(gen_nee_kernel<false>, g, b, 0, st, S, F, P);
+  BDPT_LAUNCH_GEN(gen_nee_kernel)
 }
 void launchGenSplat(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np || (F.p.flags & BDPT_PARAM_NO_SPLAT)) return;
-  const dim3 g(queueGrid(P)), b(kWave);
-  if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(gen_splat_kernel<true>, g, b, 0, st, S, F, P);
-  else
-    hipLaunchKernelGGL(gen_splat_kernel<false>, g, b, 0, st, S, F, P);
+  BDPT_LAUNCH_GEN(gen_splat_kernel)
 }
 void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
-  if (!P.Np || (F.p.flags & BDPT_PARAM_NO_CONNECT)) return;
-  const dim3 g(queueGrid(P)), b(kWave);
-  if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(gen_connect_kernel<true>, g, b, 0, st, S, F, P);
-  else
-    hipLaunchKernelGGL(gen_connect_kernel<false>, g, b, 0, st, S, F, P);
+  if (!P.Np || (F.p.flags & BDPT_PARAM_NO_CONNECT) || F.p.maxDepth < 2) return;
+  BDPT_LAUNCH_GEN(gen_connect_kernel)
 }
+#undef BDPT_LAUNCH_GEN
 
-void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st) {
+void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int cls, LaunchGrids& G, int numCUs, hipStream_t st) {
   if (!P.Np) return;
   const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
-  RayQueue Q{P.rayQ, P.rayCap, P.raySubCap, kNumSubQueues, P.rayCount, P.rayHead};
+  // the class's rays are ids [rayBase, rayBase + kNumSubQueues * raySubCap): the kernel sees planes and visibility bytes from rayBase on
+  RayQueue Q{P.rayQ + P.rayBase[cls], P.rayCap, P.raySubCap[cls], kNumSubQueues, P.rayCount + (size_t)cls * kCursorBlock,
+             P.rayHead + (size_t)cls * kCursorBlock};
+  uint8_t* vis = P.rayVis + P.rayBase[cls];
   uint32_t& g = G.shadow[cnt ? 1 : 0];
   if (cnt) {
     if (!g) g = persistentGrid(trace_shadow_kernel<true>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, P.rayVis, F.counters, F.p.minT);
+    hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
   } else {
     if (!g) g = persistentGrid(trace_shadow_kernel<false>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, P.rayVis, F.counters, F.p.minT);
+    hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
   }
 }
 

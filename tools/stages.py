@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Stage times (HIP events, bdpt_get_stage_times) of the bench frame; one line.  Used by tools/variants.sh."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+scene = pkg.Scene.atrium(1, 262144)
+pipe = pkg.FramePipeline(scene, 1920, 1080, max_depth=8, mat_index=0, accum_limit=10000)
+pipe.ctx.enable_stage_timing(True)
+agg = {}
+N = 6
+for it in range(N + 2):
+    pipe.render_frame()
+    st = pipe.ctx.stage_times()
+    if it >= 2:
+        for k, v in st:
+            agg[k] = agg.get(k, 0.0) + v / N
+c = pipe.ctx.counters().as_dict()
+tot = sum(agg.values())
+print("frame %.2f ms | walk %.2f gen_terms %.2f trace_terms %.2f trace_pairs %.2f lazy %.2f other %.2f | rays %.1fM" % (
+    tot, agg.get("walk", 0), agg.get("gen_terms", 0), agg.get("trace_terms", 0), agg.get("trace_pairs", 0),
+    agg.get("lazy_gen", 0) + agg.get("lazy_trace", 0) + agg.get("lazy_check", 0),
+    tot - sum(agg.get(k, 0) for k in ("walk", "gen_terms", "trace_terms", "trace_pairs", "lazy_gen", "lazy_trace", "lazy_check")),
+    sum(c[k] for k in ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")) / 1e6))

@@ -31,7 +31,7 @@ constexpr int kMaxStages = 64;
 constexpr size_t kCountBlocks = 1;  // lengths of the valid-pixel lists
 constexpr size_t kHeadBlocks = 2;   // fetch cursors of the walk kernel: pixel list x {eye, light}
 constexpr size_t kLazyBlocks = kMaxLazyRounds + 2;
-constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks + 4) * kCursorBlock;  // + ray count / head blocks of two classes
+constexpr size_t kCursorWords = (kCountBlocks + kHeadBlocks + kLazyBlocks) * kCursorBlock + 4 * kRayCursorBlock;  // + ray count / head blocks of two classes
 }
 
 struct bdpt_ctx {
@@ -78,7 +78,7 @@ struct bdpt_ctx {
   int bmfrRead = 0;  // which half holds the previous frame
   // the splat and NEE generators run beside the connection generator on this stream (fork/join with events; capture-safe)
   hipStream_t walkStream = nullptr;
-  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr, evSplat = nullptr;
 };
 
 namespace {
@@ -228,7 +228,8 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
     c->numCUs = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->walkStream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->evSplat, hipEventDisableTiming) != hipSuccess) {
     bdpt_destroy(c);
     return BDPT_E_HIP;
   }
@@ -246,6 +247,7 @@ void bdpt_destroy(bdpt_ctx* c) {
     for (int i = 0; i <= kMaxStages; i++) (void)hipEventDestroy(c->ev[i]);
   if (c->evFork) (void)hipEventDestroy(c->evFork);
   if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+  if (c->evSplat) (void)hipEventDestroy(c->evSplat);
   if (c->walkStream) (void)hipStreamDestroy(c->walkStream);
   delete c;
 }
@@ -652,16 +654,27 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
   P.qhead = P.qcount + kCountBlocks * kCursorBlock;
   P.lazyCount = P.qhead + kHeadBlocks * kCursorBlock;
   P.rayCount = P.lazyCount + kLazyBlocks * kCursorBlock;
-  P.rayHead = P.rayCount + 2 * kCursorBlock;
+  P.rayHead = P.rayCount + 2 * kRayCursorBlock;
   {
     // one shadow ray per NEE term, per splat term and per defined connection pair, at most
     const uint32_t D = std::max<uint32_t>(maxDepth, 1);
     const uint64_t slots = (uint64_t)2 * D + numConnectPairs(D);
     // workgroup b appends to sub-queue b % kNumSubQueues: size each for the workgroups it serves
     const uint64_t blocks = (np + kWave - 1) / kWave;
-    const uint64_t perSub = ((blocks + kNumSubQueues - 1) / kNumSubQueues) * kWave;  // pixels one sub-queue serves
-    const uint64_t subCapTerms = perSub * 2 * D, subCapPairs = perSub * std::max<uint32_t>(numConnectPairs(D), 1);
-    const uint64_t cap = (subCapTerms + subCapPairs) * kNumSubQueues;
+    // Producer workgroup b appends to ray sub-queue b % kNumRaySubQueues.  Generators run G lanes per pixel (8, or 16
+    // when the context is sized for depth > 8: G x queueGrid workgroups of 64 / G pixels), lazy_gen one lane per pixel:
+    // size every sub-queue for the workgroups it can serve under either launch shape.
+    const uint64_t queueGridBlocks = (uint64_t)(P.pathSubCap / kWave) * kNumSubQueues;
+    const uint64_t pairs = std::max<uint32_t>(numConnectPairs(D), 1);
+    uint64_t subCapTerms = 0, subCapPairs = ((queueGridBlocks + kNumRaySubQueues - 1) / kNumRaySubQueues) * kWave * pairs;
+    {
+      const uint64_t G = D > 8 ? 16 : 8;
+      const uint64_t perSub = (queueGridBlocks * G + kNumRaySubQueues - 1) / kNumRaySubQueues;  // workgroups per sub-queue
+      subCapTerms = std::max<uint64_t>(subCapTerms, perSub * kWave * 2);                           // one NEE + one splat ray per lane
+      subCapPairs = std::max<uint64_t>(subCapPairs, perSub * (kWave / G) * pairs);
+    }
+    (void)blocks;
+    const uint64_t cap = (subCapTerms + subCapPairs) * kNumRaySubQueues;
     if (cap >= (1ull << 32) - 1) {
       fail(c, "resize: shadow-ray queue would exceed 2^32 entries; render in smaller tiles");
       return BDPT_E_LIMIT;
@@ -669,7 +682,7 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
     P.raySubCap[RAY_TERMS] = (uint32_t)subCapTerms;
     P.raySubCap[RAY_PAIRS] = (uint32_t)subCapPairs;
     P.rayBase[RAY_TERMS] = 0;
-    P.rayBase[RAY_PAIRS] = (uint32_t)(subCapTerms * kNumSubQueues);
+    P.rayBase[RAY_PAIRS] = (uint32_t)(subCapTerms * kNumRaySubQueues);
     P.rayCap = (uint32_t)cap;
     if ((rc = devAlloc(c, c->frameAllocs, &P.rayQ, (size_t)7 * cap))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.rayContrib, (size_t)3 * cap))) return rc;
@@ -796,8 +809,8 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
       left -= batch;
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];
-      HIPCHK(c, hipMemsetAsync(P.rayCount + (size_t)RAY_PAIRS * kCursorBlock, 0, kCursorBlock * sizeof(uint32_t), st));
-      HIPCHK(c, hipMemsetAsync(P.rayHead + (size_t)RAY_PAIRS * kCursorBlock, 0, kCursorBlock * sizeof(uint32_t), st));
+      HIPCHK(c, hipMemsetAsync(P.rayCount + (size_t)RAY_PAIRS * kRayCursorBlock, 0, kRayCursorBlock * sizeof(uint32_t), st));
+      HIPCHK(c, hipMemsetAsync(P.rayHead + (size_t)RAY_PAIRS * kRayCursorBlock, 0, kRayCursorBlock * sizeof(uint32_t), st));
       launchLazyGen(F, P, list, P.lazyCount + (size_t)r * kCursorBlock, batch, st);
       stageMark(c, st, "lazy_gen");
       launchTraceShadow(c->S, F, P, RAY_PAIRS, c->grids, c->numCUs, st);
@@ -850,9 +863,9 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   launchWalk(c->S, F, P, c->grids, c->numCUs, st);
   stageMark(c, st, "walk");
 
-  // NEE and splat terms are generated on the caller's stream and traced at once (ray class RAY_TERMS) while the
-  // connection generator — the long one — fills the RAY_PAIRS queue on the context's second stream; the connection
-  // rays are traced when both are done.  (The MIS weights read both paths: everything sequential then.)
+  // NEE terms (caller's stream) and splat terms (second stream) are generated side by side and traced at once (ray
+  // class RAY_TERMS) while the connection generator — the long one — fills the RAY_PAIRS queue on the second stream;
+  // the connection rays are traced when both are done.  (The MIS weights read both paths: everything sequential then.)
   const bool mis = (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) != 0;
   if (mis) {
     launchMisPrefix(F, P, st);
@@ -865,10 +878,12 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   } else {
     HIPCHK(c, hipEventRecord(c->evFork, st));
     HIPCHK(c, hipStreamWaitEvent(c->walkStream, c->evFork, 0));
+    launchGenSplat(c->S, F, P, c->walkStream);  // beside the NEE generator; both are short and latency-bound
+    HIPCHK(c, hipEventRecord(c->evSplat, c->walkStream));
     launchGenConnect(c->S, F, P, c->walkStream);
     HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
     launchGenNee(c->S, F, P, st);
-    launchGenSplat(c->S, F, P, st);
+    HIPCHK(c, hipStreamWaitEvent(st, c->evSplat, 0));
     stageMark(c, st, "gen_terms");
     launchTraceShadow(c->S, F, P, RAY_TERMS, c->grids, c->numCUs, st);
     stageMark(c, st, "trace_terms");

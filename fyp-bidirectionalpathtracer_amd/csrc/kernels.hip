@@ -632,8 +632,8 @@ BD uint32_t emitRay(const PathBuf& P, int cls, bool active, f3 o, f3 d, float tm
   const int lane = (int)(threadIdx.x & 63u);
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
-  const uint32_t q = blockIdx.x % kNumSubQueues;
-  if (lane == leader) base = atomicAdd(&P.rayCount[(size_t)cls * kCursorBlock + q * kCursorStride], (uint32_t)__popcll(mask));
+  const uint32_t q = blockIdx.x % kNumRaySubQueues;
+  if (lane == leader) base = atomicAdd(&P.rayCount[(size_t)cls * kRayCursorBlock + q * kCursorStride], (uint32_t)__popcll(mask));
   base = (uint32_t)__shfl((int)base, leader);
   if (active) {
     id = P.rayBase[cls] + q * P.raySubCap[cls] + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -886,7 +886,9 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
       }
     }
     const uint32_t id = emitRay(P, RAY_PAIRS, emit, ce.pos, dirAB, lengthAB, shade);
+#ifndef BDPT_EXP_NO_SLOT
     if (pairAct) P.slotRay[(size_t)slot * P.Np + p] = id;
+#endif
     nConn += emit ? 1u : 0u;
   }
   waveAddCount(F.counters, C_RAYS_CONNECT, nConn);
@@ -1245,10 +1247,10 @@ void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st) {
   hipLaunchKernelGGL(mis_prefix_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P);
 }
 // The three generators only share the ray queues (atomic appends), so the host may launch them on different streams.
-// G lanes per pixel: 8 up to depth 8, else 16.
+// G lanes per pixel: 8 for contexts sized up to depth 8, else 16 (the ray queues are sized for that shape).
 #define BDPT_LAUNCH_GEN(KERNEL)                                                                   \
   {                                                                                               \
-    const bool ggx = F.p.matIndex == 0, wide = F.p.maxDepth > 8;                                  \
+    const bool ggx = F.p.matIndex == 0, wide = P.D1 > 9; /* the depth the context is sized for */  \
     const dim3 b(kWave);                                                                          \
     if (ggx && !wide) hipLaunchKernelGGL((KERNEL<true, 8>), dim3(queueGrid(P) * 8), b, 0, st, S, F, P);    \
     else if (ggx) hipLaunchKernelGGL((KERNEL<true, 16>), dim3(queueGrid(P) * 16), b, 0, st, S, F, P);      \
@@ -1272,9 +1274,9 @@ void launchGenConnect(const SceneDev& S, const FrameDev& F, const PathBuf& P, hi
 void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, int cls, LaunchGrids& G, int numCUs, hipStream_t st) {
   if (!P.Np) return;
   const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0;
-  // the class's rays are ids [rayBase, rayBase + kNumSubQueues * raySubCap): the kernel sees planes and visibility bytes from rayBase on
-  RayQueue Q{P.rayQ + P.rayBase[cls], P.rayCap, P.raySubCap[cls], kNumSubQueues, P.rayCount + (size_t)cls * kCursorBlock,
-             P.rayHead + (size_t)cls * kCursorBlock};
+  // the class's rays are ids [rayBase, rayBase + kNumRaySubQueues * raySubCap): the kernel sees planes and visibility bytes from rayBase on
+  RayQueue Q{P.rayQ + P.rayBase[cls], P.rayCap, P.raySubCap[cls], kNumRaySubQueues, P.rayCount + (size_t)cls * kRayCursorBlock,
+             P.rayHead + (size_t)cls * kRayCursorBlock};
   uint8_t* vis = P.rayVis + P.rayBase[cls];
   uint32_t& g = G.shadow[cnt ? 1 : 0];
   if (cnt) {

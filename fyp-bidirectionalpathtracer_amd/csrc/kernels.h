@@ -21,7 +21,10 @@ constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // producer and consumer cursors of the shadow-ray queue are sharded over sub-queues, consumers
 // take kFetchChunk rays per atomic, and the statistics counters are sharded per workgroup.
 constexpr uint32_t kNumSubQueues = 32;
-constexpr uint32_t kFetchChunk = 256;
+#ifndef BDPT_FETCH_CHUNK
+#define BDPT_FETCH_CHUNK 256
+#endif
+constexpr uint32_t kFetchChunk = BDPT_FETCH_CHUNK;
 constexpr uint32_t kCursorStride = 32;
 constexpr uint32_t kCursorBlock = kNumSubQueues * kCursorStride;  // words of one sharded cursor  // uint32 words between two sub-queue cursors: one 128-byte line each
 // The ray queues have their own cursor count (BDPT_RAY_SUBQUEUES).  Measured on the bench frame: 128 cursors instead

@@ -333,6 +333,9 @@ constexpr uint32_t kPoolEntries = 128;
 #ifndef BDPT_WALK_ORDER
 #define BDPT_WALK_ORDER 1  // child order of the walk's closest-hit traversal (device_trace.hpp nodeStep)
 #endif
+#ifndef BDPT_WALK_CHUNK
+#define BDPT_WALK_CHUNK 64  // sub-paths per fetch from the valid-pixel lists
+#endif
 #ifndef BDPT_WALK_REFILL
 #define BDPT_WALK_REFILL BDPT_REFILL_IDLE  // empty lanes before the walk kernel refills
 #endif
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
   T.cur = kDone;
   uint32_t nNodes = 0, nTris = 0;
   uint32_t nEye = 0, nLight = 0, nParked = 0, nReady = 0;  // wave-uniform
-  uint32_t vq = firstV + blockIdx.x % numV, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
+  uint32_t vq = firstV + blockIdx.x % numV, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = BDPT_WALK_CHUNK;
   bool exhausted = false;
   const uint32_t wavesPerList = (gridDim.x + numV - 1) / numV;
   for (;;) {
@@ -453,8 +456,10 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
           const uint32_t nq = P.qcount[(vq % kNumSubQueues) * kCursorStride];
           uint32_t base = nq;
           if (__hip_atomic_load(&head[vq * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
-            uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
-            chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
+            // A sub-path keeps its lane for up to D rays, so the list is handed out in small pieces (BDPT_WALK_CHUNK):
+            // with 256 per fetch the last pieces kept single waves busy long after the rest of the grid had drained.
+            uint32_t share = (nq / wavesPerList + 15u) & ~15u;
+            chunk = share < 16u ? 16u : (share > (uint32_t)BDPT_WALK_CHUNK ? (uint32_t)BDPT_WALK_CHUNK : share);
             if (lane == 0) base = atomicAdd(&head[vq * kCursorStride], chunk);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           }

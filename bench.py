@@ -50,6 +50,22 @@ def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
     return b
 
 
+def load_sq_summary(scene, W, H, D, world):
+    """Per-kernel SQ / cache counter summary of the committed PMC passes (tools/pmc_summary.py): lane utilisation,
+    VALU busy fraction per SIMD, L2 hit rate.  Decides what `bound` says."""
+    sj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "sq_summary.json")
+    if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(sj)):
+        return {}
+    with open(sj) as f:
+        raw = json.load(f)["kernels"]
+    out = {}
+    for k, v in raw.items():
+        name = k.split("<")[0]
+        if name not in out or v.get("waves", 0) > out[name].get("waves", 0):  # the timed variant (no visit counters) has more launches
+            out[name] = v
+    return out
+
+
 def load_traffic(scene, W, H, D, world):
     """HBM-side bytes per frame per kernel from the committed rocprofv3 PMC passes of this very command
     (separate FETCH_SIZE and WRITE_SIZE runs; profiles/README.md).  FETCH_SIZE is doubled here per
@@ -349,6 +365,7 @@ def main():
                                  ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0),
         }
         traffic = load_traffic(args.scene, W, H, D, world)
+        sq = load_sq_summary(args.scene, W, H, D, world)
         traffic_of = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
                       "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
                       "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
@@ -361,9 +378,15 @@ def main():
                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr}
             if tr:
                 r["traffic_over_algorithmic"] = round(tr / by, 3)
-                # what the counters say: well under the algorithmic bytes reach HBM -> the BVH is served by L2 / MALL and
-                # the kernel is bound by VALU issue under divergence (profiles/README.md: lane utilisation, VALU busy)
-                r["bound"] = "valu" if tr < 0.5 * by else "hbm"
+            c = sq.get(traffic_of[name][0]) if len(traffic_of[name]) == 1 else None
+            if c and "valu_busy" in c:
+                r["counters"] = {k: c[k] for k in ("lane_util", "valu_busy", "wait_any", "l2_hit", "waves_per_simd") if k in c}
+                # what the counters say: each SIMD's VALU is busy most of the time although only a third of the lanes work
+                # per instruction, and the fabric side moves a fraction of the algorithmic bytes (the BVH lives in L2 / MALL):
+                # bound by VALU issue under lane divergence, not by HBM
+                r["bound"] = "valu" if c["valu_busy"] >= 0.7 else ("hbm" if tr and tr >= 0.5 * by else "latency")
+            elif tr:
+                r["bound"] = "hbm" if tr >= 0.5 * by else "latency"
             return r
 
         kernels = {k: roof(k) for k in kernel_ms}

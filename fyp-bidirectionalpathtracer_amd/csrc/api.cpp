@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <atomic>
@@ -804,8 +805,20 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
     // cannot finish faster than its slowest ray (~0.1 ms), so once few pixels are pending one big round beats several.
     const int b0 = (nPairs + kLazyBatchDiv - 1) / kLazyBatchDiv;
     int left = nPairs;
-    for (int r = 0; r < c->lazyRounds && left > 0; r++) {
-      const int batch = (r + 1 == c->lazyRounds) ? left : (b0 < left ? b0 : left);
+    // experiment hook: BDPT_LAZY_SCHEDULE="1,2,4" = front rounds of 1, 2 and 4 candidates, then one round with the rest
+    int sched[kMaxLazyRounds] = {0};
+    int nSched = 0;
+    if (const char* e = std::getenv("BDPT_LAZY_SCHEDULE")) {
+      for (const char* q = e; *q && nSched < kMaxLazyRounds - 1;) {
+        sched[nSched++] = std::max(1, std::atoi(q));
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+      }
+    }
+    const int rounds = nSched ? nSched + 1 : c->lazyRounds;
+    for (int r = 0; r < rounds && left > 0; r++) {
+      const int want = nSched ? (r < nSched ? sched[r] : left) : ((r + 1 == rounds) ? left : b0);
+      const int batch = (r + 1 == rounds) ? left : (want < left ? want : left);
       left -= batch;
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];

@@ -333,6 +333,9 @@ constexpr uint32_t kPoolEntries = 128;
 #ifndef BDPT_WALK_ORDER
 #define BDPT_WALK_ORDER 1  // child order of the walk's closest-hit traversal (device_trace.hpp nodeStep)
 #endif
+#ifndef BDPT_WALK_SHADE_MIN
+#define BDPT_WALK_SHADE_MIN 64  // parked hit records that trigger a shading pass (64 = every lane shades)
+#endif
 #ifndef BDPT_WALK_CHUNK
 #define BDPT_WALK_CHUNK 64  // sub-paths per fetch from the valid-pixel lists
 #endif
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
     // ---- 1. hit / miss shaders, one parked record per lane ------------------------------------------
     // (also when nothing else can make progress: the last records of the wave are shaded short-handed)
     const bool flush = (travMask == 0ull) && nReady == 0 && exhausted && nParked > 0;
-    if (nParked >= (uint32_t)kWave || flush) {
+    if (nParked >= (uint32_t)BDPT_WALK_SHADE_MIN || flush) {
       const uint32_t n = nParked < (uint32_t)kWave ? nParked : (uint32_t)kWave;
       nParked -= n;
       const bool act = (uint32_t)lane < n;

@@ -54,8 +54,17 @@ struct TmpNode {
   uint32_t depth = 0;
 };
 
-constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;
+#ifndef BDPT_SAH_BINS
+#define BDPT_SAH_BINS 16
+#endif
+#ifndef BDPT_LEAF_MAX
+#define BDPT_LEAF_MAX 2
+#endif
+constexpr int kBins = BDPT_SAH_BINS;
+// Leaves hold at most two triangles.  Measured on the bench frame (profiles/README.md r2): leaves of <= 1 / 2 / 3 / 4 / 8
+// triangles give 23.6 / 19.1 / 19.5 / 20.1 / 23.0 ms per frame — a triangle test costs half a node visit and leaf runs of
+// different lengths idle lanes, while one-triangle leaves double the node array past the 4 MiB L2 of an XCD.
+constexpr uint32_t kLeafMax = BDPT_LEAF_MAX;  // at most 8 (three count bits in a leaf reference)
 constexpr float kCostTraverse = 1.0f, kCostTri = 1.0f;
 constexpr int kBinaryMaxDepth = 48;  // depth budget of the intermediate binary tree
 

@@ -19,10 +19,16 @@ for it in range(N + 2):
     if it >= 2:
         for k, v in st:
             agg[k] = agg.get(k, 0.0) + v / N
+pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
 c = pipe.ctx.counters().as_dict()
+info = pipe.ctx.bvh_info()
 tot = sum(agg.values())
 print("frame %.2f ms | walk %.2f gen_terms %.2f trace_terms %.2f trace_pairs %.2f lazy %.2f other %.2f | rays %.1fM" % (
     tot, agg.get("walk", 0), agg.get("gen_terms", 0), agg.get("trace_terms", 0), agg.get("trace_pairs", 0),
     agg.get("lazy_gen", 0) + agg.get("lazy_trace", 0) + agg.get("lazy_check", 0),
     tot - sum(agg.get(k, 0) for k in ("walk", "gen_terms", "trace_terms", "trace_pairs", "lazy_gen", "lazy_trace", "lazy_check")),
-    sum(c[k] for k in ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")) / 1e6))
+    sum(c[k] for k in ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")) / 1e6),
+    "| visits/ray closest %.2f nodes %.2f tris, shadow %.2f nodes %.2f tris | sah %.2f nodes %d" % (
+        c["nodeVisitsClosest"] / max(1, c["raysEyeExtend"] + c["raysLightExtend"]), c["triTestsClosest"] / max(1, c["raysEyeExtend"] + c["raysLightExtend"]),
+        c["nodeVisitsShadow"] / max(1, c["raysNee"] + c["raysSplat"] + c["raysConnect"]), c["triTestsShadow"] / max(1, c["raysNee"] + c["raysSplat"] + c["raysConnect"]),
+        info.sahCost, info.numNodes))

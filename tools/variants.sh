@@ -3,9 +3,9 @@
 # the bench frame's stage times; restores the default build at the end.
 cd fyp-bidirectionalpathtracer_amd/csrc
 for v in "$@"; do
-  rm -f kernels.o libbdpt_amd.so
+  rm -f kernels.o bvh_build.o libbdpt_amd.so
   make EXTRA="$v" > /tmp/variant_build.log 2>&1 || { echo "== $v : build failed"; tail -5 /tmp/variant_build.log; continue; }
   echo "== [$v]"
   (cd ../.. && timeout -k 10 180 python tools/stages.py 2>&1 | grep -v amdgpu.ids | tail -1)
 done
-rm -f kernels.o libbdpt_amd.so; make > /dev/null 2>&1
+rm -f kernels.o bvh_build.o libbdpt_amd.so; make > /dev/null 2>&1

@@ -920,6 +920,7 @@ int bdpt_execute_tail(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in,
   FrameDev F;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (int rc = frameSetup(c, p, in, out, st, F)) return rc;
+  stageMark(c, st, "tail_wait");  // stream time between the end of phase 1 and this call (the host's exchange set-up), not a kernel
   return connectionTail(c, F, st);
 }
 

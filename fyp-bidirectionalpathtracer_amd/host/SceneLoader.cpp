@@ -160,14 +160,36 @@ std::string lower(std::string s) {
 }
 bool endsWith(const std::string& s, const std::string& suf) { return s.size() >= suf.size() && lower(s).compare(s.size() - suf.size(), suf.size(), suf) == 0; }
 
+}  // namespace
+// ImageDecode.cpp
+bool decodePng(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba8, int& channels, std::string& err);
+bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba8, int& channels, std::string& err);
+namespace {
+
 // ---------------------------------------------------------------------------------------------
-// images: binary PPM (P6) / PGM (P5), TGA (uncompressed and RLE, 24/32-bit colour, 8-bit grey)
+// images: PNG and baseline JPEG (ImageDecode.cpp), binary PPM (P6) / PGM (P5), TGA (uncompressed and RLE, 24/32-bit
+// colour, 8-bit grey).  hasAlpha = the image is a 32-bit one for Falcor (Utils/Bitmap.cpp:104-126), which is what
+// makes a material's alpha mode Mask (Graphics/Material/Material.cpp:120-126).  Grey images become (g, g, g, 255).
 // ---------------------------------------------------------------------------------------------
-bool loadImage(const std::string& path, Scene::Texture& out, bool& hasAlpha) {
+bool loadImage(const std::string& path, Scene::Texture& out, bool& hasAlpha, std::string* why = nullptr) {
   std::ifstream f(path, std::ios::binary);
   if (!f) return false;
   std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   hasAlpha = false;
+  const bool png = d.size() > 8 && d[0] == 0x89 && d[1] == 'P' && d[2] == 'N' && d[3] == 'G';
+  const bool jpg = d.size() > 3 && d[0] == 0xff && d[1] == 0xd8;
+  if (png || jpg) {
+    int channels = 0;
+    std::string err;
+    const bool ok = png ? decodePng(d.data(), d.size(), out.width, out.height, out.rgba8, channels, err)
+                        : decodeJpeg(d.data(), d.size(), out.width, out.height, out.rgba8, channels, err);
+    if (!ok) {
+      if (why) *why = err;
+      return false;
+    }
+    hasAlpha = channels == 4;
+    return true;
+  }
   if (d.size() > 2 && d[0] == 'P' && (d[1] == '6' || d[1] == '5')) {
     size_t p = 2;
     auto num = [&]() -> long {
@@ -282,12 +304,14 @@ struct ModelLoader {
     std::string p = dir + "/" + file;
     std::replace(p.begin(), p.end(), '\\', '/');
     int id = -1;
-    if (loadImage(p, t, a)) {
+    std::string why;
+    if (loadImage(p, t, a, &why)) {
       t.srgb = srgb ? 1u : 0u;
       id = (int)s.textures.size();
       s.textures.push_back(std::move(t));
     } else {
-      std::fprintf(stderr, "[SceneLoader] cannot load texture %s (supported: PPM/PGM/TGA)\n", p.c_str());
+      std::fprintf(stderr, "[SceneLoader] cannot load texture %s (supported: PNG, baseline JPEG, PPM/PGM, TGA)%s%s\n", p.c_str(),
+                   why.empty() ? "" : ": ", why.c_str());
     }
     texCache[key] = id;
     alphaOf[id] = a;
@@ -756,6 +780,26 @@ Scene::SharedPtr Scene::loadFromFile(const std::string& path, std::string* error
 struct bdpt_scene {
   bdpt::Scene::SharedPtr scene;
 };
+
+extern "C" int bdpt_image_load(const char* path, uint32_t* width, uint32_t* height, uint32_t* hasAlpha, uint8_t* rgba8, uint64_t cap, char* msg,
+                               uint32_t msgCap) {
+  if (!path || !width || !height) return BDPT_E_INVALID;
+  bdpt::Scene::Texture t;
+  bool a = false;
+  std::string why;
+  if (!bdpt::loadImage(path, t, a, &why)) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "%s", why.empty() ? "cannot read or recognise the image" : why.c_str());
+    return BDPT_E_INVALID;
+  }
+  *width = t.width;
+  *height = t.height;
+  if (hasAlpha) *hasAlpha = a ? 1u : 0u;
+  if (rgba8) {
+    if (cap < t.rgba8.size()) return BDPT_E_LIMIT;
+    std::memcpy(rgba8, t.rgba8.data(), t.rgba8.size());
+  }
+  return BDPT_OK;
+}
 
 extern "C" bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap) {
   if (!path) return nullptr;

@@ -39,12 +39,18 @@ bdpt_scene* bdpt_scene_create_courtyard(uint32_t seed, uint32_t targetTriangles,
 bdpt_scene* bdpt_scene_create_soup(uint32_t seed, uint32_t numTriangles, float maxEdge);
 
 /* Loads a Falcor `.fscene` (JSON: models/instances, lights, cameras) or a bare
- * Wavefront `.obj` (+ `.mtl`; PPM/PGM/TGA textures), applying the reference's
+ * Wavefront `.obj` (+ `.mtl`; PNG / baseline-JPEG / PPM / PGM / TGA textures), applying the reference's
  * import rules (SceneImporter.cpp:106-460, AssimpModelImporter.cpp:326-417,
  * Material.cpp:119-184, SceneLoaderWrapper.cpp:56-103).  Returns NULL and writes
  * a message into msg (if msgCap > 0) on failure, as loadScene returns nullptr
  * (SceneLoaderWrapper.cpp:60). */
 bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap);
+
+/* Decode one texture image the way the loader does (PNG, baseline JPEG, PPM/PGM, TGA): RGBA8, row 0 first; *hasAlpha =
+ * the file is a 32-bit image for Falcor (Utils/Bitmap.cpp:104-126).  rgba8 may be NULL to query the size.
+ * Replaces Bitmap::createFromFile -> FreeImage_Load (Utils/Bitmap.cpp:45-140). */
+int bdpt_image_load(const char* path, uint32_t* width, uint32_t* height, uint32_t* hasAlpha, uint8_t* rgba8, uint64_t cap, char* msg,
+                    uint32_t msgCap);
 
 void bdpt_scene_destroy(bdpt_scene* s);
 

@@ -117,6 +117,38 @@ int main(int argc, char** argv) {
     bdpt_scene* bad = bdpt_scene_load((tmp + "/missing.fscene").c_str(), msg, sizeof(msg));
     if (bad) rc |= 1;
   }
+  {  // image decoders: the files tests/test_sanitizers.py wrote, then byte-mutated and truncated copies of them (a corrupt
+     // file may be refused or decoded to garbage, never read or written out of bounds)
+    uint32_t state = 12345u;
+    auto rnd = [&]() { return state = state * 1664525u + 1013904223u; };
+    int decoded = 0, refused = 0;
+    for (const char* name : {"san_rgba.png", "san_pal.png", "san_420.jpg", "san_grey.jpg", "san_rst.jpg"}) {
+      std::ifstream f(tmp + "/" + name, std::ios::binary);
+      if (!f) continue;
+      std::vector<char> good((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+      for (int k = 0; k < 400; k++) {
+        std::vector<char> d = good;
+        if (k > 0) {
+          const int flips = 1 + (int)(rnd() % 4);
+          for (int i = 0; i < flips; i++) d[rnd() % d.size()] = (char)(rnd() >> 24);
+          if (k % 5 == 0) d.resize(1 + rnd() % d.size());
+        }
+        const std::string path = tmp + "/mut.bin";
+        std::ofstream(path, std::ios::binary).write(d.data(), (std::streamsize)d.size());
+        uint32_t w = 0, h = 0, a = 0;
+        char msg[128];
+        if (bdpt_image_load(path.c_str(), &w, &h, &a, nullptr, 0, msg, sizeof(msg)) == BDPT_OK) {
+          std::vector<uint8_t> px((size_t)w * h * 4);
+          if (bdpt_image_load(path.c_str(), &w, &h, &a, px.data(), px.size(), msg, sizeof(msg)) != BDPT_OK) rc |= 1;
+          decoded++;
+        } else {
+          refused++;
+          if (k == 0) rc |= 1;  // the unmodified file must decode
+        }
+      }
+    }
+    std::printf("image decoders: %d decoded, %d refused\n", decoded, refused);
+  }
   std::printf("sanitizer run finished rc=%d\n", rc);
   return rc;
 }

@@ -1,0 +1,224 @@
+"""The loader's own PNG and baseline-JPEG decoders (host/ImageDecode.cpp) against independently produced files.
+
+PNG files are written here chunk by chunk with Python's zlib (stored, fixed-Huffman and dynamic-Huffman DEFLATE
+streams; every scan-line filter type; every colour type the decoder accepts) and by Pillow; decoded texels must equal
+the source exactly.  JPEG files are written by Pillow (libjpeg-turbo) at several qualities, chroma sub-samplings, sizes
+that are not multiples of the MCU and with restart markers; the decoder follows the IJG release-6b arithmetic that
+libjpeg-turbo keeps, so its output must equal Pillow's decode bit for bit.  Neither pins the reference's FreeImage
+(not in the image; its bundled IJG 9a up-samples chroma differently): geometry/material import stays parity-unpinned.
+"""
+import ctypes as C
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+Image = pytest.importorskip("PIL.Image")
+
+
+def _load(pkg, path):
+    lib = pkg.load_library()
+    w, h, a = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    msg = C.create_string_buffer(256)
+    rc = lib.bdpt_image_load(str(path).encode(), C.byref(w), C.byref(h), C.byref(a), None, 0, msg, 256)
+    if rc != 0:
+        return None, msg.value.decode()
+    buf = np.zeros((h.value, w.value, 4), np.uint8)
+    assert lib.bdpt_image_load(str(path).encode(), C.byref(w), C.byref(h), C.byref(a), buf.ctypes.data, buf.size, msg, 256) == 0
+    return buf, bool(a.value)
+
+
+def _png(width, height, color_type, depth, rows, level=9, strategy=zlib.Z_DEFAULT_STRATEGY, filt=None, extra=b""):
+    """rows: list of raw scan lines (bytes, unfiltered).  filt: filter type per row (None = 0)."""
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+    samples = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    bpp = max(1, samples * depth // 8)
+    raw = bytearray()
+    prev = bytes(len(rows[0]))
+    for y, line in enumerate(rows):
+        ft = 0 if filt is None else filt[y % len(filt)]
+        out = bytearray(len(line))
+        for i, v in enumerate(line):
+            a = line[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (v - p) & 255
+        raw.append(ft)
+        raw += out
+        prev = line
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+    data = co.compress(bytes(raw)) + co.flush()
+    half = len(data) // 2  # two IDAT chunks: the stream may be split anywhere
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, color_type, 0, 0, 0)) + extra +
+            chunk(b"IDAT", data[:half]) + chunk(b"IDAT", data[half:]) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (1, zlib.Z_HUFFMAN_ONLY)])
+def test_png_colour_types_filters_and_deflate_block_kinds(pkg, tmp_path, level, strategy):
+    rng = np.random.default_rng(7 + level)
+    W, H = 37, 29
+    smooth = (np.add.outer(np.arange(H), np.arange(W)) * 3 % 256).astype(np.uint8)  # compressible: long matches
+    rgba = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    rgba[..., 0] = smooth
+    rgba[5:20, 3:30, 1] = 17
+    cases = {
+        "rgba": (6, 8, [rgba[y].tobytes() for y in range(H)], rgba, True),
+        "rgb": (2, 8, [rgba[y, :, :3].tobytes() for y in range(H)], np.dstack([rgba[..., :3], np.full((H, W), 255, np.uint8)]), False),
+        "grey": (0, 8, [smooth[y].tobytes() for y in range(H)], np.dstack([smooth] * 3 + [np.full((H, W), 255, np.uint8)]), False),
+        "grey_alpha": (4, 8, [np.stack([smooth[y], rgba[y, :, 3]], 1).tobytes() for y in range(H)],
+                       np.dstack([smooth] * 3 + [rgba[..., 3]]), True),
+    }
+    for name, (ct, depth, rows, want, alpha) in cases.items():
+        f = tmp_path / f"{name}.png"
+        f.write_bytes(_png(W, H, ct, depth, rows, level, strategy, filt=[0, 1, 2, 3, 4]))
+        got, a = _load(pkg, f)
+        assert got is not None, a
+        assert a == alpha and np.array_equal(got, want), name
+        # Pillow reads the same file the same way (the writer above is not the only witness)
+        ref = np.asarray(Image.open(f).convert("RGBA"))
+        assert np.array_equal(got, ref), name
+
+
+def test_png_palette_low_bit_depths_and_transparent_colour(pkg, tmp_path):
+    rng = np.random.default_rng(3)
+    W, H = 21, 9
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    plte = struct.pack(">I", 48) + b"PLTE" + pal.tobytes() + struct.pack(">I", zlib.crc32(b"PLTE" + pal.tobytes()) & 0xFFFFFFFF)
+    for depth in (1, 2, 4, 8):
+        idx = rng.integers(0, min(16, 1 << depth), (H, W), dtype=np.uint8)
+        rows = []
+        for y in range(H):
+            bits = "".join(format(int(v), f"0{depth}b") for v in idx[y])
+            bits += "0" * (-len(bits) % 8)
+            rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+        f = tmp_path / f"pal{depth}.png"
+        f.write_bytes(_png(W, H, 3, depth, rows, extra=plte))
+        got, a = _load(pkg, f)
+        assert got is not None and not a
+        assert np.array_equal(got[..., :3], pal[idx]) and (got[..., 3] == 255).all()
+        g = tmp_path / f"grey{depth}.png"
+        g.write_bytes(_png(W, H, 0, depth, rows))
+        got, a = _load(pkg, g)
+        assert not a and np.array_equal(got[..., 0], (idx.astype(np.int32) * 255 // ((1 << depth) - 1)).astype(np.uint8))
+    # RGB with a tRNS colour key: FreeImage converts such files to 32 bits -> the material gets an alpha mask
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    rgb[2, 3] = rgb[4, 5] = (9, 8, 7)
+    body = struct.pack(">HHH", 9, 8, 7)
+    trns = struct.pack(">I", 6) + b"tRNS" + body + struct.pack(">I", zlib.crc32(b"tRNS" + body) & 0xFFFFFFFF)
+    f = tmp_path / "key.png"
+    f.write_bytes(_png(W, H, 2, 8, [rgb[y].tobytes() for y in range(H)], extra=trns))
+    got, a = _load(pkg, f)
+    assert a and got[2, 3, 3] == 0 and got[4, 5, 3] == 0 and (got[..., 3] == 0).sum() == 2 and np.array_equal(got[..., :3], rgb)
+
+
+def test_png_written_by_pillow_and_refusals(pkg, tmp_path):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (64, 48, 4), dtype=np.uint8)
+    img[10:40, 5:30] = (200, 100, 50, 128)
+    for mode, arr in (("RGBA", img), ("RGB", img[..., :3]), ("L", img[..., 0]), ("LA", img[..., [0, 3]])):
+        f = tmp_path / f"pil_{mode}.png"
+        Image.fromarray(arr, mode).save(f, optimize=True)
+        got, a = _load(pkg, f)
+        assert got is not None and a == (mode in ("RGBA", "LA"))
+        assert np.array_equal(got, np.asarray(Image.open(f).convert("RGBA"))), mode
+    f = tmp_path / "interlaced.png"
+    data = bytearray(_png(4, 4, 2, 8, [bytes(12)] * 4))
+    ihdr = bytearray(data[8:8 + 25])
+    ihdr[8 + 12] = 1  # interlace method
+    ihdr[21:25] = struct.pack(">I", zlib.crc32(bytes(ihdr[4:21])) & 0xFFFFFFFF)
+    f.write_bytes(bytes(data[:8]) + bytes(ihdr) + bytes(data[33:]))
+    got, why = _load(pkg, f)
+    assert got is None and "interlaced" in why
+    f = tmp_path / "sixteen.png"
+    Image.fromarray((rng.integers(0, 65536, (8, 8))).astype(np.uint16)).save(f)
+    got, why = _load(pkg, f)
+    assert got is None and "16-bit" in why
+    f = tmp_path / "corrupt.png"
+    good = bytearray((tmp_path / "pil_RGB.png").read_bytes())
+    good[len(good) // 2] ^= 0x55
+    f.write_bytes(bytes(good))
+    got, why = _load(pkg, f)
+    assert got is None
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 29), (17, 1), (1, 23), (200, 131)])
+@pytest.mark.parametrize("subsampling,quality", [(0, 90), (1, 75), (2, 50), (2, 95)])
+def test_jpeg_baseline_equals_libjpeg_turbo(pkg, tmp_path, size, subsampling, quality):
+    rng = np.random.default_rng(size[0] * 131 + size[1] + subsampling)
+    W, H = size
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 5 + yy * 3) % 256, (xx * 2 + 40 * np.sin(yy / 5.0) + 128) % 256, (yy * 7) % 256], -1).astype(np.uint8)
+    img[H // 3: H // 2 + 1, W // 4: W // 2 + 1] = rng.integers(0, 256, 3, dtype=np.uint8)
+    img = np.clip(img.astype(np.int32) + rng.integers(-20, 21, img.shape), 0, 255).astype(np.uint8)
+    f = tmp_path / "a.jpg"
+    Image.fromarray(img, "RGB").save(f, quality=quality, subsampling=subsampling, optimize=(quality == 95))
+    got, a = _load(pkg, f)
+    assert got is not None, a
+    ref = np.asarray(Image.open(f).convert("RGB"))
+    assert not a and got.shape == (H, W, 4) and (got[..., 3] == 255).all()
+    assert np.array_equal(got[..., :3], ref), f"{(got[..., :3] != ref).any(-1).sum()} of {W * H} pixels differ, max {np.abs(got[..., :3].astype(int) - ref).max()}"
+
+
+def test_jpeg_greyscale_restart_markers_and_refusals(pkg, tmp_path):
+    rng = np.random.default_rng(11)
+    g = (rng.integers(0, 256, (45, 70))).astype(np.uint8)
+    f = tmp_path / "g.jpg"
+    Image.fromarray(g, "L").save(f, quality=80)
+    got, a = _load(pkg, f)
+    ref = np.asarray(Image.open(f).convert("L"))
+    assert not a and np.array_equal(got[..., 0], ref) and np.array_equal(got[..., 1], ref) and np.array_equal(got[..., 2], ref)
+    rgb = rng.integers(0, 256, (50, 90, 3), dtype=np.uint8)
+    f = tmp_path / "r.jpg"
+    try:
+        Image.fromarray(rgb, "RGB").save(f, quality=85, subsampling=2, restart_marker_blocks=3)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    assert b"\xff\xdd" in f.read_bytes()
+    got, a = _load(pkg, f)
+    assert got is not None, a
+    assert np.array_equal(got[..., :3], np.asarray(Image.open(f).convert("RGB")))
+    f = tmp_path / "p.jpg"
+    Image.fromarray(rgb, "RGB").save(f, quality=85, progressive=True)
+    got, why = _load(pkg, f)
+    assert got is None and "progressive" in why
+
+
+def test_obj_material_with_png_and_jpeg_textures(pkg, tmp_path):
+    """The loader end to end: an OBJ whose base-colour map is a PNG with an alpha channel becomes an alpha-masked
+    material (Material.cpp:120-126), one with a JPEG map stays opaque; texels arrive as decoded."""
+    rng = np.random.default_rng(2)
+    rgba = rng.integers(0, 256, (16, 16, 4), dtype=np.uint8)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "leaf.png")
+    Image.fromarray(rgba[..., :3].copy(), "RGB").save(tmp_path / "wall.jpg", quality=90)
+    (tmp_path / "m.mtl").write_text("newmtl leaf\nKd 1 1 1\nmap_Kd leaf.png\nnewmtl wall\nKd 1 1 1\nmap_Kd wall.jpg\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\n"
+                                    "usemtl leaf\nf 1/1 2/2 3/3\nusemtl wall\nf 2/2 4/4 3/3\n")
+    scene = pkg.Scene.load(tmp_path / "m.obj")
+    d = scene.desc
+    assert d.numTriangles == 2 and d.numTextures == 2
+    mats = {int(d.triMaterial[t]) for t in range(2)}
+    assert len(mats) == 2
+    alpha_modes = sorted((d.materials[m].flags >> 17) & 3 for m in mats)
+    assert alpha_modes == [0, 1]  # opaque (JPEG) and mask (RGBA PNG)
+    for i in range(2):
+        t = d.textures[i]
+        px = np.ctypeslib.as_array(C.cast(t.rgba8, C.POINTER(C.c_uint8)), (t.height, t.width, 4))
+        if (px[..., 3] != 255).any():
+            assert np.array_equal(px, rgba)
+        else:
+            assert np.array_equal(px[..., :3], np.asarray(Image.open(tmp_path / "wall.jpg").convert("RGB")))
+    scene.close()

@@ -14,6 +14,7 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     pk = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd")
     srcs = [os.path.join(ROOT, "tests", "sanitize", "san_main.cpp"),
             os.path.join(pk, "host", "Scene.cpp"), os.path.join(pk, "host", "Atrium.cpp"), os.path.join(pk, "host", "SceneLoader.cpp"),
+            os.path.join(pk, "host", "ImageDecode.cpp"),
             os.path.join(pk, "csrc", "bvh_build.cpp"),
             os.path.join(ROOT, "oracle", "bdpt_oracle.cpp"), os.path.join(ROOT, "oracle", "bmfr_oracle.cpp")]
     exe = str(tmp_path / "san_main")
@@ -21,6 +22,22 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
            "-fno-sanitize-recover=undefined", "-o", exe] + srcs + ["-lpthread"]
     b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert b.returncode == 0, b.stderr[-3000:]
+    try:  # inputs for the image decoders' mutation loop (san_main.cpp skips it without them)
+        import numpy as np
+        from PIL import Image
+        rng = np.random.default_rng(1)
+        px = rng.integers(0, 256, (40, 56, 4), dtype=np.uint8)
+        px[8:30, 10:40] = (10, 200, 90, 128)
+        Image.fromarray(px, "RGBA").save(tmp_path / "san_rgba.png")
+        Image.fromarray(px[..., :3].copy(), "RGB").quantize(32).save(tmp_path / "san_pal.png")
+        Image.fromarray(px[..., :3].copy(), "RGB").save(tmp_path / "san_420.jpg", quality=70, subsampling=2)
+        Image.fromarray(px[..., 0].copy(), "L").save(tmp_path / "san_grey.jpg", quality=85)
+        try:
+            Image.fromarray(px[..., :3].copy(), "RGB").save(tmp_path / "san_rst.jpg", quality=60, subsampling=1, restart_marker_blocks=2)
+        except TypeError:
+            pass
+    except ImportError:
+        pass
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sanitizer run finished rc=0" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

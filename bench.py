@@ -452,7 +452,8 @@ def main():
                         "traffic = HBM-side bytes from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE).  The BVH of this scene "
                         "lives in L2/MALL, so traffic << algorithmic bytes for the two traversal kernels: they are bound by "
                         "VALU issue under lane divergence, not by HBM; frac says how close node/triangle delivery is to what "
-                        "HBM could stream",
+                        "HBM could stream.  gen_kernels exceed 1: SURVEY's 200 B per connection pair assumes both vertices are fetched per "
+                        "pair, the generator fetches every vertex record once per pixel and shares it through LDS",
             },
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only

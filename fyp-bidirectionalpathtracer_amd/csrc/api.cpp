@@ -803,22 +803,12 @@ int connectionTail(bdpt_ctx* c, const FrameDev& F, hipStream_t st) {
     const int nPairs = (int)numConnectPairs((uint32_t)D);
     // Schedule: rounds of ceil(pairs / kLazyBatchDiv) candidates; the last round takes everything that is left.  A launch
     // cannot finish faster than its slowest ray (~0.1 ms), so once few pixels are pending one big round beats several.
+    // (Front rounds of 1,2,4 / 2,4 / 1,4 / 2,6 / 3 / 1,2,4,8 / 2 candidates were measured within 5 % of this one:
+    // most lazy rays belong to pixels whose candidates are all occluded.  profiles/README.md)
     const int b0 = (nPairs + kLazyBatchDiv - 1) / kLazyBatchDiv;
     int left = nPairs;
-    // experiment hook: BDPT_LAZY_SCHEDULE="1,2,4" = front rounds of 1, 2 and 4 candidates, then one round with the rest
-    int sched[kMaxLazyRounds] = {0};
-    int nSched = 0;
-    if (const char* e = std::getenv("BDPT_LAZY_SCHEDULE")) {
-      for (const char* q = e; *q && nSched < kMaxLazyRounds - 1;) {
-        sched[nSched++] = std::max(1, std::atoi(q));
-        while (*q && *q != ',') q++;
-        if (*q == ',') q++;
-      }
-    }
-    const int rounds = nSched ? nSched + 1 : c->lazyRounds;
-    for (int r = 0; r < rounds && left > 0; r++) {
-      const int want = nSched ? (r < nSched ? sched[r] : left) : ((r + 1 == rounds) ? left : b0);
-      const int batch = (r + 1 == rounds) ? left : (want < left ? want : left);
+    for (int r = 0; r < c->lazyRounds && left > 0; r++) {
+      const int batch = (r + 1 == c->lazyRounds) ? left : (b0 < left ? b0 : left);
       left -= batch;
       uint32_t* list = P.queue[1 + (r & 1)];
       uint32_t* next = P.queue[1 + ((r + 1) & 1)];

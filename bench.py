@@ -398,7 +398,8 @@ def main():
         shadow_per_frame = (per_stage_rays.get("raysNee", 0) + per_stage_rays.get("raysSplat", 0) +
                             per_stage_rays.get("raysConnect", 0)) / stage_frames
         out = {
-            "metric": "Mrays/s + RMSE vs the scalar oracle, BDPT pass, Sponza-class scene 1080p depth 8",
+            "metric": "Mrays/s + RMSE vs the scalar oracle, BDPT pass, %s %dx%d depth %d" % (
+                "Sponza-class scene" if args.scene == "atrium" else "Cornell box", W, H, D),
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,

@@ -18,15 +18,15 @@ constexpr int kStackEntries = KSTACK;  // per-lane traversal stack in LDS, 8 KiB
 constexpr int kShadeRecF4 = BDPT_SHADE_REC_F4;  // float4s per triangle shading record (7 used = 112 B)
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // Hot single-word atomics top out near 90 M/s on this chip (MI355X_MICROARCH.md "dequeue"), so
-// producer and consumer cursors of the shadow-ray queue are sharded over sub-queues, consumers
-// take kFetchChunk rays per atomic, and the statistics counters are sharded per workgroup.
+// producer and consumer cursors of every queue are sharded over sub-queues, the any-hit trace kernel
+// takes up to kFetchChunk rays per atomic, and the statistics counters are sharded per workgroup.
 constexpr uint32_t kNumSubQueues = 32;
 #ifndef BDPT_FETCH_CHUNK
 #define BDPT_FETCH_CHUNK 256
 #endif
 constexpr uint32_t kFetchChunk = BDPT_FETCH_CHUNK;
-constexpr uint32_t kCursorStride = 32;
-constexpr uint32_t kCursorBlock = kNumSubQueues * kCursorStride;  // words of one sharded cursor  // uint32 words between two sub-queue cursors: one 128-byte line each
+constexpr uint32_t kCursorStride = 32;                            // uint32 words between two sub-queue cursors: one 128-byte line each
+constexpr uint32_t kCursorBlock = kNumSubQueues * kCursorStride;  // words of one sharded cursor
 // The ray queues have their own cursor count (BDPT_RAY_SUBQUEUES).  Measured on the bench frame: 128 cursors instead
 // of 32 change nothing (20.9 vs 20.5 ms: the appends of the generators are not what bounds them).
 #ifndef BDPT_RAY_SUBQUEUES
@@ -36,7 +36,7 @@ constexpr uint32_t kNumRaySubQueues = BDPT_RAY_SUBQUEUES;
 constexpr uint32_t kRayCursorBlock = kNumRaySubQueues * kCursorStride;  // words of one sharded ray cursor
 constexpr uint32_t kCounterShards = 64;
 
-// Vertex-plane field indices (PathVertex, BDPT/RayPathData.hlsli:1-45).  pdfForward is only read by the
+// Path-vertex field ids (PathVertex, BDPT/RayPathData.hlsli:1-45); kernels.hip "Path vertices" maps them to the 96-byte record.  pdfForward is only read by the
 // MIS weights (BDPT_PARAM_MIS_*), which the reference defines but never calls.
 enum : int { F_COL = 0, F_POS = 3, F_N = 6, F_V = 9, F_DIF = 12, F_SPEC = 15, F_ROUGH = 18, F_ISSPEC = 19, F_PDF = 20, NF = 21 };
 constexpr int NF4 = 6;  // float4s per stored vertex record (96 B; layout in kernels.hip "Path vertices")

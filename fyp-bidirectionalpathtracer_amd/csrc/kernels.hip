@@ -1,6 +1,7 @@
 // kernels.hip — the wavefront BDPT pipeline for gfx950 (CDNA4, wave64).
 //
-// Per frame (all on one HIP stream, no host synchronisation in between):
+// Per frame (the caller's stream plus one stream the context owns for two of the generators; no host
+// synchronisation in between):
 //   gbuffer_kernel      primary visibility                      CP lightProbeGBuffer.rt.hlsl:63-159
 //   init_paths_kernel   eye vertex 1 + light vertex 0           BDPTMain.rt.hlsl:51-103, 124-135
 //   walk_kernel         both random walks, one persistent launch:
@@ -12,12 +13,13 @@
 //   resolve_kernel      fold the splat buffer in                (build definition)
 //   accumulate_kernel   running mean                            CP accumulate.ps.hlsl:28-42
 //
-// Layout: path vertices and rays are SoA planes, so a wave reads 64 consecutive floats per field;
-// live paths and generated rays are compacted with __ballot + popcount prefix + one atomic per
-// wave; all BVH traversal happens in one persistent kernel whose lanes are refilled from the ray
-// queue as they retire (device_trace.hpp), with each lane's stack in LDS interleaved by lane
-// (entry e of lane l at word e*64+l: pushes and pops never bank-conflict).  One workgroup = one
-// wave (64 threads): no __syncthreads anywhere, and a finished wave frees its slot immediately.
+// Layout: path vertices are 96-byte records by pixel (a lane owns a sub-path and moves whole records), shadow
+// rays SoA planes by ray id (a wave reads 64 consecutive floats per field); valid pixels and generated rays are
+// compacted with __ballot + popcount prefix + one atomic per wave; BVH traversal happens in two persistent
+// kernels — the walk kernel and the any-hit trace kernel (device_trace.hpp) — whose lanes are refilled as they
+// retire, with each lane's stack in LDS interleaved by lane (entry e of lane l at word e*64+l: pushes and pops
+// never bank-conflict).  One workgroup = one wave (64 threads): __syncthreads only orders a wave's own LDS
+// traffic, and a finished wave frees its slot immediately.
 #include "kernels.h"
 
 #include <algorithm>
@@ -31,7 +33,7 @@ namespace bdpt {
 #define BD __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------------------
-// Path queues.  A queue is kNumSubQueues dense lists (workgroup b appends to and, in the dense
+// Pixel queues (valid pixels, lazy-round lists).  A queue is kNumSubQueues dense lists (workgroup b appends to and, in the dense
 // kernels, reads list b % kNumSubQueues) with one cursor per list on its own 128-byte line, because
 // every wave of a launch hitting one atomic word caps the chip near 90 M appends/s.
 //   item of list q at offset i lives at items[q*subCap + i]; count[q*kCursorStride] = list length

@@ -27,6 +27,14 @@
  *                                   light-tracing loop (BDPTMain.rt.hlsl:186-204), made
  *                                   deterministic: fixed-point atomics into a separate buffer,
  *                                   one final saturate
+ *   bdpt_resize / bdpt_resize_stripes / bdpt_prepare
+ *                                   RenderPass::resize + the lazy texture creation of
+ *                                   ResourceManager::requestTextureResource (SharedUtils/RenderPass.h:42,
+ *                                   SharedUtils/ResourceManager.cpp:210-241): per-tile path state; the striped form
+ *                                   and bdpt_resolve_tile / bdpt_accumulate_tile / bdpt_get_tile_info have no
+ *                                   counterpart (the reference renders on one GPU: a single DispatchRays,
+ *                                   Falcor API/D3D12/D3D12RenderContext.cpp:350-384) — they are the multi-GPU
+ *                                   tiling of SURVEY.md §8e
  *   bdpt_accumulate                 SimpleAccumulationPass::execute + accumulate.ps.hlsl
  *                                   (CommonPasses/SimpleAccumulationPass.cpp:104-134,
  *                                    CommonPasses/Data/CommonPasses/accumulate.ps.hlsl:28-42)

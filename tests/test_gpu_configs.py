@@ -94,6 +94,19 @@ def test_config2_cornell_1080p_depth8_lambert_accumulated(pkg, ob):
     scene.close()
 
 
+def test_config2_full_size_bands_and_stripes_equal_full_frame(pkg):
+    """configs[1] at full size (Cornell 1920x1080, depth 8, Lambertian): two bands and four owners' stripes reproduce
+    the one-context frame; rays within the (D+1)^2 bound."""
+    scene = pkg.Scene.cornell()
+    W, H, D = 1920, 1080, 8
+    img, cnt = _bands_equal_full(pkg, scene, W, H, D, 1, [(0, 500), (500, 1080)])
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.01
+    assert 0 < sum(cnt[k] for k in RAY_KEYS) <= W * H * (D + 1) ** 2
+    ref = _stripes_equal_full(pkg, scene, W, H, D, 1, 4)
+    assert np.array_equal(ref.view(np.uint32), img.view(np.uint32))
+    scene.close()
+
+
 def test_config5_alpha_masked_foliage_depth16_matches_oracle(pkg, ob):
     """configs[4] arithmetic: depth 16 on a textured scene in which 60 % of the triangles are alpha-masked leaf
     cards (any-hit alpha test on extension, NEE, splat and connection rays), against the oracle."""

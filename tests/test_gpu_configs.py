@@ -316,3 +316,24 @@ def test_config4_full_size_stripes_equal_full_frame(pkg):
     img = _stripes_equal_full(pkg, scene, 3840, 2160, 12, 0, 8)
     assert np.isfinite(img).all() and img[..., :3].mean() > 0.01
     scene.close()
+
+
+def test_execute_at_lower_depth_than_the_context_is_sized_for(pkg, ob):
+    """bdpt_resize fixes the storage depth (and with it the generators' lanes-per-pixel shape: 16 above depth 8);
+    gMaxDepth may then be any smaller value per frame (the reference's GUI slider, BDPTPass.cpp:64-66)."""
+    import torch
+    scene = pkg.Scene.atrium(8, 16000)
+    for sized, depths in ((12, (12, 5, 2, 1)), (8, (8, 3))):
+        pipe = pkg.FramePipeline(scene, 72, 40, max_depth=sized, mat_index=0)
+        for d in depths:
+            pipe.max_depth = d
+            gp, p = pipe.render_frame()
+            assert p.maxDepth == d
+            torch.cuda.synchronize()
+            orc, _ = _oracle_frame(pkg, ob, scene, pipe, gp, p)
+            orc.resolve()
+            gpu, ref = pipe.output.cpu().numpy(), orc.image()
+            assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), (sized, d, int((gpu != ref).any(axis=-1).sum()))
+            orc.close()
+        pipe.close()
+    scene.close()

@@ -56,6 +56,9 @@ class Texture {
   void clear(const vec4& c, hipStream_t stream);
   // read back as RGBA32F regardless of format (tests / image output)
   std::vector<float> download(hipStream_t stream) const;
+  // raw bytes in the texture's own format (checkpoints)
+  void downloadRaw(hipStream_t stream, std::vector<uint8_t>& out) const;
+  bool uploadRaw(hipStream_t stream, const uint8_t* data, size_t size);
  private:
   Texture() = default;
   uint32_t mW = 0, mH = 0;

@@ -77,6 +77,16 @@ void Texture::clear(const vec4& c, hipStream_t stream) {
     (void)hipMemcpy(mData, host.data(), host.size() * 2, hipMemcpyHostToDevice);
   }
 }
+void Texture::downloadRaw(hipStream_t stream, std::vector<uint8_t>& out) const {
+  (void)hipStreamSynchronize(stream);
+  out.resize(getSizeInBytes());
+  (void)hipMemcpy(out.data(), mData, out.size(), hipMemcpyDeviceToHost);
+}
+bool Texture::uploadRaw(hipStream_t stream, const uint8_t* data, size_t size) {
+  if (size != getSizeInBytes()) return false;
+  (void)hipStreamSynchronize(stream);
+  return hipMemcpy(mData, data, size, hipMemcpyHostToDevice) == hipSuccess;
+}
 std::vector<float> Texture::download(hipStream_t stream) const {
   (void)hipStreamSynchronize(stream);
   const size_t n = (size_t)mW * mH * 4;
@@ -468,9 +478,10 @@ void SimpleAccumulationPass::execute(RenderContext* pRenderContext) {
   Texture::SharedPtr inputTexture = mpResManager->getTexture(mAccumChannel);
   if (!inputTexture || !mDoAccumulation || !mpLastFrame || !mpRays) return;
   if (hasCameraMoved()) {
-    mAccumCount = 0;
+    if (!mResumed) mAccumCount = 0;
     mLastCameraVersion = mpScene->getActiveCamera()->getViewVersion();
   }
+  mResumed = false;
   const uint32_t gAccumCount = (int32_t)mAccumCount < mCountLimit ? mAccumCount++ : (uint32_t)mCountLimit;
   bdpt_accumulate(mpRays->ctx(), (float*)mpLastFrame->getDevicePointer(), (float*)inputTexture->getDevicePointer(), gAccumCount,
                   (uint32_t)mCountLimit, (uint64_t)inputTexture->getWidth() * inputTexture->getHeight(), pRenderContext->getStream());
@@ -579,6 +590,94 @@ void RenderingPipeline::renderFrame() {
   for (auto& p : mActivePasses)
     if (p) p->onExecute(&mContext);
 }
+// ---- checkpoints: [magic][pass count] then per pass [name length][name][state length][state]
+namespace {
+constexpr uint32_t kCheckpointMagic = 0x42445054u;  // "BDPT"
+void put32(std::vector<uint8_t>& o, uint32_t v) {
+  for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i)));
+}
+void put64(std::vector<uint8_t>& o, uint64_t v) {
+  for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i)));
+}
+uint32_t get32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t get64(const uint8_t* p) { return (uint64_t)get32(p) | ((uint64_t)get32(p + 4) << 32); }
+}  // namespace
+
+void LightProbeGBufferPass::saveState(RenderContext*, std::vector<uint8_t>& out) { put32(out, mFrameCount); }
+bool LightProbeGBufferPass::loadState(RenderContext*, const uint8_t* data, size_t size) {
+  if (size != 4) return false;
+  mFrameCount = get32(data);
+  return true;
+}
+void BDPTPass::saveState(RenderContext*, std::vector<uint8_t>& out) { put32(out, mFrameCount); }
+bool BDPTPass::loadState(RenderContext*, const uint8_t* data, size_t size) {
+  if (size != 4) return false;
+  mFrameCount = get32(data);
+  return true;
+}
+void SimpleAccumulationPass::saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) {
+  put32(out, mAccumCount);
+  std::vector<uint8_t> raw;
+  if (mpLastFrame) mpLastFrame->downloadRaw(pRenderContext->getStream(), raw);
+  out.insert(out.end(), raw.begin(), raw.end());
+}
+bool SimpleAccumulationPass::loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) {
+  if (size < 4 || !mpLastFrame || size - 4 != mpLastFrame->getSizeInBytes()) return false;
+  mAccumCount = get32(data);
+  // resuming is not a camera move: the first frame's own set-up (the G-buffer pass sets the aspect ratio) will bump the
+  // camera's view version once more
+  mResumed = true;
+  return mpLastFrame->uploadRaw(pRenderContext->getStream(), data + 4, size - 4);
+}
+
+bool RenderingPipeline::saveCheckpoint(const std::string& path) {
+  std::vector<uint8_t> out;
+  put32(out, kCheckpointMagic);
+  put32(out, (uint32_t)mActivePasses.size());
+  for (auto& pass : mActivePasses) {
+    const std::string name = pass->getName();
+    std::vector<uint8_t> st;
+    pass->onSaveState(&mContext, st);
+    put32(out, (uint32_t)name.size());
+    out.insert(out.end(), name.begin(), name.end());
+    put64(out, st.size());
+    out.insert(out.end(), st.begin(), st.end());
+  }
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+  return std::fclose(f) == 0 && ok;
+}
+
+bool RenderingPipeline::loadCheckpoint(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::vector<uint8_t> d;
+  uint8_t buf[65536];
+  for (size_t n; (n = std::fread(buf, 1, sizeof(buf), f)) > 0;) d.insert(d.end(), buf, buf + n);
+  std::fclose(f);
+  size_t p = 0;
+  if (d.size() < 8 || get32(&d[0]) != kCheckpointMagic || get32(&d[4]) != mActivePasses.size()) return false;
+  // deliver the refresh notification a first frame would (it resets the accumulation) BEFORE the state comes in
+  for (auto& pass : mActivePasses) {
+    pass->onStateRefresh();
+    pass->resetRefreshFlag();
+  }
+  p = 8;
+  for (auto& pass : mActivePasses) {
+    if (p + 4 > d.size()) return false;
+    const uint32_t nl = get32(&d[p]);
+    p += 4;
+    if (p + nl + 8 > d.size() || std::string(d.begin() + (long)p, d.begin() + (long)(p + nl)) != pass->getName()) return false;
+    p += nl;
+    const uint64_t sl = get64(&d[p]);
+    p += 8;
+    if (p + sl > d.size() || !pass->onLoadState(&mContext, sl ? &d[p] : nullptr, (size_t)sl)) return false;
+    p += (size_t)sl;
+  }
+  return p == d.size();
+}
+
 std::vector<float> RenderingPipeline::readOutput() {
   Texture::SharedPtr t = mpResourceManager->getTexture(ResourceManager::kOutputChannel);
   return t ? t->download(mContext.getStream()) : std::vector<float>();

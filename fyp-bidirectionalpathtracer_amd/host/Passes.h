@@ -55,6 +55,8 @@ class LightProbeGBufferPass : public RenderPass {
   bool mUseThinLens = false;
   float mFStop = 32.0f, mFocalLength = 1.0f, mLensRadius = 0.0f;
   bool mUseJitter = true, mUseRandomJitter = false;  // random jitter (std::mt19937 seeded by time) is not reproduced
+  void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) override;
+  bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) override;
   uint32_t mFrameCount = 0xdeadbeefu;
 };
 
@@ -83,6 +85,8 @@ class BDPTPass : public RenderPass {
   float mClampUpper = 0.9f;
   float mRefractiveIndex = 1.0f;
   std::string mOutputTextureName;
+  void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) override;
+  bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) override;
   uint32_t mFrameCount = 0x1337u;
   uint32_t mParamFlags = 0;
 };
@@ -106,6 +110,8 @@ class SimpleAccumulationPass : public RenderPass {
   bool appliesPostprocess() override { return true; }
   bool hasAnimation() override { return false; }
   bool hasCameraMoved();
+  void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) override;
+  bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) override;
 
   std::string mAccumChannel;
   RayLaunch::SharedPtr mpRays;  // only for the context that runs bdpt_accumulate
@@ -113,6 +119,7 @@ class SimpleAccumulationPass : public RenderPass {
   Scene::SharedPtr mpScene;
   uint64_t mLastCameraVersion = 0;
   bool mDoAccumulation = true;
+  bool mResumed = false;  // state came from a checkpoint: the next frame's camera set-up is not a camera move
   uint32_t mAccumCount = 0;
   int32_t mCountLimit = 100;
   const int32_t mMaxCountLimit = 10000;
@@ -166,6 +173,10 @@ class RenderingPipeline {
   ResourceManager::SharedPtr getResourceManager() { return mpResourceManager; }
   RenderContext* getRenderContext() { return &mContext; }
   std::vector<float> readOutput();    // "PipelineOutput" as RGBA32F
+  // every pass's cross-frame state (frame counters, accumulated frame) to / from a file: a run resumed from a
+  // checkpoint continues the frame sequence bit for bit.  false on I/O errors or a file that does not match the passes.
+  bool saveCheckpoint(const std::string& path);
+  bool loadCheckpoint(const std::string& path);
   size_t getPassCount() const { return mActivePasses.size(); }
 
  private:

@@ -88,6 +88,11 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   virtual void stateRefreshed() {}
   virtual void activatePass() {}
   virtual void deactivatePass() {}
+  // Checkpoint / resume of a long accumulation (not in the reference, whose runs are interactive: SURVEY.md section 5):
+  // what a pass must carry over for the frame sequence to continue bit for bit — frame counters, accumulated
+  // texture — as raw bytes.  A pass without cross-frame state keeps the defaults.
+  virtual void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) {}
+  virtual bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) { return size == 0; }
 
  public:
   virtual bool requiresScene() { return false; }
@@ -111,6 +116,8 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   void onShutdown();
   void onPassActivation() { activatePass(); }
   void onPassDeactivation() { deactivatePass(); }
+  void onSaveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) { saveState(pRenderContext, out); }
+  bool onLoadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) { return loadState(pRenderContext, data, size); }
 
   void setName(const std::string& name) { mName = name; }
   std::string getName() const { return mName; }
@@ -123,6 +130,7 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   ivec2 getGuiSize() const { return mGuiSize; }
   bool isInitialized() const { return mIsInitialized; }
   bool isRefreshFlagSet() const { return mRefreshFlag; }
+  void resetRefreshFlag() { mRefreshFlag = false; }
   bool isRebindFlagSet() const { return mRebindFlag; }
   void resetRebindFlag() { mRebindFlag = false; }
 

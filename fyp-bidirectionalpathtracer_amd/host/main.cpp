@@ -21,7 +21,7 @@ static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t 
 }
 
 int main(int argc, char** argv) {
-  std::string scene = "cornell", out = "bdpt_out.pfm", raw;
+  std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume;
   uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
   int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100;
   bool denoise = false, denoiseRegression = false;
@@ -42,9 +42,12 @@ int main(int argc, char** argv) {
     else if (const char* v = next("--accum-limit")) accumLimit = std::atoi(v);
     else if (const char* v = next("--out")) out = v;
     else if (const char* v = next("--raw")) raw = v;
+    else if (const char* v = next("--checkpoint")) checkpoint = v;
+    else if (const char* v = next("--resume")) resume = v;
     else {
       std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
-                           "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32]\n");
+                           "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32] "
+                           "[--resume file.ckpt] [--checkpoint file.ckpt]\n");
       return 2;
     }
   }
@@ -78,6 +81,10 @@ int main(int argc, char** argv) {
   if (denoise) gui.overrides["Ignore the denoise stage"] = 1;  // the check box's label while it is off (DenoisePass.cpp:139)
   if (denoiseRegression) gui.overrides["Skip Regression"] = 1;
   pipeline->applyGui(&gui);
+  if (!resume.empty() && !pipeline->loadCheckpoint(resume)) {  // continue an earlier run's frame sequence
+    std::fprintf(stderr, "bdpt_render: cannot resume from %s (missing, or written for other passes / another frame size)\n", resume.c_str());
+    return 1;
+  }
 
   auto t0 = std::chrono::steady_clock::now();
   for (int f = 0; f < frames; f++) pipeline->renderFrame();
@@ -89,6 +96,10 @@ int main(int argc, char** argv) {
   std::printf("%s %ux%u depth %d mat %d: %d frames in %.2f ms (%.2f ms/frame), mean radiance %.6f\n", scene.c_str(), W, H, depth, mat,
               frames, ms, ms / frames, mean / (3.0 * (double)(img.size() / 4)));
   writePfm(out.c_str(), img, W, H);
+  if (!checkpoint.empty() && !pipeline->saveCheckpoint(checkpoint)) {
+    std::fprintf(stderr, "bdpt_render: cannot write %s\n", checkpoint.c_str());
+    return 1;
+  }
   if (!raw.empty()) {
     FILE* f = std::fopen(raw.c_str(), "wb");
     if (f) {

@@ -560,3 +560,32 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(pkg, tmp_path):
     a, b = np.load(one), np.load(two)
     assert a.shape == (180, 320, 4) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.isfinite(a).all() and a[..., :3].mean() > 0.01
+
+
+def test_cpp_host_checkpoint_resume_continues_bit_for_bit(pkg, tmp_path):
+    """host/bdpt_render --checkpoint / --resume: 7 accumulated frames in one run == 3 frames, checkpoint, a new process
+    resuming for 4 more (frame counters, jitter sequence and the running mean carry over); a checkpoint written for
+    another frame size is refused."""
+    import os
+    import subprocess
+    import __graft_entry__ as ge
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe), "host/bdpt_render not built (run __graft_entry__.build())"
+    common = ["--scene", "cornell", "--width", "56", "--height", "40", "--depth", "4", "--mat", "0", "--out", str(tmp_path / "o.pfm")]
+
+    def run(extra):
+        r = subprocess.run([exe] + common + extra, capture_output=True, text=True, timeout=300)
+        return r
+
+    assert run(["--frames", "7", "--raw", str(tmp_path / "straight.f32")]).returncode == 0
+    assert run(["--frames", "3", "--raw", str(tmp_path / "part.f32"), "--checkpoint", str(tmp_path / "c.ckpt")]).returncode == 0
+    r = run(["--frames", "4", "--raw", str(tmp_path / "resumed.f32"), "--resume", str(tmp_path / "c.ckpt")])
+    assert r.returncode == 0, r.stderr
+    a = np.fromfile(tmp_path / "straight.f32", np.float32)
+    b = np.fromfile(tmp_path / "resumed.f32", np.float32)
+    c = np.fromfile(tmp_path / "part.f32", np.float32)
+    assert a.size == 56 * 40 * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert not np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    r = subprocess.run([exe, "--scene", "cornell", "--width", "48", "--height", "40", "--depth", "4", "--frames", "1", "--out", str(tmp_path / "o.pfm"),
+                        "--resume", str(tmp_path / "c.ckpt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "cannot resume" in r.stderr

@@ -250,6 +250,14 @@ BD void waveAddCount(DevCounters* c, int idx, uint32_t n) {
 // Inside, the loop is while-while: all lanes descend interior nodes together, then all lanes
 // that reached a leaf intersect triangles together.
 // ------------------------------------------------------------------------------------------------
+// Loop structure of the persistent kernels (0 = plain while-while): node visits in bursts of BDPT_NODE_BURST, leaves
+// intersected once BDPT_LEAF_WAIT lanes are waiting at one.
+#ifndef BDPT_LEAF_WAIT
+#define BDPT_LEAF_WAIT 32
+#endif
+#ifndef BDPT_NODE_BURST
+#define BDPT_NODE_BURST 3
+#endif
 #ifndef BDPT_REFILL_IDLE
 #define BDPT_REFILL_IDLE 16
 #endif
@@ -325,6 +333,40 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
     // OR one triangle test per iteration, whichever group is larger — raised lane utilisation from
     // 0.33 to 0.52 but executed as many wave instructions because of its per-iteration bookkeeping,
     // so the simpler loop stays: profiles/r1.)
+#if BDPT_LEAF_WAIT > 0
+    // Deferred leaves: every lane with a ray takes up to BDPT_NODE_BURST node visits; a lane that reaches a leaf (or runs
+    // out of stack) waits, and the leaves are intersected once BDPT_LEAF_WAIT lanes are waiting or no lane can take a
+    // node visit.  The plain while-while loop (#else) descends until EVERY lane sits on a leaf, so the node visits —
+    // nine tenths of the work — ran with a third of the lanes; a leaf phase after every node visit (if-if) or by
+    // majority vote (round 1) paid a 65-instruction triangle test for a handful of lanes per iteration.  Measured on
+    // the bench frame: any-hit tracing 7.9 -> 6.75 ms, walk 7.4 -> 6.6 ms (profiles/README.md).
+    if (has) {
+#pragma unroll 1
+      for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
+        if (COUNT) nNodes++;
+        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0>(S, T, stk);
+      }
+    }
+    const unsigned long long waitMask = __ballot(has && T.cur < 0), nodeMask = __ballot(has && T.cur >= 0);
+    if (__popcll(waitMask) >= BDPT_LEAF_WAIT || nodeMask == 0ull) {
+      if (has && T.cur < 0) {
+        bool finished = (T.cur == kDone);
+        if (!finished) {
+          finished = leafStep<2, COUNT>(S, T, nTris);
+          if (!finished) {
+            T.cur = travPop(T, stk);
+            finished = (T.cur == kDone);
+          }
+        }
+        if (finished) {
+          vis[rid] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
+          has = false;
+          T.cur = kDone;
+        }
+      }
+    }
+  }
+#else
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
@@ -345,6 +387,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
       }
     }
   }
+#endif
   if (COUNT) {
     waveAddCount(counters, C_NODE_SHADOW, nNodes);
     waveAddCount(counters, C_TRI_SHADOW, nTris);

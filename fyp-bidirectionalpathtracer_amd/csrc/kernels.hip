@@ -338,6 +338,12 @@ constexpr uint32_t kPoolEntries = 128;
 #ifndef BDPT_WALK_SHADE_MIN
 #define BDPT_WALK_SHADE_MIN 64  // parked hit records that trigger a shading pass (64 = every lane shades)
 #endif
+#ifndef BDPT_WALK_LEAF_WAIT
+#define BDPT_WALK_LEAF_WAIT 32  // deferred leaf phase (device_trace.hpp); 0 = plain while-while
+#endif
+#ifndef BDPT_WALK_NODE_BURST
+#define BDPT_WALK_NODE_BURST 3
+#endif
 #ifndef BDPT_WALK_CHUNK
 #define BDPT_WALK_CHUNK 64  // sub-paths per fetch from the valid-pixel lists
 #endif
@@ -503,8 +509,34 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
       if (nParked == 0 && nReady == 0 && exhausted) break;
       continue;  // parked records are flushed (or ready rays picked up) at the top
     }
-    // ---- 3. one while-while round of traversal for the lanes that hold a ray ---------------------------
+    // ---- 3. traversal for the lanes that hold a ray
     bool finished = false;
+#if BDPT_WALK_LEAF_WAIT > 0
+    // node visits in short bursts; a lane that reaches a leaf (or runs out of stack) waits, and the leaves are intersected
+    // once BDPT_WALK_LEAF_WAIT lanes are waiting or no lane can take a node step (device_trace.hpp, trace_shadow_kernel)
+    if (trav) {
+#pragma unroll 1
+      for (int kk = 0; kk < BDPT_WALK_NODE_BURST && T.cur >= 0; kk++) {
+        if (COUNT) nNodes++;
+        nodeStep<BDPT_WALK_ORDER>(S, T, stk);
+      }
+    }
+    {
+      const unsigned long long waitMask = __ballot(trav && T.cur < 0), nodeMask = __ballot(trav && T.cur >= 0);
+      if (__popcll(waitMask) >= BDPT_WALK_LEAF_WAIT || nodeMask == 0ull) {
+        if (trav && T.cur < 0) {
+          finished = (T.cur == kDone);
+          if (!finished) {
+            finished = leafStep<0, COUNT>(S, T, nTris);
+            if (!finished) {
+              T.cur = travPop(T, stk);
+              finished = (T.cur == kDone);
+            }
+          }
+        }
+      }
+    }
+#else
     if (trav) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
@@ -519,6 +551,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
         }
       }
     }
+#endif
     const unsigned long long finMask = __ballot(finished);
     if (finMask) {
       if (finished) {

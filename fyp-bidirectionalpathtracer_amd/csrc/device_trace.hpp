@@ -250,10 +250,13 @@ BD void waveAddCount(DevCounters* c, int idx, uint32_t n) {
 // Inside, the loop is while-while: all lanes descend interior nodes together, then all lanes
 // that reached a leaf intersect triangles together.
 // ------------------------------------------------------------------------------------------------
-// Loop structure of the persistent kernels (0 = plain while-while): node visits in bursts of BDPT_NODE_BURST, leaves
-// intersected once BDPT_LEAF_WAIT lanes are waiting at one.
+// Loop structure of the persistent kernels (BDPT_LEAF_WAIT 0 = plain while-while): node visits in bursts of
+// BDPT_NODE_BURST, leaves intersected once BDPT_LEAF_WAIT_FRAC8 eighths of the lanes that hold a ray are waiting at one.
 #ifndef BDPT_LEAF_WAIT
-#define BDPT_LEAF_WAIT 32
+#define BDPT_LEAF_WAIT 1
+#endif
+#ifndef BDPT_LEAF_WAIT_FRAC8
+#define BDPT_LEAF_WAIT_FRAC8 4
 #endif
 #ifndef BDPT_NODE_BURST
 #define BDPT_NODE_BURST 3
@@ -335,11 +338,11 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
     // so the simpler loop stays: profiles/r1.)
 #if BDPT_LEAF_WAIT > 0
     // Deferred leaves: every lane with a ray takes up to BDPT_NODE_BURST node visits; a lane that reaches a leaf (or runs
-    // out of stack) waits, and the leaves are intersected once BDPT_LEAF_WAIT lanes are waiting or no lane can take a
-    // node visit.  The plain while-while loop (#else) descends until EVERY lane sits on a leaf, so the node visits —
+    // out of stack) waits, and the leaves are intersected once half of the lanes that hold a ray are waiting or no lane
+    // can take a node visit.  The plain while-while loop (#else) descends until EVERY lane sits on a leaf, so the node visits —
     // nine tenths of the work — ran with a third of the lanes; a leaf phase after every node visit (if-if) or by
     // majority vote (round 1) paid a 65-instruction triangle test for a handful of lanes per iteration.  Measured on
-    // the bench frame: any-hit tracing 7.9 -> 6.75 ms, walk 7.4 -> 6.6 ms (profiles/README.md).
+    // the bench frame: any-hit tracing 7.9 -> 6.7 ms, walk 7.4 -> 6.5 ms (profiles/README.md).
     if (has) {
 #pragma unroll 1
       for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
@@ -348,7 +351,8 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
       }
     }
     const unsigned long long waitMask = __ballot(has && T.cur < 0), nodeMask = __ballot(has && T.cur >= 0);
-    if (__popcll(waitMask) >= BDPT_LEAF_WAIT || nodeMask == 0ull) {
+    const int waitNeed = (__popcll(waitMask | nodeMask) * BDPT_LEAF_WAIT_FRAC8 + 7) >> 3;
+    if ((int)__popcll(waitMask) >= waitNeed || nodeMask == 0ull) {
       if (has && T.cur < 0) {
         bool finished = (T.cur == kDone);
         if (!finished) {

@@ -339,7 +339,7 @@ constexpr uint32_t kPoolEntries = 128;
 #define BDPT_WALK_SHADE_MIN 64  // parked hit records that trigger a shading pass (64 = every lane shades)
 #endif
 #ifndef BDPT_WALK_LEAF_WAIT
-#define BDPT_WALK_LEAF_WAIT 32  // deferred leaf phase (device_trace.hpp); 0 = plain while-while
+#define BDPT_WALK_LEAF_WAIT 1  // deferred leaf phase (device_trace.hpp); 0 = plain while-while
 #endif
 #ifndef BDPT_WALK_NODE_BURST
 #define BDPT_WALK_NODE_BURST 3
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
     bool finished = false;
 #if BDPT_WALK_LEAF_WAIT > 0
     // node visits in short bursts; a lane that reaches a leaf (or runs out of stack) waits, and the leaves are intersected
-    // once BDPT_WALK_LEAF_WAIT lanes are waiting or no lane can take a node step (device_trace.hpp, trace_shadow_kernel)
+    // once half of the lanes that hold a ray are waiting or no lane can take a node visit (device_trace.hpp, trace_shadow_kernel)
     if (trav) {
 #pragma unroll 1
       for (int kk = 0; kk < BDPT_WALK_NODE_BURST && T.cur >= 0; kk++) {
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
     }
     {
       const unsigned long long waitMask = __ballot(trav && T.cur < 0), nodeMask = __ballot(trav && T.cur >= 0);
-      if (__popcll(waitMask) >= BDPT_WALK_LEAF_WAIT || nodeMask == 0ull) {
+      const int waitNeed = (__popcll(waitMask | nodeMask) * BDPT_LEAF_WAIT_FRAC8 + 7) >> 3;
+      if ((int)__popcll(waitMask) >= waitNeed || nodeMask == 0ull) {
         if (trav && T.cur < 0) {
           finished = (T.cur == kDone);
           if (!finished) {

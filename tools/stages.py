@@ -8,7 +8,7 @@ import torch
 import __graft_entry__ as ge
 
 pkg = ge.load_package()
-scene = pkg.Scene.atrium(1, 262144)
+scene = pkg.Scene.atrium(1, int(os.environ.get("BDPT_STAGES_TRIS", "262144")))
 pipe = pkg.FramePipeline(scene, 1920, 1080, max_depth=8, mat_index=0, accum_limit=10000)
 pipe.ctx.enable_stage_timing(True)
 agg = {}

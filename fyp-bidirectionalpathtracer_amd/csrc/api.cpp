@@ -322,10 +322,14 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
     fail(c, "bvh needs a deeper traversal stack than the device provides");
     return BDPT_E_LIMIT;
   }
+  if (bvh.recs.empty()) {
+    fail(c, "bvh does not fit the packed record format (2^31 records)");
+    return BDPT_E_LIMIT;
+  }
   c->bvhInfo.numNodes = (uint32_t)bvh.nodes.size();
   c->bvhInfo.numTriangles = d->numTriangles;
   c->bvhInfo.maxDepth = bvh.maxDepth;
-  c->bvhInfo.nodeBytes = sizeof(BvhNode);
+  c->bvhInfo.nodeBytes = sizeof(BvhRec);
   c->bvhInfo.triBytes = sizeof(BvhTri);
   c->bvhInfo.sahCost = bvh.sahCost;
   c->bvhInfo.maxStack = bvh.maxStack;
@@ -355,15 +359,13 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   });
 
   int rc;
-  const BvhNode* dNodes;
-  const BvhTri* dTris;
+  const BvhRec* dRecs;
   const float* dShade;
-  if ((rc = devUpload(c, c->sceneAllocs, &dNodes, bvh.nodes.data(), bvh.nodes.size()))) return rc;
-  if ((rc = devUpload(c, c->sceneAllocs, &dTris, bvh.tris.data(), bvh.tris.size()))) return rc;
+  if ((rc = devUpload(c, c->sceneAllocs, &dRecs, bvh.recs.data(), bvh.recs.size()))) return rc;
   if ((rc = devUpload(c, c->sceneAllocs, &dShade, shade.data(), shade.size()))) return rc;
-  c->S.nodes = reinterpret_cast<const float4*>(dNodes);
-  c->S.tris = reinterpret_cast<const float4*>(dTris);
+  c->S.recs = reinterpret_cast<const uint4*>(dRecs);
   c->S.shade = reinterpret_cast<const float4*>(dShade);
+  c->S.numRecs = (uint32_t)bvh.recs.size();
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.indices, d->indices, (size_t)d->numTriangles * 3))) return rc;
   if (d->bitangents) {
     if ((rc = devUpload(c, c->sceneAllocs, &c->S.bitangents, d->bitangents, (size_t)d->numVertices * 3))) return rc;
@@ -409,7 +411,7 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   out->numNodes = (uint32_t)bvh.nodes.size();
   out->numTriangles = d->numTriangles;
   out->maxDepth = bvh.maxDepth;
-  out->nodeBytes = sizeof(BvhNode);
+  out->nodeBytes = sizeof(BvhRec);
   out->triBytes = sizeof(BvhTri);
   out->sahCost = bvh.sahCost;
   out->maxStack = bvh.maxStack;
@@ -494,6 +496,67 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   if (!ok) return say(why);
   for (uint32_t i = 0; i < d->numTriangles; i++)
     if (!covered[i]) return say("a leaf-order triangle is not referenced by any leaf");
+  // the packed 48-byte records (what the device traverses) must decode to the same tree
+  if (bvh.recs.empty()) return say("packed records missing");
+  std::vector<uint8_t> used(bvh.recs.size(), 0);
+  std::function<void(uint32_t, uint32_t, uint32_t)> walkPacked = [&](uint32_t rec, uint32_t node, uint32_t depth) {
+    if (!ok) return;
+    if (rec >= bvh.recs.size() || used[rec] || depth > 64) {
+      ok = false;
+      why = "packed node record out of range or shared";
+      return;
+    }
+    used[rec] = 1;
+    const BvhRec& r = bvh.recs[rec];
+    const BvhNode& n = bvh.nodes[node];
+    bool same = std::memcmp(&r.w[0], n.origin, 12) == 0 && std::memcmp(&r.w[4], n.lo, 12) == 0 && std::memcmp(&r.w[7], n.hi, 12) == 0;
+    for (int a = 0; a < 3; a++) {
+      const uint32_t bits = ((r.w[3] >> (8 * a)) & 0xffu) << 23;  // the device's decode
+      float f;
+      std::memcpy(&f, &bits, 4);
+      same = same && f == n.scale[a];
+    }
+    if (!same) {
+      ok = false;
+      why = "packed node does not decode to its node";
+      return;
+    }
+    const uint32_t numChildren = (uint32_t)bvhNumChildren(n);
+    for (uint32_t c = 0; c < numChildren; c++) {
+      const uint32_t idx = r.w[10] + ((r.w[11] >> (8 * c)) & 0xffu);
+      const bool leaf = ((r.w[3] >> (24 + c)) & 1u) != 0;
+      const int32_t ref = n.child[c];
+      if (leaf != (ref < 0)) {
+        ok = false;
+        why = "packed child kind differs";
+        return;
+      }
+      if (!leaf) {
+        walkPacked(idx, (uint32_t)ref, depth + 1);
+        continue;
+      }
+      const uint32_t enc = (uint32_t)(-1 - ref), first = enc >> 3, cnt = (enc & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; k++) {
+        if (idx + k >= bvh.recs.size() || used[idx + k]) {
+          ok = false;
+          why = "packed leaf out of range or shared";
+          return;
+        }
+        used[idx + k] = 1;
+        BvhTri t = bvh.tris[first + k];
+        if (k + 1 == cnt) t.flags |= kTriLastOfLeaf;
+        if (std::memcmp(&bvh.recs[idx + k], &t, sizeof(BvhTri)) != 0) {
+          ok = false;
+          why = "packed leaf triangle differs";
+          return;
+        }
+      }
+    }
+  };
+  walkPacked(0, 0, 0);
+  if (!ok) return say(why);
+  for (size_t i = 0; i < used.size(); i++)
+    if (!used[i]) return say("a packed record is not referenced");
   return BDPT_OK;
 }
 
@@ -508,6 +571,7 @@ int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_has
   };
   mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
   mix(bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri));
+  mix(bvh.recs.data(), bvh.recs.size() * sizeof(BvhRec));
   mix(&bvh.maxDepth, sizeof(bvh.maxDepth));
   mix(&bvh.maxStack, sizeof(bvh.maxStack));
   mix(&bvh.sahCost, sizeof(bvh.sahCost));
@@ -516,7 +580,7 @@ int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_has
     out_info->numNodes = (uint32_t)bvh.nodes.size();
     out_info->numTriangles = d->numTriangles;
     out_info->maxDepth = bvh.maxDepth;
-    out_info->nodeBytes = sizeof(BvhNode);
+    out_info->nodeBytes = sizeof(BvhRec);
     out_info->triBytes = sizeof(BvhTri);
     out_info->sahCost = bvh.sahCost;
     out_info->maxStack = bvh.maxStack;

@@ -53,9 +53,27 @@ static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
 constexpr int kBvhMaxStack = BDPT_BVH_STACK_BUDGET;  // worst-case traversal stack entries (the device stack holds KSTACK per lane)
 constexpr uint32_t kTriNonOpaque = 1u, kTriDoubleSided = 2u;
 
+// What the device traverses: ONE array of 48-byte records in which a node's children — interior nodes (one record
+// each) and leaves (their triangles, one BvhTri record each) — follow one another from `childBase` on.
+// A divergent wave pays for every 16-byte load of every lane (the vector-memory address unit takes one lane-load per
+// clock per CU: profiles/README.md), so a node visit is three loads here instead of four:
+//   word 0-2  origin.xyz (float)
+//   word 3    biased scale exponents ex | ey << 8 | ez << 16 (scale = 2^(e-127)), leaf bits << 24 (bit c: child c is a leaf)
+//   word 4-9  lo.x lo.y lo.z hi.x hi.y hi.z, four child bytes each (as BvhNode)
+//   word 10   childBase: record index of the first child
+//   word 11   record offset of child c from childBase in byte c (child 0: 0)
+// Device references: ref >= 0 interior record index; ref < 0 leaf, ~ref = record index of its first triangle; the last
+// triangle of a leaf carries kTriLastOfLeaf in its flags.  The root is record 0.
+struct alignas(16) BvhRec {
+  uint32_t w[12];
+};
+static_assert(sizeof(BvhRec) == 48, "record must be 48 bytes");
+constexpr uint32_t kTriLastOfLeaf = 4u;  // BvhTri::flags bit set by packBvh (device-side records only)
+
 struct Bvh {
   std::vector<BvhNode> nodes;
   std::vector<BvhTri> tris;  // in leaf order
+  std::vector<BvhRec> recs;  // packed device form of the two (packBvh)
   uint32_t maxDepth = 0;     // depth of the four-wide tree
   uint32_t maxStack = 0;     // worst-case number of simultaneously stacked references
   float sahCost = 0.0f;
@@ -67,6 +85,10 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTrian
               int threads = 0);
 // host threads the builder uses by default: BDPT_BUILD_THREADS, else the affinity mask capped by the cgroup CPU quota
 int bvhBuildThreads();
+
+// Re-encodes nodes + tris as the 48-byte record array (called by buildBvh; a pure function of the two).
+// Returns false when a child block does not fit the format (more than 255 records before a node's last child).
+bool packBvh(Bvh& bvh, int threads = 0);
 
 // Decode one quantised plane exactly as the device does.
 inline float bvhDecodePlane(const BvhNode& n, int axis, uint8_t q) { return n.origin[axis] + (float)q * n.scale[axis]; }

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 #include <sched.h>
@@ -486,6 +487,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
     for (int c = 0; c < 4; c++) nd.child[c] = -1;
     nd.scale[0] = nd.scale[1] = nd.scale[2] = 1.0f;
     out.nodes.push_back(nd);
+    packBvh(out, 1);
     return;
   }
   // Binary height of every subtree: the stack need of a subtree left two-wide is its height, so a
@@ -625,6 +627,79 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
   for (size_t wi = 1; wi < wide.size(); wi++) out.nodes[(size_t)slots[wi].first].child[slots[wi].second] = (int32_t)wi;
   out.sahCost = (float)cost + kCostTraverse;
   lap("quantise");
+  if (!packBvh(out, threads)) out.recs.clear();  // (leaves of at most 8 triangles always fit: 3 x 8 < 256)
+  lap("pack");
+}
+
+bool packBvh(Bvh& bvh, int threads) {
+  if (threads <= 0) threads = bvhBuildThreads();
+  const size_t nn = bvh.nodes.size();
+  // record index of every node, and of every node's first child: parents come before their children in `nodes`,
+  // so one pass in index order hands out the child blocks (a node's block follows the blocks of all earlier nodes)
+  std::vector<uint32_t> pos(nn, 0), base(nn, 0);
+  uint64_t next = 1;  // record 0 = the root
+  for (size_t i = 0; i < nn; i++) {
+    const BvhNode& n = bvh.nodes[i];
+    const int nk = bvhNumChildren(n);
+    base[i] = (uint32_t)next;
+    for (int c = 0; c < nk; c++) {
+      const int32_t r = n.child[c];
+      if (r >= 0) {
+        if ((size_t)r <= i || (size_t)r >= nn) return false;
+        pos[(size_t)r] = (uint32_t)next;
+        next += 1;
+      } else {
+        next += (uint64_t)(((uint32_t)(-1 - r)) & 7u) + 1u;
+      }
+    }
+    if (next >= 0x7fffffffull) return false;
+  }
+  bvh.recs.assign((size_t)next, BvhRec{});
+  bool ok = true;
+  std::mutex failMutex;
+  parallelFor(nn, threads, [&](size_t i0, size_t i1, int) {
+    for (size_t i = i0; i < i1; i++) {
+      const BvhNode& n = bvh.nodes[i];
+      BvhRec rec{};
+      std::memcpy(&rec.w[0], n.origin, 12);
+      uint32_t ex[3];
+      for (int a = 0; a < 3; a++) {
+        uint32_t bits;
+        std::memcpy(&bits, &n.scale[a], 4);
+        ex[a] = (bits >> 23) & 0xffu;  // the scales are powers of two: mantissa 0, sign 0
+      }
+      std::memcpy(&rec.w[4], n.lo, 12);
+      std::memcpy(&rec.w[7], n.hi, 12);
+      const int nk = bvhNumChildren(n);
+      uint32_t leafBits = 0, offs = 0, off = 0;
+      for (int c = 0; c < nk; c++) {
+        if (off > 255u) {
+          std::lock_guard<std::mutex> g(failMutex);
+          ok = false;
+          break;
+        }
+        offs |= off << (8 * c);
+        const int32_t r = n.child[c];
+        if (r >= 0) {
+          off += 1;
+        } else {
+          leafBits |= 1u << c;
+          const uint32_t enc = (uint32_t)(-1 - r), first = enc >> 3, cnt = (enc & 7u) + 1u;
+          for (uint32_t k = 0; k < cnt; k++) {
+            BvhTri t = bvh.tris[first + k];
+            if (k + 1 == cnt) t.flags |= kTriLastOfLeaf;
+            std::memcpy(&bvh.recs[(size_t)base[i] + off + k], &t, sizeof(BvhRec));
+          }
+          off += cnt;
+        }
+      }
+      rec.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (leafBits << 24);
+      rec.w[10] = base[i];
+      rec.w[11] = offs;
+      bvh.recs[pos[i]] = rec;
+    }
+  });
+  return ok;
 }
 
 }  // namespace bdpt

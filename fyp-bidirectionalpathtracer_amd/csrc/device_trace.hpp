@@ -75,16 +75,18 @@ BD float ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  /
 // entered, the rest stacked in slot order; ORDER 0 (any hit): slot order.
 template <int ORDER>
 BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
-  const uint4* np = reinterpret_cast<const uint4*>(S.nodes) + (size_t)T.cur * 4;
-  const uint4 q0 = np[0], q1 = np[1], q2 = np[2];  // origin.xyz scale.x | scale.yz lo.x lo.y | lo.z hi.xyz
-  const uint4 q3 = np[3];                          // child refs
-  const float ax = __uint_as_float(q0.w) * T.idir.x, ay = __uint_as_float(q1.x) * T.idir.y, az = __uint_as_float(q1.y) * T.idir.z;
+  const uint4* np = S.recs + (size_t)T.cur * 3;
+  // origin.xyz, exponents + leaf bits | lo.x lo.y lo.z hi.x | hi.y hi.z childBase childOffsets   (bvh.h BvhRec)
+  const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+  const float sx = __uint_as_float((q0.w << 23) & 0x7f800000u), sy = __uint_as_float((q0.w << 15) & 0x7f800000u),
+              sz = __uint_as_float((q0.w << 7) & 0x7f800000u);
+  const float ax = sx * T.idir.x, ay = sy * T.idir.y, az = sz * T.idir.z;
   const float bx = (__uint_as_float(q0.x) - T.o.x) * T.idir.x, by = (__uint_as_float(q0.y) - T.o.y) * T.idir.y,
               bz = (__uint_as_float(q0.z) - T.o.z) * T.idir.z;
   const bool nx = (T.neg & 1u) != 0, ny = (T.neg & 2u) != 0, nz = (T.neg & 4u) != 0;
-  const uint32_t nearX = nx ? q2.y : q1.z, farX = nx ? q1.z : q2.y;
-  const uint32_t nearY = ny ? q2.z : q1.w, farY = ny ? q1.w : q2.z;
-  const uint32_t nearZ = nz ? q2.w : q2.x, farZ = nz ? q2.x : q2.w;
+  const uint32_t nearX = nx ? q1.w : q1.x, farX = nx ? q1.x : q1.w;
+  const uint32_t nearY = ny ? q2.x : q1.y, farY = ny ? q1.y : q2.x;
+  const uint32_t nearZ = nz ? q2.y : q1.z, farZ = nz ? q1.z : q2.y;
   float tn[4];
   bool hit[4];
 #pragma unroll
@@ -97,7 +99,11 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
     hit[c] = n <= f;
     tn[c] = n;
   }
-  int r0 = (int)q3.x, r1 = (int)q3.y, r2 = (int)q3.z, r3 = (int)q3.w;
+  // child c: record childBase + offset byte c; a leaf reference is the complement of its first triangle's record index
+  int r0 = (int)q2.z ^ ((int)(q0.w << 7) >> 31);
+  int r1 = (int)(q2.z + ((q2.w >> 8) & 0xffu)) ^ ((int)(q0.w << 6) >> 31);
+  int r2 = (int)(q2.z + ((q2.w >> 16) & 0xffu)) ^ ((int)(q0.w << 5) >> 31);
+  int r3 = (int)(q2.z + (q2.w >> 24)) ^ ((int)(q0.w << 4) >> 31);
   if (ORDER == 2) {
     // nearest hit child by a 3-comparator min tree over (t, slot); every other hit child goes on the stack in slot
     // order with unconditional stores (a slot above sp is scratch) and a conditional stack-pointer bump
@@ -164,14 +170,15 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
   }
 }
 
-// One triangle of a leaf (index into S.tris); returns true when an any-hit query is finished.
+// One triangle of a leaf (record index); returns true when an any-hit query is finished; `last`: the leaf ends here.
 // Moeller-Trumbore exactly as the oracle evaluates it (this is the part that must match bit for bit).
 template <int MODE>
-BD bool triStep(const SceneDev& S, TravState& T, uint32_t triIndex) {
-  const float4* tp = S.tris + (size_t)triIndex * 3;
+BD bool triStep(const SceneDev& S, TravState& T, uint32_t rec, bool& last) {
+  const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)rec * 3;
   const float4 a = tp[0], b = tp[1], c = tp[2];
   const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
   const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
+  last = (flags & 4u) != 0;  // kTriLastOfLeaf
   const f3 pvec = cross(T.d, e2);
   const float det = dot(e1, pvec);
   if (MODE == 1 && !(flags & 2u)) {
@@ -206,13 +213,14 @@ BD bool triStep(const SceneDev& S, TravState& T, uint32_t triIndex) {
 // All triangles of the leaf in T.cur; returns true when an any-hit query is finished.
 template <int MODE, bool COUNT>
 BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
-  const uint32_t enc = (uint32_t)(-1 - T.cur);
-  const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-  for (uint32_t k = 0; k < cnt; k++) {
+  uint32_t rec = (uint32_t)~T.cur;
+  for (;;) {
+    bool last;
     if (COUNT) nTris++;
-    if (triStep<MODE>(S, T, first + k)) return true;
+    if (triStep<MODE>(S, T, rec, last)) return true;
+    if (last) return false;
+    rec++;
   }
-  return false;
 }
 
 // Whole query by one lane (coherent primary rays, test hooks, the few lazy rays of the gather stage).

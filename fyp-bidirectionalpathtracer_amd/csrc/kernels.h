@@ -54,8 +54,7 @@ struct SceneConst {
 };
 
 struct SceneDev {
-  const float4* nodes;      // 4 per node
-  const float4* tris;       // 3 per leaf triangle, leaf order
+  const uint4* recs;        // 3 per 48-byte record: interior nodes and leaf triangles in one array (bvh.h BvhRec)
   const float4* shade;      // kShadeRecF4 per primitive, primitive order
   const float* bitangents;  // 3 per vertex (normal-mapped primary hits only)
   const uint32_t* indices;  // 3 per primitive
@@ -64,6 +63,7 @@ struct SceneDev {
   const SceneConst* sc;
   uint32_t numLights;
   uint32_t hasBitangents;
+  uint32_t numRecs;
 };
 
 struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; one 128-byte line per shard

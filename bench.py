@@ -27,6 +27,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; its measur
 PROFILE_ROUND = "r2"   # profiles/<round>/hbm_traffic_pmc.json holds the PMC traffic the roofline block quotes
 
 
+SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 48  # algorithmic bytes per interior-node / triangle visit
+
+
 def num_connect_pairs(D):
     """Connection pairs the reference defines for depth D (BDPTMain.rt.hlsl:212-216)."""
     return sum(min(t, D - 1) for t in range(2, D + 1))
@@ -354,7 +357,9 @@ def main():
         # ---- roofline per kernel and for the whole frame.  Algorithmic bytes from the device tallies
         # of one frame of the same sequence; durations = HIP events on the launch stream around each kernel's launches
         # (bdpt_get_stage_times), summed over the frame, averaged over the frames named in stage_timing.
-        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, info.nodeBytes, info.triBytes)
+        # SURVEY's per-unit figures (64 B per interior-node visit, 48 B per leaf triangle) whatever the build stores: the
+        # records of this build are 48 B each (config.bvh.node_bytes), so a node visit FETCHES 48 B and is COSTED at 64
+        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, SURVEY_NODE_BYTES, SURVEY_TRI_BYTES)
         ms = {k: v / stage_frames for k, v in stage_ms.items()}
         kernel_ms = {
             "walk_kernel": ms.get("walk", 0.0),
@@ -449,7 +454,9 @@ def main():
                           "achieved": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 1) if frame_ms > 0 else 0.0,
                           "frac": round(frame_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms > 0 else 0.0,
                           "traffic": sum(traffic.values()) if traffic else None},
-                "note": "achieved = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit) / measured time, against HBM peak; "
+                "node_bytes_costed": SURVEY_NODE_BYTES, "node_bytes_fetched": info.nodeBytes,
+                "note": "achieved = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit; an interior-node visit costed at "
+                        "SURVEY's 64 B although this build's node records are 48 B) / measured time, against HBM peak; "
                         "traffic = HBM-side bytes from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE).  The BVH of this scene "
                         "lives in L2/MALL, so traffic << algorithmic bytes for the two traversal kernels: they are bound by "
                         "VALU issue under lane divergence, not by HBM; frac says how close node/triangle delivery is to what "

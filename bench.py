@@ -458,9 +458,10 @@ def main():
                 "note": "achieved = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit; an interior-node visit costed at "
                         "SURVEY's 64 B although this build's node records are 48 B) / measured time, against HBM peak; "
                         "traffic = HBM-side bytes from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE).  The BVH of this scene "
-                        "lives in L2/MALL, so traffic << algorithmic bytes for the two traversal kernels: they are bound by "
-                        "VALU issue under lane divergence, not by HBM; frac says how close node/triangle delivery is to what "
-                        "HBM could stream.  gen_kernels exceed 1: SURVEY's 200 B per connection pair assumes both vertices are fetched per "
+                        "lives in L2/MALL, so traffic << algorithmic bytes for the two traversal kernels: HBM does not bound them; "
+                        "they sit at about 0.7 of the vector-memory address rate and 0.6-0.7 of VALU issue at half of the lanes "
+                        "(DESIGN.md section 4: measured sensitivities; `bound` is the largest counter fraction); frac says how "
+                        "close node/triangle delivery is to what HBM could stream.  gen_kernels exceed 1: SURVEY's 200 B per connection pair assumes both vertices are fetched per "
                         "pair, the generator fetches every vertex record once per pixel and shares it through LDS",
             },
         }

@@ -173,9 +173,7 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
 // One triangle of a leaf (record index); returns true when an any-hit query is finished; `last`: the leaf ends here.
 // Moeller-Trumbore exactly as the oracle evaluates it (this is the part that must match bit for bit).
 template <int MODE>
-BD bool triStep(const SceneDev& S, TravState& T, uint32_t rec, bool& last) {
-  const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)rec * 3;
-  const float4 a = tp[0], b = tp[1], c = tp[2];
+BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, bool& last) {
   const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
   const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
   last = (flags & 4u) != 0;  // kTriLastOfLeaf
@@ -213,14 +211,25 @@ BD bool triStep(const SceneDev& S, TravState& T, uint32_t rec, bool& last) {
 // All triangles of the leaf in T.cur; returns true when an any-hit query is finished.
 template <int MODE, bool COUNT>
 BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
-  uint32_t rec = (uint32_t)~T.cur;
-  for (;;) {
-    bool last;
+  // The first TWO records are fetched together (six loads in flight): half of the leaves hold two triangles and their
+  // second test would otherwise wait for a second, dependent fetch; a one-triangle leaf fetches the record behind it
+  // for nothing (the array ends with a pad record).
+  const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(uint32_t)~T.cur * 3;
+  const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2], a1 = tp[3], b1 = tp[4], c1 = tp[5];
+  bool last;
+  if (COUNT) nTris++;
+  if (triStep<MODE>(S, T, a0, b0, c0, last)) return true;
+  if (last) return false;
+  if (COUNT) nTris++;
+  if (triStep<MODE>(S, T, a1, b1, c1, last)) return true;
+  tp += 6;
+  while (!last) {  // leaves of more than two triangles (builder knob BDPT_LEAF_MAX)
+    const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) nTris++;
-    if (triStep<MODE>(S, T, rec, last)) return true;
-    if (last) return false;
-    rec++;
+    if (triStep<MODE>(S, T, a, b, c, last)) return true;
+    tp += 3;
   }
+  return false;
 }
 
 // Whole query by one lane (coherent primary rays, test hooks, the few lazy rays of the gather stage).

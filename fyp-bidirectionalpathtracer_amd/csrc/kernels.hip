@@ -945,58 +945,90 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
 // zero-valued pairs still matter, because the first visible one would have saturated the pixel
 // (rgb clamp + alpha = 1).  Visible splats are added to the fixed-point splat buffer (quirk 6).
 // ------------------------------------------------------------------------------------------------
+// The slots of a pixel are read eight at a time: first the eight ray ids, then their visibility bytes, then the
+// contributions of the visible ones — three rounds of independent loads instead of a (id -> visibility -> contribution)
+// chain per slot; the sums below still run in the reference's order.
+constexpr int kGatherChunk = 8;
+struct SlotChunk {
+  uint32_t id[kGatherChunk];
+  bool vis[kGatherChunk];
+  float cx[kGatherChunk], cy[kGatherChunk], cz[kGatherChunk];
+};
+BD void loadSlotChunk(const PathBuf& P, uint32_t p, int slot0, int n, SlotChunk& c) {
+  const size_t cap = P.rayCap;
+#pragma unroll
+  for (int j = 0; j < kGatherChunk; j++) c.id[j] = (j < n) ? P.slotRay[(size_t)(slot0 + j) * P.Np + p] : kNoRay;
+#pragma unroll
+  for (int j = 0; j < kGatherChunk; j++) c.vis[j] = (c.id[j] != kNoRay) && (P.rayVis[c.id[j]] != 0);
+#pragma unroll
+  for (int j = 0; j < kGatherChunk; j++) {
+    c.cx[j] = c.cy[j] = c.cz[j] = 0.0f;
+    if (c.vis[j]) {
+      c.cx[j] = P.rayContrib[c.id[j]];
+      c.cy[j] = P.rayContrib[cap + c.id[j]];
+      c.cz[j] = P.rayContrib[2 * cap + c.id[j]];
+    }
+  }
+}
+
 BD bool gatherLane(const FrameDev& F, const PathBuf& P, uint32_t p, uint32_t& nSplat) {
   bool pending = false;
   const size_t pix = P.pix[p];
   float4* out4 = reinterpret_cast<float4*>(F.out);
   float4 acc = out4[pix];
   const int D = (int)F.p.maxDepth;
-  const size_t cap = P.rayCap;
+  SlotChunk c;
   if (!(F.p.flags & BDPT_PARAM_NO_NEE)) {
-    for (int t = 0; t < D; t++) {
-      const uint32_t id = P.slotRay[(size_t)t * P.Np + p];
-      if (id != kNoRay && P.rayVis[id]) {
-        acc.x = acc.x + P.rayContrib[id];
-        acc.y = acc.y + P.rayContrib[cap + id];
-        acc.z = acc.z + P.rayContrib[2 * cap + id];
-      } else {
-        acc.x = acc.x + 0.0f;
-        acc.y = acc.y + 0.0f;
-        acc.z = acc.z + 0.0f;
-      }
-      acc.w = acc.w + 1.0f;
+    for (int t0 = 0; t0 < D; t0 += kGatherChunk) {
+      const int n = (D - t0 < kGatherChunk) ? D - t0 : kGatherChunk;
+      loadSlotChunk(P, p, t0, n, c);
+#pragma unroll
+      for (int j = 0; j < kGatherChunk; j++)
+        if (j < n) {  // an occluded or absent term adds 0 (the sum's rounding is the reference's either way)
+          acc.x = acc.x + c.cx[j];
+          acc.y = acc.y + c.cy[j];
+          acc.z = acc.z + c.cz[j];
+          acc.w = acc.w + 1.0f;
+        }
     }
   }
   if (!(F.p.flags & BDPT_PARAM_NO_CONNECT)) {
     const int nPairs = (int)numConnectPairs((uint32_t)D);
     bool sat = false;
-    for (int s = 0; s < nPairs; s++) {
-      const uint32_t id = P.slotRay[(size_t)(2 * D + s) * P.Np + p];
-      if (id != kNoRay && P.rayVis[id]) {
-        acc.x = saturate(acc.x + P.rayContrib[id]);
-        acc.y = saturate(acc.y + P.rayContrib[cap + id]);
-        acc.z = saturate(acc.z + P.rayContrib[2 * cap + id]);
-        acc.w = saturate(acc.w + 1.0f);
-        sat = true;
-      }
+    for (int s0 = 0; s0 < nPairs; s0 += kGatherChunk) {
+      const int n = (nPairs - s0 < kGatherChunk) ? nPairs - s0 : kGatherChunk;
+      loadSlotChunk(P, p, 2 * D + s0, n, c);
+#pragma unroll
+      for (int j = 0; j < kGatherChunk; j++)
+        if (c.vis[j]) {
+          acc.x = saturate(acc.x + c.cx[j]);
+          acc.y = saturate(acc.y + c.cy[j]);
+          acc.z = saturate(acc.z + c.cz[j]);
+          acc.w = saturate(acc.w + 1.0f);
+          sat = true;
+        }
     }
     pending = (!sat && nPairs > 0);  // settled by the lazy rounds below
   }
   out4[pix] = acc;
   if (!(F.p.flags & BDPT_PARAM_NO_SPLAT)) {
-    for (int t = 0; t < D; t++) {
-      const uint32_t id = P.slotRay[(size_t)(D + t) * P.Np + p];
-      if (id == kNoRay || !P.rayVis[id]) continue;
-      const uint32_t target = P.splatPix[(size_t)t * P.Np + p];
-      if (target == kNoRay) continue;  // outside the frame (quirk 8)
-      unsigned long long* sp = F.splat + (size_t)target * 4;
-      const unsigned long long qx = toFixed(P.rayContrib[id]), qy = toFixed(P.rayContrib[cap + id]),
-                               qz = toFixed(P.rayContrib[2 * cap + id]);
-      if (qx) atomicAdd(&sp[0], qx);
-      if (qy) atomicAdd(&sp[1], qy);
-      if (qz) atomicAdd(&sp[2], qz);
-      atomicAdd(&sp[3], 1ull);
-      nSplat++;
+    for (int t0 = 0; t0 < D; t0 += kGatherChunk) {
+      const int n = (D - t0 < kGatherChunk) ? D - t0 : kGatherChunk;
+      loadSlotChunk(P, p, D + t0, n, c);
+      uint32_t target[kGatherChunk];
+#pragma unroll
+      for (int j = 0; j < kGatherChunk; j++) target[j] = c.vis[j] ? P.splatPix[(size_t)(t0 + j) * P.Np + p] : kNoRay;
+#pragma unroll
+      for (int j = 0; j < kGatherChunk; j++) {
+        if (!c.vis[j] || target[j] == kNoRay) continue;  // kNoRay: outside the frame (quirk 8)
+        unsigned long long* sp = F.splat + (size_t)target[j] * 4;
+        const unsigned long long qx = toFixed(c.cx[j]), qy = toFixed(c.cy[j]), qz = toFixed(c.cz[j]);
+        if (qx) atomicAdd(&sp[0], qx);
+        if (qy) atomicAdd(&sp[1], qy);
+        if (qz) atomicAdd(&sp[2], qz);
+        atomicAdd(&sp[3], 1ull);
+        nSplat++;
+      }
     }
   }
   return pending;

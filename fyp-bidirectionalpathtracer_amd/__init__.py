@@ -227,6 +227,17 @@ class Context:
                     "bdpt_test_trace")
         return prim, tuv
 
+    def test_trace_shadow(self, rays):
+        """The persistent any-hit kernel over host rays (n x 8 float32): visibility bytes and the deepest stack reached."""
+        import numpy as np
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        vis = np.zeros(n, np.uint8)
+        deep = C.c_uint32(0)
+        self._check(self._lib.bdpt_test_trace_shadow(self._h, rays.ctypes.data, n, vis.ctypes.data, C.byref(deep)),
+                    "bdpt_test_trace_shadow")
+        return vis, deep.value
+
     def test_bsdf(self, recs, mat_index):
         import numpy as np
         recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 20)

@@ -155,6 +155,7 @@ PROTOTYPES = {
     "bdpt_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdpt_test_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bdpt_test_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "bdpt_test_trace_shadow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bdpt_test_bsdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "bdpt_scene_create_cornell": (C.c_void_p, []),
     "bdpt_scene_create_atrium": (C.c_void_p, [C.c_uint32, C.c_uint32]),

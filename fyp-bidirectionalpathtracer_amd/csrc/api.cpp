@@ -67,6 +67,8 @@ struct bdpt_ctx {
   bool evCreated = false;
   int lazyRounds = 3;
   LaunchGrids grids{};  // persistent-grid sizes for this context's device
+  int* stackOvf = nullptr;      // overflow rows of the persistent kernels' traversal stacks (kernels.h kStackLds)
+  uint32_t stackOvfStride = 0;  // lanes per row: every wave a persistent grid can hold
   // channels of the built-in primary stage (bdpt_execute with in == NULL): bdpt_prepare or first use
   bdpt_gbuffer ownGb{};
   // BMFR history (bdpt_prepare or the first bdpt_bmfr_execute): [2] = ping-pong pair
@@ -234,6 +236,13 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
     bdpt_destroy(c);
     return BDPT_E_HIP;
   }
+  // traversal-stack overflow rows for the largest persistent grid (kMaxPersistentPerCU waves per CU)
+  c->stackOvfStride = (uint32_t)c->numCUs * kMaxPersistentPerCU * kWave;
+  if (kStackLds < kStackEntries &&
+      hipMalloc(reinterpret_cast<void**>(&c->stackOvf), (size_t)(kStackEntries - kStackLds) * c->stackOvfStride * sizeof(int)) != hipSuccess) {
+    bdpt_destroy(c);
+    return BDPT_E_NOMEM;
+  }
   *out_ctx = c;
   return BDPT_OK;
 }
@@ -242,6 +251,7 @@ void bdpt_destroy(bdpt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  if (c->stackOvf) (void)hipFree(c->stackOvf);
   freePool(c->sceneAllocs);
   freePool(c->frameAllocs);
   if (c->evCreated)
@@ -305,6 +315,8 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   freePool(c->sceneAllocs);
   c->haveScene = false;
   c->S = SceneDev{};
+  c->S.stackOvf = c->stackOvf;
+  c->S.stackOvfStride = c->stackOvfStride;
 
   // per-triangle traversal flags: BLAS OPAQUE iff AlphaModeOpaque (Falcor Raytracing/RtModel.cpp:221-224),
   // TRIANGLE_CULL_DISABLE iff double-sided (Raytracing/RtScene.cpp:175-178)
@@ -1232,6 +1244,51 @@ int bdpt_test_trace(bdpt_ctx* c, const float* rays, uint32_t n, int mode, int32_
   if (e != hipSuccess) {
     fail(c, hipGetErrorString(e));
     return BDPT_E_HIP;
+  }
+  return BDPT_OK;
+}
+
+int bdpt_test_trace_shadow(bdpt_ctx* c, const float* rays, uint32_t n, uint8_t* out_vis, uint32_t* out_max_stack) {
+  if (!c || !rays || !out_vis || !n) return BDPT_E_INVALID;
+  if (!c->haveScene) return BDPT_E_STATE;
+  ENTER(c);
+  // SoA planes as the ray queue holds them; tmin comes from ray 0 (the kernel takes one tmin per launch)
+  std::vector<float> planes((size_t)7 * n);
+  for (uint32_t i = 0; i < n; i++) {
+    const float* r = rays + (size_t)i * 8;
+    for (int k = 0; k < 6; k++) planes[(size_t)k * n + i] = r[k];
+    planes[(size_t)6 * n + i] = r[7];
+  }
+  std::vector<uint32_t> cursors(2 * kCursorStride, 0u);
+  cursors[0] = n;  // count; head = cursors[kCursorStride] = 0
+  std::vector<void*> pool;
+  const float* dp;
+  const uint32_t* dc;
+  uint8_t* dv;
+  DevCounters* dcnt;
+  int rc;
+  if ((rc = devUpload(c, pool, &dp, planes.data(), planes.size())) || (rc = devUpload(c, pool, &dc, cursors.data(), cursors.size())) ||
+      (rc = devAlloc(c, pool, &dv, (size_t)n)) || (rc = devAlloc(c, pool, &dcnt, 1))) {
+    freePool(pool);
+    return rc;
+  }
+  hipError_t e = hipMemset(dcnt, 0, sizeof(DevCounters));
+  if (e == hipSuccess) {
+    launchTestTraceShadow(c->S, dp, n, dc, const_cast<uint32_t*>(dc) + kCursorStride, dv, dcnt, rays[6], c->numCUs, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  DevCounters h;
+  if (e == hipSuccess) e = hipMemcpy(out_vis, dv, (size_t)n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&h, dcnt, sizeof(h), hipMemcpyDeviceToHost);
+  freePool(pool);
+  if (e != hipSuccess) {
+    fail(c, hipGetErrorString(e));
+    return BDPT_E_HIP;
+  }
+  if (out_max_stack) {
+    unsigned long long m = 0;
+    for (uint32_t sh = 0; sh < kCounterShards; sh++) m = std::max(m, h.v[sh][C_STACK_MAX]);
+    *out_max_stack = (uint32_t)m;
   }
   return BDPT_OK;
 }

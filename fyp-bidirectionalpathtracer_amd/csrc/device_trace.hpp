@@ -55,14 +55,28 @@ BD void travInit(TravState& T, f3 o, f3 d, float tmin, float tmax) {
   T.cur = (finite && (tmax > tmin)) ? 0 : kDone;
 }
 
-BD int travPop(TravState& T, const int* stk) {
+// Stack entry e of this lane: LDS row e below KL, the context's overflow area from KL on (KL = kStackEntries: all in LDS).
+template <int KL>
+BD int* ovfSlot(const SceneDev& S, int e) {
+  return S.stackOvf + (size_t)(e - KL) * S.stackOvfStride + (size_t)blockIdx.x * kWave + (threadIdx.x & 63u);
+}
+template <int KL>
+BD void stackStore(const SceneDev& S, int* stk, int e, int ref) {
+  if (KL < kStackEntries && e >= KL)
+    *ovfSlot<KL>(S, e) = ref;
+  else
+    stk[e * kWave] = ref;
+}
+template <int KL>
+BD int travPop(const SceneDev& S, TravState& T, const int* stk) {
   if (T.sp == 0) return kDone;
   T.sp--;
+  if (KL < kStackEntries && T.sp >= KL) return *ovfSlot<KL>(S, T.sp);
   return stk[T.sp * kWave];
 }
-
-BD void travPush(TravState& T, int* stk, int ref) {
-  stk[T.sp * kWave] = ref;
+template <int KL>
+BD void travPush(const SceneDev& S, TravState& T, int* stk, int ref) {
+  stackStore<KL>(S, stk, T.sp, ref);
   T.sp++;
 }
 
@@ -73,7 +87,7 @@ BD float ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  /
 // bytes are picked per axis by the ray's direction sign (one select per axis for all four children).
 // ORDER 1 (closest hit): children are entered nearest first, the rest stacked far to near; ORDER 2: the nearest is
 // entered, the rest stacked in slot order; ORDER 0 (any hit): slot order.
-template <int ORDER>
+template <int ORDER, int KL = kStackEntries>
 BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
   const uint4* np = S.recs + (size_t)T.cur * 3;
   // origin.xyz, exponents + leaf bits | lo.x lo.y lo.z hi.x | hi.y hi.z childBase childOffsets   (bvh.h BvhRec)
@@ -115,15 +129,23 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
     const int near = sab ? ib : ia;
     const bool any = (sab ? tb : ta) < 3.0e38f;
     int sp = T.sp;
+    if (KL >= kStackEntries || sp <= KL - 4) {
 #pragma unroll
-    for (int c = 3; c >= 0; c--) {
-      const int rc = (c == 3) ? r3 : ((c == 2) ? r2 : ((c == 1) ? r1 : r0));
-      stk[sp * kWave] = rc;
-      sp += (hit[c] && c != near) ? 1 : 0;
+      for (int c = 3; c >= 0; c--) {
+        const int rc = (c == 3) ? r3 : ((c == 2) ? r2 : ((c == 1) ? r1 : r0));
+        stk[sp * kWave] = rc;
+        sp += (hit[c] && c != near) ? 1 : 0;
+      }
+    } else {  // near the end of the LDS rows: every store picks its place
+#pragma unroll
+      for (int c = 3; c >= 0; c--) {
+        const int rc = (c == 3) ? r3 : ((c == 2) ? r2 : ((c == 1) ? r1 : r0));
+        if (hit[c] && c != near) stackStore<KL>(S, stk, sp++, rc);
+      }
     }
     T.sp = sp;
     const int rn = (near == 3) ? r3 : ((near == 2) ? r2 : ((near == 1) ? r1 : r0));
-    T.cur = any ? rn : travPop(T, stk);
+    T.cur = any ? rn : travPop<KL>(S, T, stk);
   } else if (ORDER == 1) {
     float t0 = hit[0] ? tn[0] : 3.0e38f, t1 = hit[1] ? tn[1] : 3.0e38f, t2 = hit[2] ? tn[2] : 3.0e38f, t3 = hit[3] ? tn[3] : 3.0e38f;
     r0 = hit[0] ? r0 : kDone;
@@ -147,25 +169,40 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
     BDPT_CSWAP(t1, r1, t2, r2)
 #undef BDPT_CSWAP
     // misses sorted to the back (t = 3e38, ref = kDone): push far to near, enter the nearest
-    if (r3 != kDone) travPush(T, stk, r3);
-    if (r2 != kDone) travPush(T, stk, r2);
-    if (r1 != kDone) travPush(T, stk, r1);
-    T.cur = (r0 != kDone) ? r0 : travPop(T, stk);
+    if (KL >= kStackEntries || T.sp <= KL - 3) {
+      if (r3 != kDone) travPush<kStackEntries>(S, T, stk, r3);
+      if (r2 != kDone) travPush<kStackEntries>(S, T, stk, r2);
+      if (r1 != kDone) travPush<kStackEntries>(S, T, stk, r1);
+    } else {  // near the end of the LDS rows
+      if (r3 != kDone) travPush<KL>(S, T, stk, r3);
+      if (r2 != kDone) travPush<KL>(S, T, stk, r2);
+      if (r1 != kDone) travPush<KL>(S, T, stk, r1);
+    }
+    T.cur = (r0 != kDone) ? r0 : travPop<KL>(S, T, stk);
   } else {
     // Branch-free: walk the slots from 3 down to 0 keeping the last hit in `next`; a newly found hit
     // pushes the previous one.  The LDS store is unconditional (a slot above sp is scratch), only the
     // stack pointer moves conditionally, so the wave never splits here.
     int next = hit[3] ? r3 : kDone;
     int sp = T.sp;
+    if (KL >= kStackEntries || sp <= KL - 3) {
 #pragma unroll
-    for (int c = 2; c >= 0; c--) {
-      const int rc = (c == 2) ? r2 : ((c == 1) ? r1 : r0);
-      stk[sp * kWave] = next;
-      sp += (hit[c] && next != kDone) ? 1 : 0;
-      next = hit[c] ? rc : next;
+      for (int c = 2; c >= 0; c--) {
+        const int rc = (c == 2) ? r2 : ((c == 1) ? r1 : r0);
+        stk[sp * kWave] = next;
+        sp += (hit[c] && next != kDone) ? 1 : 0;
+        next = hit[c] ? rc : next;
+      }
+    } else {  // near the end of the LDS rows: every store picks its place
+#pragma unroll
+      for (int c = 2; c >= 0; c--) {
+        const int rc = (c == 2) ? r2 : ((c == 1) ? r1 : r0);
+        if (hit[c] && next != kDone) stackStore<KL>(S, stk, sp++, next);
+        next = hit[c] ? rc : next;
+      }
     }
     T.sp = sp;
-    if (next == kDone) next = travPop(T, stk);
+    if (next == kDone) next = travPop<KL>(S, T, stk);
     T.cur = next;
   }
 }
@@ -244,7 +281,7 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
     }
     if (T.cur == kDone) break;
     if (leafStep<MODE, COUNT>(S, T, nTris)) break;
-    T.cur = travPop(T, stk);
+    T.cur = travPop<kStackEntries>(S, T, stk);
   }
   return T.best;
 }
@@ -297,7 +334,7 @@ struct RayQueue {         // SoA planes, stride = cap: ox oy oz dx dy dz tmax
 template <bool COUNT>
 __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
                                                              float shadowTmin) {
-  __shared__ int s_stack[kStackEntries * kWave];
+  __shared__ int s_stack[kStackLds * kWave];
   int* stk = s_stack + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63u);
   bool has = false, exhausted = false;
@@ -305,6 +342,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
   TravState T;
   T.cur = kDone;
   uint32_t nNodes = 0, nTris = 0;
+  int maxSp = 0;
   // wave-uniform fetch state: current sub-queue and the chunk [chunkPos, chunkEnd) taken from it
   uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
   const uint32_t wavesPerList = (gridDim.x + Q.numSub - 1) / Q.numSub;
@@ -364,7 +402,8 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
 #pragma unroll 1
       for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0>(S, T, stk);
+        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0, kStackLds>(S, T, stk);
+        if (COUNT) maxSp = T.sp > maxSp ? T.sp : maxSp;
       }
     }
     const unsigned long long waitMask = __ballot(has && T.cur < 0), nodeMask = __ballot(has && T.cur >= 0);
@@ -375,7 +414,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
         if (!finished) {
           finished = leafStep<2, COUNT>(S, T, nTris);
           if (!finished) {
-            T.cur = travPop(T, stk);
+            T.cur = travPop<kStackLds>(S, T, stk);
             finished = (T.cur == kDone);
           }
         }
@@ -391,13 +430,13 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0>(S, T, stk);
+        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0, kStackLds>(S, T, stk);
       }
       bool finished = (T.cur == kDone);
       if (!finished) {
         finished = leafStep<2, COUNT>(S, T, nTris);
         if (!finished) {
-          T.cur = travPop(T, stk);
+          T.cur = travPop<kStackLds>(S, T, stk);
           finished = (T.cur == kDone);
         }
       }
@@ -412,6 +451,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
   if (COUNT) {
     waveAddCount(counters, C_NODE_SHADOW, nNodes);
     waveAddCount(counters, C_TRI_SHADOW, nTris);
+    if (maxSp > 0) atomicMax(&counters->v[blockIdx.x % kCounterShards][C_STACK_MAX], (unsigned long long)maxSp);
   }
 }
 

@@ -11,7 +11,16 @@ constexpr int kWave = 64;          // gfx950 wavefront
 #ifndef KSTACK
 #define KSTACK 32
 #endif
-constexpr int kStackEntries = KSTACK;  // per-lane traversal stack in LDS, 8 KiB per wave (kBvhMaxDepth = 30)
+constexpr int kStackEntries = KSTACK;  // per-lane traversal stack capacity (the builder's bound is kBvhMaxStack = KSTACK - 1)
+// The any-hit kernel keeps only the first BDPT_STACK_LDS entries of a lane's stack in LDS (6 KiB per wave); the few
+// deeper entries of very deep descents go to a per-context overflow area in device memory (SceneDev::stackOvf).
+// Measured on the bench frame: rays never go beyond 12 entries there, and the smaller LDS footprint (more resident
+// any-hit waves, room for the connection generator beside them) is worth 3 % of the frame (profiles/README.md).
+#ifndef BDPT_STACK_LDS
+#define BDPT_STACK_LDS 24
+#endif
+constexpr int kStackLds = BDPT_STACK_LDS < KSTACK ? BDPT_STACK_LDS : KSTACK;
+constexpr int kMaxPersistentPerCU = 32;  // resident one-wave workgroups per CU a persistent grid may use (8 per SIMD)
 #ifndef BDPT_SHADE_REC_F4
 #define BDPT_SHADE_REC_F4 7
 #endif
@@ -64,6 +73,8 @@ struct SceneDev {
   uint32_t numLights;
   uint32_t hasBitangents;
   uint32_t numRecs;
+  int* stackOvf;            // overflow rows of the persistent kernels' stacks: [entry - kStackLds][workgroup * 64 + lane]
+  uint32_t stackOvfStride;  // lanes per row
 };
 
 struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; one 128-byte line per shard
@@ -71,7 +82,8 @@ struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; one 128-by
 };
 enum : int {
   C_RAYS_PRIMARY = 0, C_RAYS_EYE, C_RAYS_LIGHT, C_RAYS_NEE, C_RAYS_SPLAT, C_RAYS_CONNECT,
-  C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS, C_RAYS_LAZY
+  C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS, C_RAYS_LAZY,
+  C_STACK_MAX  // deepest any-hit traversal stack seen (a maximum, not a sum; with BDPT_PARAM_COUNTERS)
 };
 
 // Number of connection pairs the reference defines for depth D (cameraLength <= totalLength,
@@ -198,6 +210,8 @@ void launchAccumulateTile(float* last, float* cur, uint32_t accumCount, uint32_t
 void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t draws, uint32_t* states, float* floats,
                    hipStream_t st);
 void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode, int32_t* prim, float* tuv, hipStream_t st);
+void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap, const uint32_t* count, uint32_t* head, uint8_t* vis,
+                           DevCounters* counters, float tmin, int numCUs, hipStream_t st);
 void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st);
 
 }  // namespace bdpt

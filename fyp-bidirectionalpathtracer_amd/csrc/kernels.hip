@@ -354,7 +354,7 @@ BD uint32_t packPath(uint32_t p, int path, int k) { return p | ((uint32_t)path <
 
 template <bool GGX, bool COUNT>
 __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, PathBuf P, uint32_t* __restrict__ head) {
-  __shared__ int s_stack[kStackEntries * kWave];
+  __shared__ int s_stack[kStackEntries * kWave];  // all in LDS: registers, not LDS, bound this kernel's residency
   __shared__ uint4 s_pool[kPoolEntries];
   int* stk = s_stack + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63u);
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
           if (!finished) {
             finished = leafStep<0, COUNT>(S, T, nTris);
             if (!finished) {
-              T.cur = travPop(T, stk);
+              T.cur = travPop<kStackEntries>(S, T, stk);
               finished = (T.cur == kDone);
             }
           }
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
       if (!finished) {
         finished = leafStep<0, COUNT>(S, T, nTris);
         if (!finished) {
-          T.cur = travPop(T, stk);
+          T.cur = travPop<kStackEntries>(S, T, stk);
           finished = (T.cur == kDone);
         }
       }
@@ -1268,7 +1268,7 @@ __global__ void test_bsdf_kernel(const float* in, uint32_t n, bool fromLobe, flo
 // launchers
 // ------------------------------------------------------------------------------------------------
 #ifndef PERCU
-#define PERCU 20
+#define PERCU 24
 #endif
 static inline uint32_t blocksFor(uint64_t n) { return (uint32_t)((n + kWave - 1) / kWave); }
 // grid of a dense kernel over a sharded path queue: every (list, chunk) pair gets a workgroup
@@ -1280,6 +1280,7 @@ static uint32_t persistentGrid(K kernel, int numCUs) {
   int perCU = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kWave, 0) != hipSuccess || perCU <= 0) perCU = 8;
   if (perCU > PERCU) perCU = PERCU;
+  if (perCU > kMaxPersistentPerCU) perCU = kMaxPersistentPerCU;  // the stack overflow area is sized for that many
   return (uint32_t)(perCU * numCUs);
 }
 
@@ -1411,6 +1412,14 @@ void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode,
     hipLaunchKernelGGL(test_trace_kernel<1>, dim3(blocksFor(n)), dim3(kWave), 0, st, S, rays, n, prim, tuv);
   else
     hipLaunchKernelGGL(test_trace_kernel<2>, dim3(blocksFor(n)), dim3(kWave), 0, st, S, rays, n, prim, tuv);
+}
+// The persistent any-hit kernel over a caller's ray list (planes ox oy oz dx dy dz tmax of stride `cap`, one sub-queue):
+// visibility bytes and, through `counters`, the visit tallies and the deepest stack.
+void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap, const uint32_t* count, uint32_t* head, uint8_t* vis,
+                           DevCounters* counters, float tmin, int numCUs, hipStream_t st) {
+  RayQueue Q{planes, cap, cap, 1u, count, head};
+  const uint32_t g = persistentGrid(trace_shadow_kernel<true>, numCUs);
+  hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
 }
 void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st) {
   if (!n) return;

@@ -426,6 +426,10 @@ int bdpt_test_rng(bdpt_ctx* ctx, const uint32_t* val0, const uint32_t* val1, uin
 /* Closest-hit / any-hit queries on host ray arrays (origin xyz, dir xyz, tmin, tmax per ray).
  * hit: prim (int32, -1 miss), t, u, v per ray.  mode 0 closest, 1 closest+cull-back, 2 any-hit (prim = 0/-1). */
 int bdpt_test_trace(bdpt_ctx* ctx, const float* rays, uint32_t n, int mode, int32_t* out_prim, float* out_tuv);
+/* The persistent any-hit kernel (the one the pass uses for NEE, splat and connection rays) over host rays of the same
+ * layout; tmin is taken from ray 0.  out_vis: 1 = unoccluded.  out_max_stack (may be NULL): deepest traversal stack any
+ * ray reached — entries beyond the LDS rows live in the context's overflow area (kernels.h kStackLds). */
+int bdpt_test_trace_shadow(bdpt_ctx* ctx, const float* rays, uint32_t n, uint8_t* out_vis, uint32_t* out_max_stack);
 /* BSDF known-answer hook: inputs are n records of 20 floats
  * (N3 V3 L3 dif3 spec3 rough isSpecular seed(bits) pad2); outputs n records of 16 floats
  * (sampleBRDF: weight3 L3 pdf isSpec | evalBRDF: f3 | pad).  matIndex bit 1 = BDPT_PARAM_SPECULAR_FROM_LOBE. */

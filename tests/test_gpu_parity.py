@@ -73,6 +73,36 @@ def test_trace_matches_oracle_bvh_and_brute_force(pkg, ob, gpu_ctx, ntri, edge):
     scene.close()
 
 
+@pytest.mark.gpu
+def test_persistent_anyhit_kernel_with_stacks_beyond_the_lds_rows(pkg, ob, gpu_ctx):
+    """The any-hit kernel keeps 24 stack entries per lane in LDS and the rest in the context's overflow area
+    (kernels.h kStackLds).  A soup of large overlapping triangles makes descents that stack more than that: the
+    kernel's visibility must still equal the oracle's any-hit answer (and the brute-force scan's) for every ray."""
+    scene = pkg.Scene.soup(99, 300000, 0.9)
+    gpu_ctx.set_scene(scene.desc)
+    lib = ob.load_oracle(pkg.abi)
+    osc = lib.oracle_scene_create(C.byref(scene.desc))
+    rng = np.random.default_rng(5)
+    n = 20000
+    rays = _random_rays(rng, n, -0.5, 1.5)
+    rays[:, 6] = 0.0  # one tmin per launch
+    rays[:, 7] = rng.uniform(1e-6, 3e-5, n).astype(np.float32)  # very short segments: about half miss every triangle, all descend deep
+    rays[0, 3:6] = np.nan
+    rays[1, 7] = 0.0
+    vis, deepest = gpu_ctx.test_trace_shadow(rays)
+    po = np.zeros(n, np.int32)
+    to = np.zeros((n, 3), np.float32)
+    lib.oracle_trace(osc, rays.ctypes.data, n, 2, 0, po.ctypes.data, to.ctypes.data)
+    assert np.array_equal(vis == 1, po < 0), int(((vis == 1) != (po < 0)).sum())
+    nb = 256
+    lib.oracle_trace(osc, rays.ctypes.data, nb, 2, ob.ORACLE_BRUTE_FORCE, po.ctypes.data, to.ctypes.data)
+    assert np.array_equal(vis[:nb] == 1, po[:nb] < 0)
+    assert 0 < (vis == 1).sum() < n
+    assert deepest > 24, deepest  # the overflow rows were used
+    lib.oracle_scene_destroy(osc)
+    scene.close()
+
+
 @pytest.mark.parametrize("mat", [0, 1, 2])
 def test_bsdf_kat(pkg, ob, gpu_ctx, mat):
     rng = np.random.default_rng(20260104 + mat)

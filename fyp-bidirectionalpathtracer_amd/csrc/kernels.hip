@@ -352,9 +352,16 @@ constexpr uint32_t kPoolEntries = 128;
 #endif
 BD uint32_t packPath(uint32_t p, int path, int k) { return p | ((uint32_t)path << 24) | ((uint32_t)k << 25); }
 
+#ifndef BDPT_WALK_WAVES_PER_EU
+#define BDPT_WALK_WAVES_PER_EU 4
+#endif
+#ifndef BDPT_WALK_STACK_LDS
+#define BDPT_WALK_STACK_LDS kStackEntries
+#endif
+constexpr int kWalkStackLds = BDPT_WALK_STACK_LDS;
 template <bool GGX, bool COUNT>
-__global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, PathBuf P, uint32_t* __restrict__ head) {
-  __shared__ int s_stack[kStackEntries * kWave];  // all in LDS: registers, not LDS, bound this kernel's residency
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK_WAVES_PER_EU, 8))) void walk_kernel(SceneDev S, FrameDev F, PathBuf P, uint32_t* __restrict__ head) {
+  __shared__ int s_stack[kWalkStackLds * kWave];
   __shared__ uint4 s_pool[kPoolEntries];
   int* stk = s_stack + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63u);
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
 #pragma unroll 1
       for (int kk = 0; kk < BDPT_WALK_NODE_BURST && T.cur >= 0; kk++) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_WALK_ORDER>(S, T, stk);
+        nodeStep<BDPT_WALK_ORDER, kWalkStackLds>(S, T, stk);
       }
     }
     {
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
           if (!finished) {
             finished = leafStep<0, COUNT>(S, T, nTris);
             if (!finished) {
-              T.cur = travPop<kStackEntries>(S, T, stk);
+              T.cur = travPop<kWalkStackLds>(S, T, stk);
               finished = (T.cur == kDone);
             }
           }
@@ -541,13 +548,13 @@ __global__ __launch_bounds__(kWave) void walk_kernel(SceneDev S, FrameDev F, Pat
     if (trav) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_WALK_ORDER>(S, T, stk);
+        nodeStep<BDPT_WALK_ORDER, kWalkStackLds>(S, T, stk);
       }
       finished = (T.cur == kDone);
       if (!finished) {
         finished = leafStep<0, COUNT>(S, T, nTris);
         if (!finished) {
-          T.cur = travPop<kStackEntries>(S, T, stk);
+          T.cur = travPop<kWalkStackLds>(S, T, stk);
           finished = (T.cur == kDone);
         }
       }

@@ -67,7 +67,7 @@ constexpr int kBins = BDPT_SAH_BINS;
 // different lengths idle lanes, while one-triangle leaves double the node array past the 4 MiB L2 of an XCD.
 constexpr uint32_t kLeafMax = BDPT_LEAF_MAX;  // at most 8 (three count bits in a leaf reference)
 constexpr float kCostTraverse = 1.0f, kCostTri = 1.0f;
-constexpr int kBinaryMaxDepth = 48;  // depth budget of the intermediate binary tree
+constexpr int kBinaryMaxDepth = kBvhMaxStack;  // depth budget of the intermediate binary tree: a two-wide path stacks one reference per level, so the device stack bounds it (a budget of 48 let a 10 M-triangle scene of overlapping cards through that bdpt_set_scene then had to refuse)
 
 inline uint32_t ceilLog2(uint32_t x) {
   uint32_t l = 0;

@@ -308,6 +308,34 @@ def test_bvh_builder_invariants(pkg, make):
     assert info.nodeBytes == 48 and info.triBytes == 48 and info.numNodes >= 1
 
 
+def test_bvh_builder_keeps_skewed_scenes_within_the_device_stack(pkg):
+    """Triangles whose size and position fall off geometrically in x and in y make binned SAH peel a few columns or rows per
+    level: a binary tree far deeper than the 31 references the device stack holds (with a depth budget of 48 this scene gave
+    a worst-case stack of 35, a 10 M-triangle scene of overlapping cards gave the same kind of tree, and bdpt_set_scene had
+    to refuse both).  The builder falls back to median splits early enough for the four-wide tree's worst case to stay
+    within the stack, and the checker agrees."""
+    lib = pkg.load_library()
+    n = 60
+    e = np.float32(2.0) ** (30 - np.arange(n, dtype=np.float32))
+    cx, cy = (a.reshape(-1) for a in np.meshgrid(e, e))
+    m = cx.size
+    pos = np.zeros((m, 3, 3), np.float32)
+    pos[:, 0, 0], pos[:, 0, 1] = cx, cy
+    pos[:, 1, 0], pos[:, 1, 1] = cx * np.float32(1.1), cy
+    pos[:, 2, 0], pos[:, 2, 1] = cx, cy * np.float32(1.1)
+    idx = np.arange(3 * m, dtype=np.uint32)
+    desc = pkg.abi.SceneDesc()
+    desc.numVertices, desc.numTriangles = 3 * m, m
+    flat = np.ascontiguousarray(pos.reshape(-1))
+    desc.positions = flat.ctypes.data_as(C.POINTER(C.c_float))
+    desc.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    info = pkg.abi.BvhInfo()
+    msg = C.create_string_buffer(256)
+    rc = lib.bdpt_bvh_build_check(C.byref(desc), C.byref(info), msg, 256)
+    assert rc == 0, msg.value
+    assert info.numTriangles == m and info.maxStack <= 31 and info.maxDepth >= 20
+
+
 def test_tiling_bands(pkg):
     t = pkg.tiling
     for H, world in ((1080, 1), (1080, 2), (1080, 4), (1080, 8), (2160, 8), (7, 4), (64, 3)):

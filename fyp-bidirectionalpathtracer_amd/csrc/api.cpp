@@ -328,8 +328,15 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
                     (BDPT_FLAG_DOUBLE_SIDED(f) ? kTriDoubleSided : 0u);
     }
   });
+  // non-opaque triangles get an alpha-test record (device_scene.hpp alphaTestFails); its index travels in BvhTri::aux
+  std::vector<uint32_t> triAux(d->numTriangles, 0u), alphaTris;
+  for (uint32_t t = 0; t < d->numTriangles; t++)
+    if (triFlags[t] & kTriNonOpaque) {
+      triAux[t] = (uint32_t)alphaTris.size();
+      alphaTris.push_back(t);
+    }
   Bvh bvh;
-  buildBvh(d->positions, d->indices, d->numTriangles, triFlags.data(), bvh);
+  buildBvh(d->positions, d->indices, d->numTriangles, triFlags.data(), bvh, 0, triAux.data());
   if (bvh.maxStack > (uint32_t)kBvhMaxStack) {
     fail(c, "bvh needs a deeper traversal stack than the device provides");
     return BDPT_E_LIMIT;
@@ -396,6 +403,46 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
     texs[i] = TexDev{px, t.width, t.height, t.srgb, 0};
   }
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.textures, texs.data(), texs.size()))) return rc;
+  {
+    std::vector<float> alphaRecs(std::max<size_t>(alphaTris.size(), 1) * 16, 0.0f);
+    hostParallelFor(alphaTris.size(), [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; i++) {
+        const uint32_t t = alphaTris[i];
+        const bdpt_material& m = d->materials[d->triMaterial[t]];
+        float* r = alphaRecs.data() + i * 16;
+        for (int k = 0; k < 3; k++) {
+          const uint32_t vi = d->indices[(size_t)t * 3 + k];
+          r[k * 2] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
+          r[k * 2 + 1] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
+        }
+        r[6] = m.alphaThreshold;
+        r[7] = m.baseColor[3];
+        const uint32_t type = BDPT_FLAG_DIFFUSE_TYPE(m.flags);
+        uint32_t mode = 0, tw = 0, th = 0;
+        unsigned long long px = 0;
+        if (type == BDPT_CHANNEL_UNUSED) {
+          mode = 0;
+        } else if (type == BDPT_CHANNEL_CONST || m.texBaseColor < 0) {
+          mode = 1;
+        } else {
+          mode = 2;
+          const TexDev& td = texs[(size_t)m.texBaseColor];
+          tw = td.w;
+          th = td.h;
+          px = (unsigned long long)reinterpret_cast<uintptr_t>(td.px);
+        }
+        const uint32_t lo = (uint32_t)(px & 0xffffffffull), hi = (uint32_t)(px >> 32);
+        std::memcpy(&r[8], &mode, 4);
+        std::memcpy(&r[9], &tw, 4);
+        std::memcpy(&r[10], &th, 4);
+        std::memcpy(&r[12], &lo, 4);
+        std::memcpy(&r[13], &hi, 4);
+      }
+    });
+    const float* dAlpha;
+    if ((rc = devUpload(c, c->sceneAllocs, &dAlpha, alphaRecs.data(), alphaRecs.size()))) return rc;
+    c->S.alphaRecs = reinterpret_cast<const float4*>(dAlpha);
+  }
   SceneConst sc;
   std::memset(&sc, 0, sizeof(sc));
   std::memcpy(sc.lights, d->lights, sizeof(bdpt_light) * d->numLights);

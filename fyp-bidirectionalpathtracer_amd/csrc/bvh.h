@@ -40,7 +40,7 @@ struct alignas(16) BvhTri {
   float e1[3];
   uint32_t flags;  // bit0 non-opaque (any-hit alpha test), bit1 double-sided (no back-face cull)
   float e2[3];
-  uint32_t pad;
+  uint32_t aux;  // caller's word per triangle (bdpt_set_scene: index of the alpha-test record of a non-opaque triangle)
 };
 static_assert(sizeof(BvhTri) == 48, "triangle must be 48 bytes");
 
@@ -82,7 +82,7 @@ struct Bvh {
 // positions: 3 floats per vertex; indices: 3 per triangle; triFlags: per triangle (may be null).
 // threads <= 0: bvhBuildThreads().  The tree does not depend on the thread count, bit for bit.
 void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTriangles, const uint32_t* triFlags, Bvh& out,
-              int threads = 0);
+              int threads = 0, const uint32_t* triAux = nullptr);
 // host threads the builder uses by default: BDPT_BUILD_THREADS, else the affinity mask capped by the cgroup CPU quota
 int bvhBuildThreads();
 

@@ -328,7 +328,8 @@ int bvhBuildThreads() {
   return std::max(1, std::min(n, 64));
 }
 
-void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const uint32_t* triFlags, Bvh& out, int threads) {
+void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const uint32_t* triFlags, Bvh& out, int threads,
+              const uint32_t* triAux) {
   if (threads <= 0) threads = bvhBuildThreads();
   const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -372,7 +373,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
         }
         r.prim = (uint32_t)t;
         r.flags = triFlags ? triFlags[t] : 0u;
-        r.pad = 0;
+        r.aux = triAux ? triAux[t] : 0u;
         Box bx;
         bx.reset();
         bx.grow(r.v0);

@@ -76,24 +76,42 @@ BD MatDev loadMaterial(const SceneDev& S, uint32_t id) {
   return r;
 }
 
-// BDPT/BDPTUtils.hlsli:115-127
-BD bool alphaTestFails(const SceneDev& S, uint32_t prim, float bu, float bv) {
-  const float4* r = S.shade + (size_t)prim * kShadeRecF4;
-  const MatDev m = loadMaterial(S, __float_as_uint(r[6].x));
-  float u = 0, v = 0;
-  const uint32_t mode = BDPT_FLAG_DIFFUSE_TYPE(m.flags);
-  if (mode == BDPT_CHANNEL_TEXTURE && m.texBase >= 0) {
-    float b0 = 1.0f - bu - bv;
-    float4 r1 = r[1], r3 = r[3], r5 = r[5];
-    u += r1.z * b0;
-    v += r1.w * b0;
-    u += r3.z * bu;
-    v += r3.w * bu;
-    u += r5.z * bv;
-    v += r5.w * bv;
+// BDPT/BDPTUtils.hlsli:115-127.  Everything the any-hit alpha test of a non-opaque triangle reads sits in ONE 64-byte
+// record (built by bdpt_set_scene: the three texture coordinates, the material's threshold and constant alpha, how the base
+// colour is sampled, and the base-colour texture's address and size), so a candidate hit costs one record fetch and four
+// texel fetches instead of the chain shading record -> material -> texture descriptor -> texels.  Same arithmetic as
+// shadeHit + sampleTexture on the alpha channel (texel alpha = byte / 255, bilinear, wrap).
+//   f4[0] = uv0, uv1   f4[1] = uv2, alphaThreshold, baseColor.a   f4[2] = mode (0 unused, 1 constant, 2 texture), width, height
+//   f4[3] = texel address (two words)
+BD bool alphaTestFails(const SceneDev& S, uint32_t rec, float bu, float bv) {
+  const float4* r = S.alphaRecs + (size_t)rec * 4;
+  const float4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3];
+  const uint32_t mode = __float_as_uint(a2.x);
+  float alpha = 0.0f;  // BDPT_CHANNEL_UNUSED: sampleTexture returns 0
+  if (mode == 1u) {
+    alpha = a1.w;
+  } else if (mode == 2u) {
+    float u = 0, v = 0;
+    const float b0 = 1.0f - bu - bv;
+    u += a0.x * b0;
+    v += a0.y * b0;
+    u += a0.z * bu;
+    v += a0.w * bu;
+    u += a1.x * bv;
+    v += a1.y * bv;
+    const int tw = (int)__float_as_uint(a2.y), th = (int)__float_as_uint(a2.z);
+    const uint8_t* px = reinterpret_cast<const uint8_t*>(((unsigned long long)__float_as_uint(a3.y) << 32) | (unsigned long long)__float_as_uint(a3.x));
+    const float x = u * (float)tw - 0.5f, y = v * (float)th - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const int ix0 = wrapi((int)x0, tw), iy0 = wrapi((int)y0, th);
+    const int ix1 = wrapi(ix0 + 1, tw), iy1 = wrapi(iy0 + 1, th);
+    const float t00 = (float)px[((size_t)iy0 * tw + (size_t)ix0) * 4 + 3] / 255.0f, t10 = (float)px[((size_t)iy0 * tw + (size_t)ix1) * 4 + 3] / 255.0f;
+    const float t01 = (float)px[((size_t)iy1 * tw + (size_t)ix0) * 4 + 3] / 255.0f, t11 = (float)px[((size_t)iy1 * tw + (size_t)ix1) * 4 + 3] / 255.0f;
+    const float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
+    alpha = top + (bot - top) * fy;
   }
-  f4 base = sampleTexture(S, m.texBase, u, v, m.baseColor, mode);
-  return base.w < m.alphaThreshold;
+  return alpha < a1.z;
 }
 
 struct Shading {

@@ -230,7 +230,7 @@ BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b,
   if (v < 0.0f || u + v > 1.0f) return false;
   const float t = dot(e2, qvec) * inv;
   if (!((t > T.tmin) && (t < T.tmax))) return false;
-  if ((flags & 1u) && alphaTestFails(S, prim, u, v)) return false;  // any-hit shader: IgnoreHit()
+  if ((flags & 1u) && alphaTestFails(S, __float_as_uint(c.w), u, v)) return false;  // any-hit shader: IgnoreHit()
   if (MODE == 2) {
     T.best.prim = 0;
     T.best.t = t;

@@ -73,6 +73,7 @@ struct SceneDev {
   uint32_t numLights;
   uint32_t hasBitangents;
   uint32_t numRecs;
+  const float4* alphaRecs;  // 4 per non-opaque triangle (device_scene.hpp alphaTestFails), indexed by BvhTri::aux
   int* stackOvf;            // overflow rows of the persistent kernels' stacks: [entry - kStackLds][workgroup * 64 + lane]
   uint32_t stackOvfStride;  // lanes per row
 };

@@ -114,6 +114,72 @@ BD bool alphaTestFails(const SceneDev& S, uint32_t rec, float bu, float bv) {
   return alpha < a1.z;
 }
 
+// Two alpha tests side by side (a leaf's two triangles): both records are fetched before either texel quad, both quads
+// before either result is used.  need0 / need1 say which to run; same arithmetic as alphaTestFails.
+struct AlphaIn {
+  float4 a0, a1, a2, a3;
+};
+BD void alphaTexels(const AlphaIn& r, float bu, float bv, bool run, float& fx, float& fy, float& t00, float& t10, float& t01, float& t11) {
+  fx = fy = t00 = t10 = t01 = t11 = 0.0f;
+  if (!run || __float_as_uint(r.a2.x) != 2u) return;
+  float u = 0, v = 0;
+  const float b0 = 1.0f - bu - bv;
+  u += r.a0.x * b0;
+  v += r.a0.y * b0;
+  u += r.a0.z * bu;
+  v += r.a0.w * bu;
+  u += r.a1.x * bv;
+  v += r.a1.y * bv;
+  const int tw = (int)__float_as_uint(r.a2.y), th = (int)__float_as_uint(r.a2.z);
+  const uint8_t* px = reinterpret_cast<const uint8_t*>(((unsigned long long)__float_as_uint(r.a3.y) << 32) | (unsigned long long)__float_as_uint(r.a3.x));
+  const float x = u * (float)tw - 0.5f, y = v * (float)th - 0.5f;
+  const float x0 = floorf(x), y0 = floorf(y);
+  fx = x - x0;
+  fy = y - y0;
+  const int ix0 = wrapi((int)x0, tw), iy0 = wrapi((int)y0, th);
+  const int ix1 = wrapi(ix0 + 1, tw), iy1 = wrapi(iy0 + 1, th);
+  t00 = (float)px[((size_t)iy0 * tw + (size_t)ix0) * 4 + 3];
+  t10 = (float)px[((size_t)iy0 * tw + (size_t)ix1) * 4 + 3];
+  t01 = (float)px[((size_t)iy1 * tw + (size_t)ix0) * 4 + 3];
+  t11 = (float)px[((size_t)iy1 * tw + (size_t)ix1) * 4 + 3];
+}
+BD bool alphaVerdict(const AlphaIn& r, float fx, float fy, float t00, float t10, float t01, float t11) {
+  const uint32_t mode = __float_as_uint(r.a2.x);
+  float alpha = 0.0f;
+  if (mode == 1u) {
+    alpha = r.a1.w;
+  } else if (mode == 2u) {
+    const float w00 = t00 / 255.0f, w10 = t10 / 255.0f, w01 = t01 / 255.0f, w11 = t11 / 255.0f;
+    const float top = w00 + (w10 - w00) * fx, bot = w01 + (w11 - w01) * fx;
+    alpha = top + (bot - top) * fy;
+  }
+  return alpha < r.a1.z;
+}
+BD void alphaTestFails2(const SceneDev& S, bool need0, uint32_t rec0, float u0, float v0, bool need1, uint32_t rec1, float u1, float v1,
+                        bool& fail0, bool& fail1) {
+  AlphaIn r0, r1;
+  r0.a0 = r0.a1 = r0.a2 = r0.a3 = r1.a0 = r1.a1 = r1.a2 = r1.a3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (need0) {
+    const float4* p = S.alphaRecs + (size_t)rec0 * 4;
+    r0.a0 = p[0];
+    r0.a1 = p[1];
+    r0.a2 = p[2];
+    r0.a3 = p[3];
+  }
+  if (need1) {
+    const float4* p = S.alphaRecs + (size_t)rec1 * 4;
+    r1.a0 = p[0];
+    r1.a1 = p[1];
+    r1.a2 = p[2];
+    r1.a3 = p[3];
+  }
+  float fx0, fy0, a00, a10, a01, a11, fx1, fy1, b00, b10, b01, b11;
+  alphaTexels(r0, u0, v0, need0, fx0, fy0, a00, a10, a01, a11);
+  alphaTexels(r1, u1, v1, need1, fx1, fy1, b00, b10, b01, b11);
+  fail0 = need0 && alphaVerdict(r0, fx0, fy0, a00, a10, a01, a11);
+  fail1 = need1 && alphaVerdict(r1, fx1, fy1, b00, b10, b01, b11);
+}
+
 struct Shading {
   f3 posW, V, N, diffuse, specular, emissive;
   float opacity, linearRoughness, roughness, IoR;

@@ -207,42 +207,69 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
   }
 }
 
-// One triangle of a leaf (record index); returns true when an any-hit query is finished; `last`: the leaf ends here.
-// Moeller-Trumbore exactly as the oracle evaluates it (this is the part that must match bit for bit).
+// One triangle of a leaf in three parts, so that a leaf's two triangles can share the fetch rounds of their alpha tests:
+// triGeom — Moeller-Trumbore exactly as the oracle evaluates it (this is the part that must match bit for bit) — says
+// whether the triangle is a candidate hit; the any-hit alpha test (IgnoreHit) may still reject it; triCommit records it.
+struct TriCand {
+  float t, u, v;
+  uint32_t prim, flags, aux;
+  bool ok, last;
+};
 template <int MODE>
-BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, bool& last) {
+BD TriCand triGeom(const TravState& T, const float4 a, const float4 b, const float4 c) {
+  TriCand k;
   const f3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
-  const uint32_t prim = __float_as_uint(a.w), flags = __float_as_uint(b.w);
-  last = (flags & 4u) != 0;  // kTriLastOfLeaf
+  k.prim = __float_as_uint(a.w);
+  k.flags = __float_as_uint(b.w);
+  k.aux = __float_as_uint(c.w);
+  k.last = (k.flags & 4u) != 0;  // kTriLastOfLeaf
+  k.ok = false;
+  k.t = k.u = k.v = 0.0f;
   const f3 pvec = cross(T.d, e2);
   const float det = dot(e1, pvec);
-  if (MODE == 1 && !(flags & 2u)) {
-    if (!(det > 0.0f)) return false;
+  if (MODE == 1 && !(k.flags & 2u)) {
+    if (!(det > 0.0f)) return k;
   } else {
-    if (det == 0.0f) return false;
+    if (det == 0.0f) return k;
   }
   const float inv = 1.0f / det;
   const f3 tvec = T.o - v0;
   const float u = dot(tvec, pvec) * inv;
-  if (u < 0.0f || u > 1.0f) return false;
+  if (u < 0.0f || u > 1.0f) return k;
   const f3 qvec = cross(tvec, e1);
   const float v = dot(T.d, qvec) * inv;
-  if (v < 0.0f || u + v > 1.0f) return false;
+  if (v < 0.0f || u + v > 1.0f) return k;
   const float t = dot(e2, qvec) * inv;
-  if (!((t > T.tmin) && (t < T.tmax))) return false;
-  if ((flags & 1u) && alphaTestFails(S, __float_as_uint(c.w), u, v)) return false;  // any-hit shader: IgnoreHit()
+  if (!((t > T.tmin) && (t < T.tmax))) return k;
+  k.t = t;
+  k.u = u;
+  k.v = v;
+  k.ok = true;
+  return k;
+}
+// returns true when an any-hit query is finished
+template <int MODE>
+BD bool triCommit(TravState& T, const TriCand& k) {
   if (MODE == 2) {
     T.best.prim = 0;
-    T.best.t = t;
+    T.best.t = k.t;
     return true;
   }
-  if (t < T.best.t || (t == T.best.t && T.best.prim >= 0 && (int)prim < T.best.prim)) {
-    T.best.prim = (int)prim;
-    T.best.t = t;
-    T.best.u = u;
-    T.best.v = v;
+  if (k.t < T.best.t || (k.t == T.best.t && T.best.prim >= 0 && (int)k.prim < T.best.prim)) {
+    T.best.prim = (int)k.prim;
+    T.best.t = k.t;
+    T.best.u = k.u;
+    T.best.v = k.v;
   }
   return false;
+}
+template <int MODE>
+BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, bool& last) {
+  const TriCand k = triGeom<MODE>(T, a, b, c);
+  last = k.last;
+  if (!k.ok) return false;
+  if ((k.flags & 1u) && alphaTestFails(S, k.aux, k.u, k.v)) return false;  // any-hit shader: IgnoreHit()
+  return triCommit<MODE>(T, k);
 }
 
 // All triangles of the leaf in T.cur; returns true when an any-hit query is finished.
@@ -250,15 +277,31 @@ template <int MODE, bool COUNT>
 BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   // The first TWO records are fetched together (six loads in flight): half of the leaves hold two triangles and their
   // second test would otherwise wait for a second, dependent fetch; a one-triangle leaf fetches the record behind it
-  // for nothing (the array ends with a pad record).
+  // for nothing (the array ends with a pad record).  Likewise the alpha tests of the two: both records, then both texel
+  // quads, fetched side by side (the test has no side effect, so running the second one although the first triangle may
+  // end an any-hit query changes nothing but a little traffic).
   const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(uint32_t)~T.cur * 3;
   const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2], a1 = tp[3], b1 = tp[4], c1 = tp[5];
-  bool last;
   if (COUNT) nTris++;
-  if (triStep<MODE>(S, T, a0, b0, c0, last)) return true;
-  if (last) return false;
-  if (COUNT) nTris++;
-  if (triStep<MODE>(S, T, a1, b1, c1, last)) return true;
+  TriCand k0 = triGeom<MODE>(T, a0, b0, c0), k1;
+  k1.ok = false;
+  k1.last = true;
+  k1.t = k1.u = k1.v = 0.0f;
+  k1.prim = k1.flags = k1.aux = 0u;
+  if (!k0.last) {
+    if (COUNT) nTris++;
+    k1 = triGeom<MODE>(T, a1, b1, c1);
+  }
+  const bool n0 = k0.ok && (k0.flags & 1u), n1 = k1.ok && (k1.flags & 1u);
+  if (n0 || n1) {
+    bool f0 = false, f1 = false;
+    alphaTestFails2(S, n0, k0.aux, k0.u, k0.v, n1, k1.aux, k1.u, k1.v, f0, f1);
+    k0.ok = k0.ok && !f0;
+    k1.ok = k1.ok && !f1;
+  }
+  if (k0.ok && triCommit<MODE>(T, k0)) return true;
+  if (k1.ok && triCommit<MODE>(T, k1)) return true;
+  bool last = k1.last;
   tp += 6;
   while (!last) {  // leaves of more than two triangles (builder knob BDPT_LEAF_MAX)
     const float4 a = tp[0], b = tp[1], c = tp[2];

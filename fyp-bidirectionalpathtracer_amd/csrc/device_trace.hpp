@@ -268,7 +268,9 @@ BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b,
   const TriCand k = triGeom<MODE>(T, a, b, c);
   last = k.last;
   if (!k.ok) return false;
-  if ((k.flags & 1u) && alphaTestFails(S, k.aux, k.u, k.v)) return false;  // any-hit shader: IgnoreHit()
+  // any-hit shader: IgnoreHit().  A closest-hit candidate beyond the hit already held cannot be committed whatever the
+  // test says (DXR does not report such candidates either), so the test and its fetches are skipped for it.
+  if ((k.flags & 1u) && (MODE == 2 || k.t <= T.best.t) && alphaTestFails(S, k.aux, k.u, k.v)) return false;
   return triCommit<MODE>(T, k);
 }
 
@@ -292,7 +294,9 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
     if (COUNT) nTris++;
     k1 = triGeom<MODE>(T, a1, b1, c1);
   }
-  const bool n0 = k0.ok && (k0.flags & 1u), n1 = k1.ok && (k1.flags & 1u);
+  // (closest hit: a candidate beyond the hit already held cannot be committed whatever its alpha test says: not run)
+  const bool n0 = k0.ok && (k0.flags & 1u) && (MODE == 2 || k0.t <= T.best.t);
+  const bool n1 = k1.ok && (k1.flags & 1u) && (MODE == 2 || k1.t <= T.best.t);
   if (n0 || n1) {
     bool f0 = false, f1 = false;
     alphaTestFails2(S, n0, k0.aux, k0.u, k0.v, n1, k1.aux, k1.u, k1.v, f0, f1);

@@ -404,6 +404,16 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   }
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.textures, texs.data(), texs.size()))) return rc;
   {
+    std::vector<TexDev> matTex((size_t)d->numMaterials * 4, TexDev{nullptr, 0, 0, 0, 0});
+    for (uint32_t mi = 0; mi < d->numMaterials; mi++) {
+      const bdpt_material& mm = d->materials[mi];
+      const int ids[4] = {mm.texBaseColor, mm.texSpecular, mm.texEmissive, mm.texNormal};
+      for (int k = 0; k < 4; k++)
+        if (ids[k] >= 0) matTex[(size_t)mi * 4 + k] = texs[(size_t)ids[k]];
+    }
+    if ((rc = devUpload(c, c->sceneAllocs, &c->S.matTex, matTex.data(), matTex.size()))) return rc;
+  }
+  {
     std::vector<float> alphaRecs(std::max<size_t>(alphaTris.size(), 1) * 16, 0.0f);
     hostParallelFor(alphaTris.size(), [&](size_t i0, size_t i1) {
       for (size_t i = i0; i < i1; i++) {

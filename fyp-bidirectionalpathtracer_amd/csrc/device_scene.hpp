@@ -32,8 +32,7 @@ BD f4 texel(const SceneDev& S, const TexDev& t, int ix, int iy) {
   return r;
 }
 // linear filter, wrap addressing, mip 0 (sampler: SharedUtils/SceneLoaderWrapper.cpp:65-68)
-BD f4 sampleBilinear(const SceneDev& S, int texId, float u, float v) {
-  const TexDev t = S.textures[texId];
+BD f4 sampleBilinearT(const SceneDev& S, const TexDev& t, float u, float v) {
   float x = u * (float)t.w - 0.5f;
   float y = v * (float)t.h - 0.5f;
   float x0 = floorf(x), y0 = floorf(y);
@@ -44,11 +43,18 @@ BD f4 sampleBilinear(const SceneDev& S, int texId, float u, float v) {
   f4 t01 = texel(S, t, ix0, iy1), t11 = texel(S, t, ix1, iy1);
   return lerp4(lerp4(t00, t10, fx), lerp4(t01, t11, fx), fy);
 }
+BD f4 sampleBilinear(const SceneDev& S, int texId, float u, float v) { return sampleBilinearT(S, S.textures[texId], u, v); }
 // Falcor ShadingUtils/Shading.slang:88-94
 BD f4 sampleTexture(const SceneDev& S, int texId, float u, float v, f4 factor, uint32_t mode) {
   if (mode == BDPT_CHANNEL_UNUSED) return f4{0, 0, 0, 0};
   if (mode == BDPT_CHANNEL_CONST || texId < 0) return factor;
   return sampleBilinear(S, texId, u, v);
+}
+// the same with the texture's descriptor already fetched (SceneDev::matTex: fetched beside the material record, not after it)
+BD f4 sampleTextureT(const SceneDev& S, const TexDev& t, int texId, float u, float v, f4 factor, uint32_t mode) {
+  if (mode == BDPT_CHANNEL_UNUSED) return f4{0, 0, 0, 0};
+  if (mode == BDPT_CHANNEL_CONST || texId < 0) return factor;
+  return sampleBilinearT(S, t, u, v);
 }
 
 struct MatDev {
@@ -208,14 +214,17 @@ BD Shading shadeHit(const SceneDev& S, uint32_t prim, float bu, float bv, f3 cam
   posW = posW + mk(r4.x, r4.y, r4.z) * bv;
   normalW = normalize(normalW);
 
-  const MatDev m = loadMaterial(S, __float_as_uint(r6.x));
+  const uint32_t matId = __float_as_uint(r6.x);
+  const MatDev m = loadMaterial(S, matId);
+  // the descriptors of the material's base, specular and emissive textures, fetched beside the material record
+  const TexDev tBase = S.matTex[(size_t)matId * 4], tSpec = S.matTex[(size_t)matId * 4 + 1], tEmis = S.matTex[(size_t)matId * 4 + 2];
   Shading sd;
-  f4 base = sampleTexture(S, m.texBase, u, v, m.baseColor, BDPT_FLAG_DIFFUSE_TYPE(m.flags));
+  f4 base = sampleTextureT(S, tBase, m.texBase, u, v, m.baseColor, BDPT_FLAG_DIFFUSE_TYPE(m.flags));
   sd.opacity = m.baseColor.w;
   sd.posW = posW;
   sd.V = normalize(camPosW - posW);
   sd.N = normalize(normalW);
-  f4 spec = sampleTexture(S, m.texSpec, u, v, m.specular, BDPT_FLAG_SPECULAR_TYPE(m.flags));
+  f4 spec = sampleTextureT(S, tSpec, m.texSpec, u, v, m.specular, BDPT_FLAG_SPECULAR_TYPE(m.flags));
   f3 baseRgb = mk(base.x, base.y, base.z);
   if (BDPT_FLAG_SHADING_MODEL(m.flags) == BDPT_SHADING_MODEL_METAL_ROUGH) {
     sd.diffuse = lerp3(baseRgb, mk(0), spec.z);
@@ -228,7 +237,7 @@ BD Shading shadeHit(const SceneDev& S, uint32_t prim, float bu, float bv, f3 cam
   }
   sd.linearRoughness = maxf(0.08f, sd.linearRoughness);
   sd.roughness = sd.linearRoughness * sd.linearRoughness;
-  f4 em = sampleTexture(S, m.texEmis, u, v, f4{m.emissive.x, m.emissive.y, m.emissive.z, 1.0f}, BDPT_FLAG_EMISSIVE_TYPE(m.flags));
+  f4 em = sampleTextureT(S, tEmis, m.texEmis, u, v, f4{m.emissive.x, m.emissive.y, m.emissive.z, 1.0f}, BDPT_FLAG_EMISSIVE_TYPE(m.flags));
   sd.emissive = mk(em.x, em.y, em.z);
   sd.IoR = m.IoR;
   const bool doubleSided = BDPT_FLAG_DOUBLE_SIDED(m.flags) != 0;

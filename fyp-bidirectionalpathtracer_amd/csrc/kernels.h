@@ -69,6 +69,7 @@ struct SceneDev {
   const uint32_t* indices;  // 3 per primitive
   const bdpt_material* materials;
   const TexDev* textures;
+  const TexDev* matTex;     // 4 per material: descriptors of its base-colour, specular, emissive and normal textures (zero when absent)
   const SceneConst* sc;
   uint32_t numLights;
   uint32_t hasBitangents;

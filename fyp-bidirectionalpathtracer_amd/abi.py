@@ -114,7 +114,8 @@ class Counters(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("maxDepth", C.c_uint32),
                 ("nodeBytes", C.c_uint32), ("triBytes", C.c_uint32), ("sahCost", C.c_float), ("maxStack", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("numReferences", C.c_uint32), ("numDropped", C.c_uint32),
+                ("numAlphaMode", C.c_uint32), ("numAlwaysPass", C.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/*.h declares
@@ -126,6 +127,10 @@ PROTOTYPES = {
     "bdpt_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(BvhInfo)]),
     "bdpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "bdpt_bvh_build_check": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BvhInfo), C.c_char_p, C.c_uint32]),
+    "bdpt_host_bvh_create": (C.c_void_p, [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(BvhInfo)]),
+    "bdpt_host_bvh_destroy": (None, [C.c_void_p]),
+    "bdpt_host_bvh_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "bdpt_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.POINTER(Camera)]),
     "bdpt_msaa_jitter": (None, [C.c_uint32, C.POINTER(C.c_float)]),

@@ -20,8 +20,11 @@
 #include <vector>
 
 #include "../../include/bdpt.h"
+#include <new>
+
 #include "bvh.h"
 #include "kernels.h"
+#include "scene_bvh.h"
 
 using namespace bdpt;
 
@@ -318,25 +321,16 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->S.stackOvf = c->stackOvf;
   c->S.stackOvfStride = c->stackOvfStride;
 
-  // per-triangle traversal flags: BLAS OPAQUE iff AlphaModeOpaque (Falcor Raytracing/RtModel.cpp:221-224),
-  // TRIANGLE_CULL_DISABLE iff double-sided (Raytracing/RtScene.cpp:175-178)
-  std::vector<uint32_t> triFlags(d->numTriangles);
-  hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
-    for (size_t t = t0; t < t1; t++) {
-      const uint32_t f = d->materials[d->triMaterial[t]].flags;
-      triFlags[t] = (BDPT_FLAG_ALPHA_MODE(f) != BDPT_ALPHA_MODE_OPAQUE ? kTriNonOpaque : 0u) |
-                    (BDPT_FLAG_DOUBLE_SIDED(f) ? kTriDoubleSided : 0u);
-    }
-  });
-  // non-opaque triangles get an alpha-test record (device_scene.hpp alphaTestFails); its index travels in BvhTri::aux
-  std::vector<uint32_t> triAux(d->numTriangles, 0u), alphaTris;
-  for (uint32_t t = 0; t < d->numTriangles; t++)
-    if (triFlags[t] & kTriNonOpaque) {
-      triAux[t] = (uint32_t)alphaTris.size();
-      alphaTris.push_back(t);
-    }
-  Bvh bvh;
-  buildBvh(d->positions, d->indices, d->numTriangles, triFlags.data(), bvh, 0, triAux.data());
+  // traversal flags, alpha classification, spatial pre-splitting and the tree itself: scene_bvh.cpp
+  SceneBvh sb;
+  try {
+    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb);
+  } catch (const std::bad_alloc&) {
+    fail(c, "scene: out of host memory while building the acceleration structure");
+    return BDPT_E_NOMEM;
+  }
+  Bvh& bvh = sb.bvh;
+  const std::vector<uint32_t>& alphaTris = sb.alphaTris;
   if (bvh.maxStack > (uint32_t)kBvhMaxStack) {
     fail(c, "bvh needs a deeper traversal stack than the device provides");
     return BDPT_E_LIMIT;
@@ -352,6 +346,10 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->bvhInfo.triBytes = sizeof(BvhTri);
   c->bvhInfo.sahCost = bvh.sahCost;
   c->bvhInfo.maxStack = bvh.maxStack;
+  c->bvhInfo.numReferences = (uint32_t)bvh.tris.size();
+  c->bvhInfo.numDropped = bvh.numDropped;
+  c->bvhInfo.numAlphaMode = sb.numAlphaMode;
+  c->bvhInfo.numAlwaysPass = sb.numAlwaysPass;
 
   // per-primitive shading records: 3 x (position, normal, uv) + material id, 112 B
   std::vector<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4, 0.0f);
@@ -464,198 +462,6 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.sc, &sc, 1))) return rc;
   c->S.numLights = d->numLights;
   c->haveScene = true;
-  return BDPT_OK;
-}
-
-int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg, uint32_t msgCap) {
-  auto say = [&](const std::string& m) {
-    if (msg && msgCap) {
-      std::snprintf(msg, msgCap, "%s", m.c_str());
-    }
-    return BDPT_E_INVALID;
-  };
-  if (!d || !out || !d->positions || !d->indices) return say("null scene");
-  Bvh bvh;
-  buildBvh(d->positions, d->indices, d->numTriangles, nullptr, bvh);
-  out->numNodes = (uint32_t)bvh.nodes.size();
-  out->numTriangles = d->numTriangles;
-  out->maxDepth = bvh.maxDepth;
-  out->nodeBytes = sizeof(BvhRec);
-  out->triBytes = sizeof(BvhTri);
-  out->sahCost = bvh.sahCost;
-  out->maxStack = bvh.maxStack;
-  if (bvh.maxStack > (uint32_t)kBvhMaxStack) return say("worst-case stack exceeds kBvhMaxStack");
-  if (bvh.tris.size() != d->numTriangles) return say("triangle list size");
-  std::vector<uint8_t> seen(d->numTriangles, 0);
-  for (const BvhTri& t : bvh.tris) {
-    if (t.prim >= d->numTriangles || seen[t.prim]) return say("primitive missing or duplicated in the leaf order");
-    seen[t.prim] = 1;
-  }
-  if (d->numTriangles == 0) return BDPT_OK;
-  // walk: returns the exact bounds of a subtree and checks them against the decoded (quantised) box
-  std::vector<uint8_t> covered(d->numTriangles, 0);
-  struct Bounds {
-    float lo[3], hi[3];
-  };
-  bool ok = true;
-  std::string why;
-  std::function<Bounds(int32_t, uint32_t, uint32_t)> walk = [&](int32_t ref, uint32_t depth, uint32_t stackAbove) -> Bounds {
-    Bounds b;
-    for (int k = 0; k < 3; k++) {
-      b.lo[k] = 1e30f;
-      b.hi[k] = -1e30f;
-    }
-    if (depth > 64) {
-      ok = false;
-      why = "walk deeper than 64 levels";
-      return b;
-    }
-    if (ref < 0) {
-      const uint32_t enc = (uint32_t)(-1 - ref), first = enc >> 3, cnt = (enc & 7u) + 1u;
-      for (uint32_t i = 0; i < cnt; i++) {
-        if (first + i >= bvh.tris.size() || covered[first + i]) {
-          ok = false;
-          why = "leaf range out of bounds or shared";
-          return b;
-        }
-        covered[first + i] = 1;
-        const BvhTri& t = bvh.tris[first + i];
-        for (int k = 0; k < 3; k++) {
-          const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];
-          b.lo[k] = std::min(b.lo[k], std::min(p0, std::min(p1, p2)));
-          b.hi[k] = std::max(b.hi[k], std::max(p0, std::max(p1, p2)));
-        }
-      }
-      return b;
-    }
-    if ((size_t)ref >= bvh.nodes.size()) {
-      ok = false;
-      why = "child index out of range";
-      return b;
-    }
-    const BvhNode& n = bvh.nodes[(size_t)ref];
-    const uint32_t numChildren = (uint32_t)bvhNumChildren(n);
-    if (numChildren < 1 || numChildren > 4 || stackAbove + numChildren - 1 > (uint32_t)kBvhMaxStack) {
-      ok = false;
-      why = "bad child count or stack bound";
-      return b;
-    }
-    for (int c = 0; c < 4; c++) {
-      if (c >= (int)numChildren) {
-        for (int k = 0; k < 3; k++)
-          if (!(n.lo[k][c] == 255 && n.hi[k][c] == 0)) {
-            ok = false;
-            why = "unused child slot is not inverted";
-          }
-        continue;
-      }
-      Bounds cb = walk(n.child[c], depth + 1, stackAbove + numChildren - 1);
-      for (int k = 0; k < 3; k++) {
-        if (cb.lo[k] < bvhDecodePlane(n, k, n.lo[k][c]) || cb.hi[k] > bvhDecodePlane(n, k, n.hi[k][c])) {
-          ok = false;
-          why = "decoded child box does not contain its subtree";
-        }
-        b.lo[k] = std::min(b.lo[k], cb.lo[k]);
-        b.hi[k] = std::max(b.hi[k], cb.hi[k]);
-      }
-    }
-    return b;
-  };
-  walk(0, 0, 0);
-  if (!ok) return say(why);
-  for (uint32_t i = 0; i < d->numTriangles; i++)
-    if (!covered[i]) return say("a leaf-order triangle is not referenced by any leaf");
-  // the packed 48-byte records (what the device traverses) must decode to the same tree
-  if (bvh.recs.empty()) return say("packed records missing");
-  std::vector<uint8_t> used(bvh.recs.size(), 0);
-  std::function<void(uint32_t, uint32_t, uint32_t)> walkPacked = [&](uint32_t rec, uint32_t node, uint32_t depth) {
-    if (!ok) return;
-    if (rec >= bvh.recs.size() || used[rec] || depth > 64) {
-      ok = false;
-      why = "packed node record out of range or shared";
-      return;
-    }
-    used[rec] = 1;
-    const BvhRec& r = bvh.recs[rec];
-    const BvhNode& n = bvh.nodes[node];
-    bool same = std::memcmp(&r.w[0], n.origin, 12) == 0 && std::memcmp(&r.w[4], n.lo, 12) == 0 && std::memcmp(&r.w[7], n.hi, 12) == 0;
-    for (int a = 0; a < 3; a++) {
-      const uint32_t bits = ((r.w[3] >> (8 * a)) & 0xffu) << 23;  // the device's decode
-      float f;
-      std::memcpy(&f, &bits, 4);
-      same = same && f == n.scale[a];
-    }
-    if (!same) {
-      ok = false;
-      why = "packed node does not decode to its node";
-      return;
-    }
-    const uint32_t numChildren = (uint32_t)bvhNumChildren(n);
-    for (uint32_t c = 0; c < numChildren; c++) {
-      const uint32_t idx = r.w[10] + ((r.w[11] >> (8 * c)) & 0xffu);
-      const bool leaf = ((r.w[3] >> (24 + c)) & 1u) != 0;
-      const int32_t ref = n.child[c];
-      if (leaf != (ref < 0)) {
-        ok = false;
-        why = "packed child kind differs";
-        return;
-      }
-      if (!leaf) {
-        walkPacked(idx, (uint32_t)ref, depth + 1);
-        continue;
-      }
-      const uint32_t enc = (uint32_t)(-1 - ref), first = enc >> 3, cnt = (enc & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; k++) {
-        if (idx + k >= bvh.recs.size() || used[idx + k]) {
-          ok = false;
-          why = "packed leaf out of range or shared";
-          return;
-        }
-        used[idx + k] = 1;
-        BvhTri t = bvh.tris[first + k];
-        if (k + 1 == cnt) t.flags |= kTriLastOfLeaf;
-        if (std::memcmp(&bvh.recs[idx + k], &t, sizeof(BvhTri)) != 0) {
-          ok = false;
-          why = "packed leaf triangle differs";
-          return;
-        }
-      }
-    }
-  };
-  walkPacked(0, 0, 0);
-  if (!ok) return say(why);
-  for (size_t i = 0; i + 1 < used.size(); i++)  // (the last record is the pad behind the array)
-    if (!used[i]) return say("a packed record is not referenced");
-  if (used.back()) return say("the pad record is referenced");
-  return BDPT_OK;
-}
-
-int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info) {
-  if (!d || !out_hash || !d->positions || !d->indices) return BDPT_E_INVALID;
-  Bvh bvh;
-  buildBvh(d->positions, d->indices, d->numTriangles, nullptr, bvh, threads);
-  uint64_t h = 1469598103934665603ull;  // FNV-1a over the node array, the leaf-ordered triangles and the summary
-  auto mix = [&](const void* p, size_t n) {
-    const uint8_t* b = static_cast<const uint8_t*>(p);
-    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
-  };
-  mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
-  mix(bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri));
-  mix(bvh.recs.data(), bvh.recs.size() * sizeof(BvhRec));
-  mix(&bvh.maxDepth, sizeof(bvh.maxDepth));
-  mix(&bvh.maxStack, sizeof(bvh.maxStack));
-  mix(&bvh.sahCost, sizeof(bvh.sahCost));
-  *out_hash = h;
-  if (out_info) {
-    out_info->numNodes = (uint32_t)bvh.nodes.size();
-    out_info->numTriangles = d->numTriangles;
-    out_info->maxDepth = bvh.maxDepth;
-    out_info->nodeBytes = sizeof(BvhRec);
-    out_info->triBytes = sizeof(BvhTri);
-    out_info->sahCost = bvh.sahCost;
-    out_info->maxStack = bvh.maxStack;
-    out_info->reserved = (uint32_t)bvhBuildThreads();
-  }
   return BDPT_OK;
 }
 

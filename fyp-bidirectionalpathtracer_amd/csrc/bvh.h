@@ -72,17 +72,41 @@ constexpr uint32_t kTriLastOfLeaf = 4u;  // BvhTri::flags bit set by packBvh (de
 
 struct Bvh {
   std::vector<BvhNode> nodes;
-  std::vector<BvhTri> tris;  // in leaf order
+  std::vector<BvhTri> tris;  // in leaf order: one record per REFERENCE (a split triangle appears once per piece)
+  std::vector<float> refBox; // 6 floats (lo, hi) per entry of `tris`: bounds of the piece the reference stands for
   std::vector<BvhRec> recs;  // packed device form of the two (packBvh)
   uint32_t maxDepth = 0;     // depth of the four-wide tree
   uint32_t maxStack = 0;     // worst-case number of simultaneously stacked references
   float sahCost = 0.0f;
+  uint32_t numDropped = 0;   // input triangles with no reference at all (the clipper found nothing that can be hit)
+};
+
+// Lets the caller shrink or drop the part of a triangle a reference stands for.  Used for non-opaque triangles
+// (flag kTriNonOpaque): a hit is only ever reported where the any-hit alpha test passes, so a piece whose texels
+// all fail can never produce a hit and needs no reference, and a reference only has to bound the part of its
+// piece where the test can pass.  `poly` is a convex polygon in the triangle's barycentric plane, vertex k =
+// (bu, bv) with P = v0 + bu e1 + bv e2, at most kBvhPolyMax vertices.  Returns false when nothing is left.
+constexpr int kBvhPolyMax = 24;
+struct BvhRefClipper {
+  virtual ~BvhRefClipper() {}
+  virtual bool clip(uint32_t tri, double (*poly)[2], int& n) const = 0;
+};
+
+struct BvhBuildOptions {
+  int threads = 0;                // <= 0: bvhBuildThreads()
+  // Spatial pre-splitting (bvh_build.cpp "References"): extra references the builder may create, as a fraction of the
+  // number of opaque / non-opaque triangles.  0 = one reference per triangle (object splits only).
+  float splitBudget = -1.0f;      // < 0: the build default (BDPT_SPLIT_BUDGET)
+  float splitBudgetAlpha = -1.0f; // < 0: the build default (BDPT_SPLIT_BUDGET_ALPHA)
+  const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
 };
 
 // positions: 3 floats per vertex; indices: 3 per triangle; triFlags: per triangle (may be null).
 // threads <= 0: bvhBuildThreads().  The tree does not depend on the thread count, bit for bit.
 void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTriangles, const uint32_t* triFlags, Bvh& out,
               int threads = 0, const uint32_t* triAux = nullptr);
+void buildBvh(const float* positions, const uint32_t* indices, uint32_t numTriangles, const uint32_t* triFlags, Bvh& out,
+              const BvhBuildOptions& opt, const uint32_t* triAux = nullptr);
 // host threads the builder uses by default: BDPT_BUILD_THREADS, else the affinity mask capped by the cgroup CPU quota
 int bvhBuildThreads();
 

@@ -61,6 +61,28 @@ struct TmpNode {
 #ifndef BDPT_LEAF_MAX
 #define BDPT_LEAF_MAX 2
 #endif
+// Default budgets.  Opaque triangles: none — measured on the bench atrium (tools/bvh_eval.py, profiles/README.md r3)
+// pre-splitting by priority makes an evenly tessellated scene's tree worse at every setting tried (SAH cost 31.3 ->
+// 31.5-35.2, +0-14 % node visits); the knob (also the environment variable BDPT_SPLIT_BUDGET) stays for scenes that
+// mix huge and tiny triangles.  Non-opaque triangles: two extra references each — the 10 M-triangle courtyard's
+// closest-hit rays go from 82 node visits + 59 triangle tests to 48 + 18.
+#ifndef BDPT_SPLIT_BUDGET
+#define BDPT_SPLIT_BUDGET 0.0f
+#endif
+#ifndef BDPT_SPLIT_BUDGET_ALPHA
+#define BDPT_SPLIT_BUDGET_ALPHA 2.0f
+#endif
+// Opaque triangles are only split when their box is an outlier — at least this many times the median box area of the
+// scene's opaque triangles — and only down to about that size: the Karras-Aila priority ranks triangles against each
+// other and would spend the whole budget on an evenly tessellated scene without a reason.  Non-opaque triangles are
+// split without this test: overlapping alpha-masked cards are what their budget is for, and each piece is also
+// clipped to the texels that can pass.
+#ifndef BDPT_SPLIT_OUTLIER
+#define BDPT_SPLIT_OUTLIER 8.0f
+#endif
+#ifndef BDPT_SPLIT_MAX_PER_TRI
+#define BDPT_SPLIT_MAX_PER_TRI 255
+#endif
 constexpr int kBins = BDPT_SAH_BINS;
 // Leaves hold at most two triangles.  Measured on the bench frame (profiles/README.md r2): leaves of <= 1 / 2 / 3 / 4 / 8
 // triangles give 23.6 / 19.1 / 19.5 / 20.1 / 23.0 ms per frame — a triangle test costs half a node visit and leaf runs of
@@ -308,6 +330,214 @@ void buildSubtree(const BuildData& B, std::vector<TmpNode>& nodes, uint32_t root
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// References.  The tree is built over REFERENCES, not triangles: a reference is (triangle, box of the piece of it
+// the reference stands for).  One reference per triangle gives the classic object-split tree; spatial
+// pre-splitting cuts the box of a triangle at spatial-median planes of the scene box and gives every piece its own
+// reference, so that large or diagonal triangles (and, above all, the overlapping alpha-masked cards of foliage)
+// stop inflating every box above them.  The leaf still intersects the WHOLE triangle (device_trace.hpp triGeom): a
+// hit found through any reference of a triangle is that triangle's one hit, and the closest-hit tie rule (lowest
+// primitive index; the same primitive never replaces itself) makes duplicates harmless.
+//
+// How many splits a triangle gets follows Karras & Aila, "Fast parallel construction of high-quality bounding
+// volume hierarchies" (HPG 2013), section 4.3: priority p = (2^-level * (A_box - A_ideal))^(1/3), where level is
+// that of the most important spatial-median plane cutting the box and A_ideal = |e1 x e2|_1 is the box area the
+// triangle would reach if split without end; split counts s_t = floor(D p_t) with D chosen so that their sum meets
+// the budget; a piece hands its remaining splits to its two halves in proportion to their extents.
+//
+// Pieces are convex polygons in the triangle's barycentric plane (vertex = (bu, bv), P = v0 + bu e1 + bv e2),
+// clipped in double precision; a piece's box is rounded outwards to float (the builder's pad covers the fp32
+// rounding of the device's triangle test, as it does for whole triangles).  For non-opaque triangles the caller's
+// BvhRefClipper shrinks a piece to where the alpha test can pass, or drops it.
+// ------------------------------------------------------------------------------------------------
+struct Piece {
+  double b[kBvhPolyMax][2];
+  int n;
+  Box box;
+  uint32_t splits;
+};
+
+inline float floatDown(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+  return f;
+}
+inline float floatUp(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+
+Box polyBox(const BvhTri& r, const double (*b)[2], int n) {
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int k = 0; k < n; k++)
+    for (int a = 0; a < 3; a++) {
+      const double p = (double)r.v0[a] + b[k][0] * (double)r.e1[a] + b[k][1] * (double)r.e2[a];
+      lo[a] = std::min(lo[a], p);
+      hi[a] = std::max(hi[a], p);
+    }
+  Box bx;
+  for (int a = 0; a < 3; a++) {
+    bx.lo[a] = floatDown(lo[a]);
+    bx.hi[a] = floatUp(hi[a]);
+  }
+  return bx;
+}
+
+// Sutherland-Hodgman against the closed half-plane A + B bu + C bv <= 0
+int clipHalfPlane(const double (*in)[2], int n, double A, double B, double C, double (*out)[2]) {
+  int m = 0;
+  for (int k = 0; k < n; k++) {
+    const double* p = in[k];
+    const double* q = in[(k + 1) % n];
+    const double fp = A + B * p[0] + C * p[1], fq = A + B * q[0] + C * q[1];
+    if (fp <= 0.0 && m < kBvhPolyMax) {
+      out[m][0] = p[0];
+      out[m][1] = p[1];
+      m++;
+    }
+    if (((fp < 0.0 && fq > 0.0) || (fp > 0.0 && fq < 0.0)) && m < kBvhPolyMax) {
+      const double t = fp / (fp - fq);
+      out[m][0] = p[0] + t * (q[0] - p[0]);
+      out[m][1] = p[1] + t * (q[1] - p[1]);
+      m++;
+    }
+  }
+  return m;
+}
+
+struct SplitGrid {  // spatial-median planes of the scene box on a 2^30 grid per axis
+  double lo[3], ext[3];
+  // most important plane strictly inside [a, b] on `axis`: its importance (bit position, higher = nearer the root) or -1
+  int plane(int axis, float a, float b, double& coord) const {
+    if (!(ext[axis] > 0.0) || !(b > a)) return -1;
+    const double s = 1073741824.0 / ext[axis];
+    double ua = std::floor(((double)a - lo[axis]) * s), ub = std::floor(((double)b - lo[axis]) * s);
+    ua = std::min(std::max(ua, 0.0), 1073741823.0);
+    ub = std::min(std::max(ub, 0.0), 1073741823.0);
+    const uint32_t ia = (uint32_t)ua, ib = (uint32_t)ub;
+    if (ia == ib) return -1;
+    const uint32_t diff = ia ^ ib;
+    const int h = 31 - __builtin_clz(diff);
+    const uint32_t pl = (ib >> h) << h;
+    coord = lo[axis] + (double)pl / s;
+    if (!(coord > (double)a && coord < (double)b)) return -1;  // (rounding at the ends of the interval)
+    return h;
+  }
+  int dominant(const Box& bx, int& axis, double& coord) const {
+    int best = -1;
+    float bestExt = -1.0f;
+    for (int a = 0; a < 3; a++) {
+      double c;
+      const int h = plane(a, bx.lo[a], bx.hi[a], c);
+      const float e = bx.hi[a] - bx.lo[a];
+      if (h > best || (h == best && h >= 0 && e > bestExt)) {
+        best = h;
+        bestExt = e;
+        axis = a;
+        coord = c;
+      }
+    }
+    return best;
+  }
+};
+
+double splitPriority(const SplitGrid& G, const BvhTri& r, const Box& bx, double polyShare) {
+  int axis = 0;
+  double c = 0;
+  const int h = G.dominant(bx, axis, c);
+  if (h < 0) return 0.0;
+  const double cx = (double)r.e1[1] * r.e2[2] - (double)r.e1[2] * r.e2[1], cy = (double)r.e1[2] * r.e2[0] - (double)r.e1[0] * r.e2[2],
+               cz = (double)r.e1[0] * r.e2[1] - (double)r.e1[1] * r.e2[0];
+  const double ideal = (std::fabs(cx) + std::fabs(cy) + std::fabs(cz)) * polyShare;
+  const double dx = (double)bx.hi[0] - bx.lo[0], dy = (double)bx.hi[1] - bx.lo[1], dz = (double)bx.hi[2] - bx.lo[2];
+  const double gain = 2.0 * (dx * dy + dy * dz + dz * dx) - ideal;
+  if (!(gain > 0.0)) return 0.0;
+  return std::cbrt(std::ldexp(gain, h - 30));
+}
+
+double polyArea2(const double (*b)[2], int n) {  // twice the area in barycentric units (the whole triangle: 1)
+  double s = 0;
+  for (int k = 0; k < n; k++) {
+    const double* p = b[k];
+    const double* q = b[(k + 1) % n];
+    s += p[0] * q[1] - q[0] * p[1];
+  }
+  return std::fabs(s);
+}
+
+inline Box intersectBox(const Box& a, const Box& b) {
+  Box r;
+  for (int k = 0; k < 3; k++) {
+    r.lo[k] = std::max(a.lo[k], b.lo[k]);
+    r.hi[k] = std::min(a.hi[k], b.hi[k]);
+    if (r.hi[k] < r.lo[k]) r.hi[k] = r.lo[k];  // (outward rounding of two disjoint-by-an-ulp intervals)
+  }
+  return r;
+}
+
+struct RefOut {
+  std::vector<Box> boxes;
+  std::vector<uint32_t> tri;
+};
+
+// All references of one triangle, appended to `out` in a fixed order.  Returns the number appended.
+uint32_t splitTriangle(const SplitGrid& G, const BvhTri& r, uint32_t t, const Piece& whole, const BvhRefClipper* clipper, RefOut& out) {
+  std::vector<Piece> todo{whole};
+  uint32_t made = 0;
+  while (!todo.empty()) {
+    Piece pc = todo.back();
+    todo.pop_back();
+    for (int guard = 0;; guard++) {
+      int axis = 0;
+      double c = 0;
+      if (pc.splits == 0 || guard > 96 || pc.n + 2 > kBvhPolyMax || G.dominant(pc.box, axis, c) < 0) {
+        out.boxes.push_back(pc.box);
+        out.tri.push_back(t);
+        made++;
+        break;
+      }
+      const double A = (double)r.v0[axis] - c, B = (double)r.e1[axis], C = (double)r.e2[axis];
+      Piece lo, hi;
+      lo.n = clipHalfPlane(pc.b, pc.n, A, B, C, lo.b);
+      hi.n = clipHalfPlane(pc.b, pc.n, -A, -B, -C, hi.b);
+      bool haveLo = lo.n >= 3 && polyArea2(lo.b, lo.n) > 0.0, haveHi = hi.n >= 3 && polyArea2(hi.b, hi.n) > 0.0;
+      if (clipper) {
+        if (haveLo) haveLo = clipper->clip(t, lo.b, lo.n) && lo.n >= 3;
+        if (haveHi) haveHi = clipper->clip(t, hi.b, hi.n) && hi.n >= 3;
+      }
+      if (haveLo) lo.box = intersectBox(polyBox(r, lo.b, lo.n), pc.box);
+      if (haveHi) hi.box = intersectBox(polyBox(r, hi.b, hi.n), pc.box);
+      if (!haveLo && !haveHi) {
+        if (!clipper) {  // (a sliver the clip lost to rounding: keep the piece as it was)
+          out.boxes.push_back(pc.box);
+          out.tri.push_back(t);
+          made++;
+        }
+        break;
+      }
+      if (!haveLo || !haveHi) {  // the polygon lies on one side of the plane although its box straddles it: shrink and go on
+        const uint32_t s = pc.splits;
+        pc = haveLo ? lo : hi;
+        pc.splits = s;
+        continue;
+      }
+      const uint32_t rest = pc.splits - 1;
+      const double wl = ((double)lo.box.hi[0] - lo.box.lo[0]) + ((double)lo.box.hi[1] - lo.box.lo[1]) + ((double)lo.box.hi[2] - lo.box.lo[2]);
+      const double wh = ((double)hi.box.hi[0] - hi.box.lo[0]) + ((double)hi.box.hi[1] - hi.box.lo[1]) + ((double)hi.box.hi[2] - hi.box.lo[2]);
+      uint32_t sl = (wl + wh > 0.0) ? (uint32_t)std::floor((double)rest * wl / (wl + wh) + 0.5) : rest / 2;
+      if (sl > rest) sl = rest;
+      lo.splits = sl;
+      hi.splits = rest - sl;
+      todo.push_back(hi);
+      pc = lo;
+      guard = 0;
+    }
+  }
+  return made;
+}
+
 }  // namespace
 
 int bvhBuildThreads() {
@@ -330,6 +560,14 @@ int bvhBuildThreads() {
 
 void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const uint32_t* triFlags, Bvh& out, int threads,
               const uint32_t* triAux) {
+  BvhBuildOptions opt;
+  opt.threads = threads;
+  buildBvh(positions, indices, n, triFlags, out, opt, triAux);
+}
+
+void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, const uint32_t* triFlags, Bvh& out,
+              const BvhBuildOptions& opt, const uint32_t* triAux) {
+  int threads = opt.threads;
   if (threads <= 0) threads = bvhBuildThreads();
   const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -342,20 +580,21 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
   };
   out.nodes.clear();
   out.tris.clear();
+  out.refBox.clear();
   out.maxDepth = 0;
   out.sahCost = 0.0f;
+  out.numDropped = 0;
 
   // Triangle records exactly as the device intersects them: the "actual" triangle is
   // (v0, v0+e1, v0+e2) in fp32, so bounds are taken from those points.
-  std::vector<BvhTri> recs(n);
-  std::vector<Box> boxes(n);
-  std::vector<float> cent((size_t)n * 3);
+  std::vector<BvhTri> recs(nTris);
+  std::vector<Box> triBox(nTris);
   Box scene;
   scene.reset();
   {
     std::vector<Box> part((size_t)threads);
     for (Box& b : part) b.reset();
-    parallelFor(n, threads, [&](size_t t0, size_t t1, int th) {
+    parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
       Box acc;
       acc.reset();
       for (size_t t = t0; t < t1; t++) {
@@ -381,8 +620,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
         bx.grow(p2);
         bx.grow(b);
         bx.grow(c);
-        boxes[t] = bx;
-        for (int k = 0; k < 3; k++) cent[t * 3 + (size_t)k] = 0.5f * (bx.lo[k] + bx.hi[k]);
+        triBox[t] = bx;
         acc.grow(bx);
       }
       part[(size_t)th].grow(acc);
@@ -390,13 +628,200 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
     for (const Box& b : part) scene.grow(b);
   }
   float diag = 0.0f;
-  if (n) {
+  if (nTris) {
     float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2];
     diag = std::sqrt(dx * dx + dy * dy + dz * dz);
   }
   // Slab tests run in fp32 on boxes that must never reject a hit the triangle test accepts:
   // pad every box by a small fraction of the scene diagonal (covers rounding in both tests).
   const float pad = 2e-5f * diag + 1e-30f;
+
+  // ---- references (see "References" above): the whole triangle, shrunk by the clipper where it is non-opaque,
+  // then split s_t times
+  auto budgetDefault = [](const char* env, float dflt) {
+    if (const char* e = std::getenv(env)) {
+      const float v = (float)std::atof(e);
+      if (v >= 0.0f && v <= 64.0f) return v;
+    }
+    return dflt;
+  };
+  const float budgetOpaque = opt.splitBudget >= 0.0f ? opt.splitBudget : budgetDefault("BDPT_SPLIT_BUDGET", (float)BDPT_SPLIT_BUDGET);
+  const float budgetAlpha = opt.splitBudgetAlpha >= 0.0f ? opt.splitBudgetAlpha : budgetDefault("BDPT_SPLIT_BUDGET_ALPHA", (float)BDPT_SPLIT_BUDGET_ALPHA);
+  SplitGrid G;
+  for (int a = 0; a < 3; a++) {
+    G.lo[a] = nTris ? (double)scene.lo[a] : 0.0;
+    G.ext[a] = nTris ? (double)scene.hi[a] - (double)scene.lo[a] : 0.0;
+  }
+  float outlierArea = 0.0f;  // opaque triangles below this box area are never split
+  if (budgetOpaque > 0.0f && nTris) {
+    std::vector<float> areas;
+    areas.reserve(nTris);
+    for (uint32_t t = 0; t < nTris; t++)
+      if (!(recs[t].flags & kTriNonOpaque)) areas.push_back(triBox[t].area());
+    if (!areas.empty()) {
+      std::nth_element(areas.begin(), areas.begin() + areas.size() / 2, areas.end());
+      outlierArea = (float)BDPT_SPLIT_OUTLIER * areas[areas.size() / 2];
+    }
+  }
+  std::vector<Piece> whole;  // only kept for triangles that are clipped or split
+  std::vector<double> prio(nTris, 0.0);
+  std::vector<float> capOf(nTris, (float)BDPT_SPLIT_MAX_PER_TRI);  // splits a triangle may get at most
+  std::vector<uint8_t> state(nTris, 0);  // 0 = plain reference (triBox), 1 = has a Piece, 2 = dropped
+  std::vector<uint32_t> pieceOf(nTris, 0);
+  const bool anySplit = budgetOpaque > 0.0f || budgetAlpha > 0.0f;
+  {
+    // pass 1: initial polygons of the non-opaque triangles (clipper) and every triangle's priority
+    std::vector<std::vector<Piece>> partPieces((size_t)threads);
+    std::vector<std::vector<uint32_t>> partIds((size_t)threads);
+    parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
+      for (size_t t = t0; t < t1; t++) {
+        const BvhTri& r = recs[t];
+        const bool alpha = (r.flags & kTriNonOpaque) != 0 && opt.clipper != nullptr;
+        Box bx = triBox[t];
+        double share = 1.0;
+        if (alpha) {
+          Piece pc;
+          pc.n = 3;
+          pc.b[0][0] = 0.0;
+          pc.b[0][1] = 0.0;
+          pc.b[1][0] = 1.0;
+          pc.b[1][1] = 0.0;
+          pc.b[2][0] = 0.0;
+          pc.b[2][1] = 1.0;
+          pc.splits = 0;
+          if (!opt.clipper->clip((uint32_t)t, pc.b, pc.n) || pc.n < 3) {
+            state[t] = 2;
+            continue;
+          }
+          const bool shrunk = !(pc.n == 3 && pc.b[0][0] == 0.0 && pc.b[0][1] == 0.0 && pc.b[1][0] == 1.0 && pc.b[1][1] == 0.0 &&
+                                pc.b[2][0] == 0.0 && pc.b[2][1] == 1.0);
+          if (shrunk) {
+            pc.box = intersectBox(polyBox(r, pc.b, pc.n), bx);
+            bx = pc.box;
+            share = polyArea2(pc.b, pc.n);
+            state[t] = 1;
+            partPieces[(size_t)th].push_back(pc);
+            partIds[(size_t)th].push_back((uint32_t)t);
+          }
+        }
+        const float budget = (r.flags & kTriNonOpaque) ? budgetAlpha : budgetOpaque;
+        if (budget > 0.0f && ((r.flags & kTriNonOpaque) || bx.area() >= outlierArea)) {
+          prio[t] = splitPriority(G, r, bx, share);
+          // an opaque outlier is cut down to about the size of its neighbours, not further
+          if (!(r.flags & kTriNonOpaque) && outlierArea > 0.0f)
+            capOf[t] = std::min((float)BDPT_SPLIT_MAX_PER_TRI, std::floor((float)BDPT_SPLIT_OUTLIER * bx.area() / outlierArea));
+        }
+      }
+    });
+    for (int th = 0; th < threads; th++)
+      for (size_t k = 0; k < partIds[(size_t)th].size(); k++) {
+        pieceOf[partIds[(size_t)th][k]] = (uint32_t)whole.size();
+        whole.push_back(partPieces[(size_t)th][k]);
+      }
+  }
+  // split counts per class: the largest D with sum floor(D p_t) <= budget (integer sums: thread-count independent)
+  std::vector<uint32_t> splits(nTris, 0);
+  if (anySplit && nTris) {
+    for (int cls = 0; cls < 2; cls++) {
+      const float budgetF = cls ? budgetAlpha : budgetOpaque;
+      if (!(budgetF > 0.0f)) continue;
+      uint64_t members = 0;
+      double pmax = 0.0;
+      for (uint32_t t = 0; t < nTris; t++)
+        if (state[t] != 2 && (((recs[t].flags & kTriNonOpaque) != 0) == (cls == 1))) {
+          members++;
+          pmax = std::max(pmax, prio[t]);
+        }
+      const uint64_t budget = (uint64_t)((double)members * (double)budgetF);
+      if (!members || !budget || !(pmax > 0.0)) continue;
+      auto total = [&](double D) {
+        std::vector<uint64_t> part((size_t)threads, 0);
+        parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
+          uint64_t acc = 0;
+          for (size_t t = t0; t < t1; t++)
+            if (state[t] != 2 && (((recs[t].flags & kTriNonOpaque) != 0) == (cls == 1)))
+              acc += (uint64_t)std::min<double>(std::floor(D * prio[t]), (double)capOf[t]);
+          part[(size_t)th] = acc;
+        });
+        uint64_t s = 0;
+        for (uint64_t v : part) s += v;
+        return s;
+      };
+      double dLo = 0.0, dHi = ((double)BDPT_SPLIT_MAX_PER_TRI + 1.0) / pmax;  // at dHi the largest priority is capped
+      if (total(dHi) <= budget) {
+        dLo = dHi;
+      } else {
+        for (int it = 0; it < 40; it++) {
+          const double mid = 0.5 * (dLo + dHi);
+          if (total(mid) <= budget)
+            dLo = mid;
+          else
+            dHi = mid;
+        }
+      }
+      parallelFor(nTris, threads, [&](size_t t0, size_t t1, int) {
+        for (size_t t = t0; t < t1; t++)
+          if (state[t] != 2 && (((recs[t].flags & kTriNonOpaque) != 0) == (cls == 1)))
+            splits[t] = (uint32_t)std::min<double>(std::floor(dLo * prio[t]), (double)capOf[t]);
+      });
+    }
+  }
+  lap("priorities");
+  // pass 2: the references, triangle order (thread chunks are contiguous triangle ranges, appended in order)
+  std::vector<Box> boxes;
+  std::vector<uint32_t> refTri;
+  {
+    std::vector<RefOut> part((size_t)threads);
+    parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
+      RefOut& o = part[(size_t)th];
+      for (size_t t = t0; t < t1; t++) {
+        if (state[t] == 2) continue;
+        if (splits[t] == 0) {
+          o.boxes.push_back(state[t] == 1 ? whole[pieceOf[t]].box : triBox[t]);
+          o.tri.push_back((uint32_t)t);
+          continue;
+        }
+        Piece pc;
+        if (state[t] == 1) {
+          pc = whole[pieceOf[t]];
+        } else {
+          pc.n = 3;
+          pc.b[0][0] = 0.0;
+          pc.b[0][1] = 0.0;
+          pc.b[1][0] = 1.0;
+          pc.b[1][1] = 0.0;
+          pc.b[2][0] = 0.0;
+          pc.b[2][1] = 1.0;
+          pc.box = triBox[t];
+        }
+        pc.splits = splits[t];
+        const bool alpha = (recs[t].flags & kTriNonOpaque) != 0 && opt.clipper != nullptr;
+        splitTriangle(G, recs[t], (uint32_t)t, pc, alpha ? opt.clipper : nullptr, o);
+      }
+    });
+    size_t total = 0;
+    for (const RefOut& o : part) total += o.tri.size();
+    boxes.reserve(total);
+    refTri.reserve(total);
+    for (const RefOut& o : part) {
+      boxes.insert(boxes.end(), o.boxes.begin(), o.boxes.end());
+      refTri.insert(refTri.end(), o.tri.begin(), o.tri.end());
+    }
+  }
+  {
+    uint32_t dropped = 0;
+    for (uint32_t t = 0; t < nTris; t++) dropped += state[t] == 2 ? 1u : 0u;
+    out.numDropped = dropped;
+  }
+  whole.clear();
+  whole.shrink_to_fit();
+  const uint32_t n = (uint32_t)boxes.size();  // references from here on
+  std::vector<float> cent((size_t)n * 3);
+  parallelFor(n, threads, [&](size_t r0, size_t r1, int) {
+    for (size_t r = r0; r < r1; r++)
+      for (int k = 0; k < 3; k++) cent[r * 3 + (size_t)k] = 0.5f * (boxes[r].lo[k] + boxes[r].hi[k]);
+  });
+  if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
 
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; i++) order[i] = i;
@@ -465,8 +890,15 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t n, const
   lap("append");
   // Leaf-ordered triangle list.
   out.tris.resize(n);
+  out.refBox.resize((size_t)n * 6);
   parallelFor(n, threads, [&](size_t a, size_t b, int) {
-    for (size_t i = a; i < b; i++) out.tris[i] = recs[order[i]];
+    for (size_t i = a; i < b; i++) {
+      out.tris[i] = recs[refTri[order[i]]];
+      for (int k = 0; k < 3; k++) {
+        out.refBox[i * 6 + (size_t)k] = boxes[order[i]].lo[k];
+        out.refBox[i * 6 + 3 + (size_t)k] = boxes[order[i]].hi[k];
+      }
+    }
   });
 
   // ---- collapse the binary tree into four-wide nodes and quantise the child boxes ----------------

@@ -279,6 +279,10 @@ typedef struct bdpt_bvh_info {
   float sahCost;
   uint32_t maxStack;  /* worst-case traversal stack entries this tree needs (the device holds 32 per lane) */
   uint32_t reserved;
+  uint32_t numReferences; /* leaf entries: a triangle cut by spatial pre-splitting has one per piece */
+  uint32_t numDropped;    /* alpha-mode triangles without any reference: every texel they can sample fails the alpha test */
+  uint32_t numAlphaMode;  /* triangles whose material is not AlphaModeOpaque (the reference runs the any-hit test on all of them) */
+  uint32_t numAlwaysPass; /* of those: triangles whose texels all pass, traversed as opaque */
 } bdpt_bvh_info;
 
 typedef struct bdpt_ctx bdpt_ctx;
@@ -291,17 +295,30 @@ int bdpt_set_scene(bdpt_ctx* ctx, const bdpt_scene_desc* scene);
 int bdpt_get_bvh_info(const bdpt_ctx* ctx, bdpt_bvh_info* out);
 int bdpt_set_camera(bdpt_ctx* ctx, const bdpt_camera* cam);
 
-/* Host-only (no GPU, no context): run the acceleration-structure builder on a scene and check
- * its invariants — every triangle in exactly one leaf, every child box contains its subtree,
- * depth within the traversal stack.  Returns BDPT_OK and fills *out, or BDPT_E_INVALID with the
- * first violated invariant in msg (msgCap bytes, may be NULL). */
+/* Host-only (no GPU, no context): run the acceleration-structure builder on a scene (geometry only: every triangle
+ * opaque) and check its invariants — every triangle referenced, every leaf entry in exactly one leaf, the pieces of
+ * a split triangle covering it, every child box containing its subtree's pieces, depth within the traversal stack.
+ * Returns BDPT_OK and fills *out, or BDPT_E_INVALID with the first violated invariant in msg (msgCap bytes, may be NULL). */
 int bdpt_bvh_build_check(const bdpt_scene_desc* scene, bdpt_bvh_info* out, char* msg, uint32_t msgCap);
 
 /* Host-only test hook: build with `threads` host threads (0 = default: BDPT_BUILD_THREADS, else the CPUs this
  * process may use) and return a 64-bit FNV-1a hash of the node array, the leaf-ordered triangle list and the
- * summary; the tree must not depend on the thread count.  out_info may be NULL (its `reserved` field returns the
- * default thread count). */
+ * summary; the tree must not depend on the thread count.  A scene with materials is built exactly as bdpt_set_scene
+ * builds it (traversal flags, alpha classification, pre-splitting), one without as plain geometry.  out_info may be
+ * NULL (its `reserved` field returns the default thread count). */
 int bdpt_bvh_build_hash(const bdpt_scene_desc* scene, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info);
+
+/* Host-only test hooks: the acceleration structure exactly as bdpt_set_scene builds it (traversal flags, alpha
+ * classification, spatial pre-splitting; negative budgets = build defaults, classify = 0 keeps the reference's
+ * per-material opacity) walked on the CPU with the device's query semantics (bdpt_test_trace), or — brute != 0 —
+ * the linear scan over every input triangle with the reference's per-material flags, which defines the right
+ * answer.  rays: n x 8 floats (origin, direction, tmin, tmax); out_visits[2] = interior-node visits and triangle
+ * tests summed over the rays (tree walk only).  The scene description must outlive the handle. */
+void* bdpt_host_bvh_create(const bdpt_scene_desc* scene, int threads, float splitBudget, float splitBudgetAlpha, int classify,
+                           bdpt_bvh_info* out_info);
+void bdpt_host_bvh_destroy(void* handle);
+int bdpt_host_bvh_trace(void* handle, const float* rays, uint32_t n, int mode, int brute, int threads, int32_t* out_prim,
+                        float* out_tuv, uint64_t* out_visits);
 
 /* Camera::calculateCameraParameters (Graphics/Camera/Camera.cpp:129-136) with
  * fovY = focalLengthToFovY (Utils/Math/FalcorMath.h:148-151).  Host-only helper. */

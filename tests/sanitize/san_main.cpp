@@ -1,6 +1,7 @@
 // CPU-only sanitizer run (AddressSanitizer + UBSan; GPU sanitizers are not available on the pool): the host-side
 // C++ that never touches the device — scene factories, scene loader, BVH builder — and the oracle, driven the way
 // the tests drive them.  Built and run by tests/test_sanitizers.py.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -84,6 +85,48 @@ int main(int argc, char** argv) {
     if (which < 2) {
       rc |= renderWith(d, cam, 36, 24, 4, 0, 0);
       rc |= renderWith(d, cam, 24, 16, 8, 1, BDPT_PARAM_MIS_POWER);
+    }
+    bdpt_scene_destroy(sc);
+  }
+  {  // the full scene build (traversal flags, alpha classification, pre-splitting with clipped pieces) and the host trace hook
+    bdpt_scene* sc = bdpt_scene_create_courtyard(2, 9000, 0.6f);
+    bdpt_scene_desc d{};
+    rc |= bdpt_scene_get_desc(sc, &d);
+    for (int variant = 0; variant < 3; variant++) {
+      bdpt_bvh_info info{};
+      void* h = bdpt_host_bvh_create(&d, 2, variant == 0 ? 0.0f : (variant == 1 ? -1.0f : 2.0f), variant == 0 ? 0.0f : (variant == 1 ? -1.0f : 12.0f),
+                                     variant != 0, &info);
+      if (!h) {
+        rc |= 1;
+        continue;
+      }
+      std::vector<float> rays;
+      uint32_t st = 99u;
+      auto u01 = [&]() { return (float)((st = st * 1664525u + 1013904223u) >> 8) / 16777216.0f; };
+      for (int i = 0; i < 600; i++) {
+        const float o[3] = {-13.0f + 26.0f * u01(), 0.2f + 7.0f * u01(), -3.0f + 6.0f * u01()};
+        float dd[3] = {u01() - 0.5f, u01() - 0.5f, u01() - 0.5f};
+        const float l = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]) + 1e-9f;
+        rays.insert(rays.end(), {o[0], o[1], o[2], dd[0] / l, dd[1] / l, dd[2] / l, 1e-4f, 1e38f});
+      }
+      std::vector<int32_t> prim(600), primScan(600);
+      std::vector<float> tuv(1800), tuvScan(1800);
+      uint64_t visits[2] = {0, 0};
+      for (int mode = 0; mode < 3; mode++) {
+        rc |= bdpt_host_bvh_trace(h, rays.data(), 600, mode, 0, 2, prim.data(), tuv.data(), visits);
+        rc |= bdpt_host_bvh_trace(h, rays.data(), 600, mode, 1, 2, primScan.data(), tuvScan.data(), nullptr);
+        for (int i = 0; i < 600; i++)
+          if ((mode == 2 ? (prim[i] >= 0) != (primScan[i] >= 0) : prim[i] != primScan[i]) || tuv[(size_t)i * 3] != tuvScan[(size_t)i * 3]) rc |= 1;
+      }
+      std::printf("courtyard variant %d: %u references for %u triangles, %u dropped, %u always pass; %llu node visits\n", variant, info.numReferences,
+                  info.numTriangles, info.numDropped, info.numAlwaysPass, (unsigned long long)visits[0]);
+      bdpt_host_bvh_destroy(h);
+    }
+    char msg[256] = {0};
+    bdpt_bvh_info info{};
+    if (bdpt_bvh_build_check(&d, &info, msg, sizeof(msg)) != BDPT_OK) {
+      std::printf("build check: %s\n", msg);
+      rc |= 1;
     }
     bdpt_scene_destroy(sc);
   }

@@ -15,7 +15,7 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     srcs = [os.path.join(ROOT, "tests", "sanitize", "san_main.cpp"),
             os.path.join(pk, "host", "Scene.cpp"), os.path.join(pk, "host", "Atrium.cpp"), os.path.join(pk, "host", "SceneLoader.cpp"),
             os.path.join(pk, "host", "ImageDecode.cpp"),
-            os.path.join(pk, "csrc", "bvh_build.cpp"),
+            os.path.join(pk, "csrc", "bvh_build.cpp"), os.path.join(pk, "csrc", "alpha_clip.cpp"), os.path.join(pk, "csrc", "scene_bvh.cpp"),
             os.path.join(ROOT, "oracle", "bdpt_oracle.cpp"), os.path.join(ROOT, "oracle", "bmfr_oracle.cpp")]
     exe = str(tmp_path / "san_main")
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",

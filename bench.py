@@ -4,10 +4,16 @@
 One "step" = one pipeline frame of the hot path (G-buffer pass + BDPT pass + accumulation) at
 1 spp over the whole 1920x1080 image, depth 8, on the Sponza stand-in scene (seeded procedural
 atrium, 262,144 triangles, textured GGX — the real Sponza asset is in neither the reference
-tree nor this image).  With N GPUs the image is tiled into N row bands (scene
-replicated); each rank renders its band, the fixed-point splat buffers are summed with one RCCL
-reduce-scatter per frame, and each rank resolves + accumulates its band.  value = rays actually
-traced by all ranks / max-over-ranks wall time of the K timed steps.
+tree nor this image).  With N GPUs the image is dealt to the ranks in interleaved
+stripes of rows (scene replicated); each rank renders its stripes, the fixed-point splat buffers
+are summed with one RCCL reduce-scatter per frame, and each rank resolves + accumulates its rows.
+value = rays actually traced by all ranks / max-over-ranks wall time of the K timed steps.
+
+The timed loop never synchronises with the host: frames are handed to `frames_in_flight` contexts
+round-robin (three by default, also at N = 1: the tail of one frame's persistent launches overlaps
+the next frame's walks), the running mean is applied in frame order through an event chain, and the
+ray tallies add up on the device.  Stage times, visit counts and the roofline block come from
+untimed frames run ALONE before the timed region (their HIP events see one frame's kernels only).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene atrium|cornell] ...
 For N > 1 launch with torch.distributed.run (one rank per GPU).
@@ -24,7 +30,18 @@ sys.path.insert(0, ROOT)
 
 RAY_KEYS = ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; its measured float4 copy rate is 6290 GB/s)
-PROFILE_ROUND = "r2"   # profiles/<round>/hbm_traffic_pmc.json holds the PMC traffic the roofline block quotes
+# Rates the traversal kernels are priced against (MI355X_MICROARCH.md "Indexed rows: gather", chip-wide; the low ends):
+L2_GATHER_GBS = 16800.0         # rows served by the XCDs' L2s
+MALL_GATHER_GBS = 8600.0        # uniformly random rows served by the Infinity Cache
+# Measured here (tools/microbench, profiles/r2/microbench/): a divergent wave costs the vector-memory address unit one
+# clock per lane and 16-byte load — 1.03 lane-loads per clock per CU, flat from 8 to 32 waves per CU; VALU issue on one
+# SIMD: v_fma / v_mul / v_add / v_sub_f32, v_add_u32, v_and, v_mov 2.2-2.7 clk per wave-instruction, everything else
+# the kernels use (v_min / v_max / v_max3 / v_cvt_f32_ubyte / v_cmp / v_cndmask / v_lshl_add / v_bfi) 4.2-4.4
+LANE_LOADS_PER_CLK_PER_CU = 1.03
+VALU_CLK_FAST, VALU_CLK_SLOW = 2.4, 4.3
+SHADER_CLK_HZ = 2.4e9
+NUM_CUS, NUM_SIMDS = 256, 1024
+PROFILE_ROUND = "r3"   # profiles/<round>/roofline_pmc.json holds the PMC counts the roofline block quotes
 
 
 SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 48  # algorithmic bytes per interior-node / triangle visit
@@ -53,100 +70,94 @@ def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
     return b
 
 
-def load_sq_summary(scene, W, H, D, world):
-    """Per-kernel SQ / cache counter summary of the committed PMC passes (tools/pmc_summary.py): lane utilisation,
-    VALU busy fraction per SIMD, L2 hit rate.  Decides what `bound` says."""
-    sj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "sq_summary.json")
-    if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(sj)):
+def load_pmc(scene, W, H, D, world):
+    """Per-kernel, per-frame hardware counts of the committed rocprofv3 --pmc passes of this command
+    (tools/collect_profiles.sh -> tools/roofline_pmc.py): {kernel base name: {counter: value per frame}}."""
+    pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "roofline_pmc.json")
+    if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(pj)):
         return {}
-    with open(sj) as f:
-        raw = json.load(f)["kernels"]
-    out = {}
-    for k, v in raw.items():
-        name = k.split("<")[0]
-        if name not in out or v.get("waves", 0) > out[name].get("waves", 0):  # the timed variant (no visit counters) has more launches
-            out[name] = v
-    return out
-
-
-def load_traffic(scene, W, H, D, world):
-    """HBM-side bytes per frame per kernel from the committed rocprofv3 PMC passes of this very command
-    (separate FETCH_SIZE and WRITE_SIZE runs; profiles/README.md).  FETCH_SIZE is doubled here per
-    MI355X_MICROARCH.md §HBM (gfx950 counts 64-B requests as 32 B; calibrated on accumulate_kernel)."""
-    tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "hbm_traffic_pmc.json")
-    if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(tj)):
-        return {}
-    with open(tj) as f:
+    with open(pj) as f:
         raw = json.load(f)
     out = {}
-    for k, v in raw.items():
-        if isinstance(v, dict) and "fetch_bytes_per_frame" in v:
-            name = k.replace("void bdpt::", "").split("<")[0]
-            out[name] = out.get(name, 0) + int(2.0 * v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"])
+    for k, v in raw["kernels"].items():
+        name = k.split("<")[0]
+        if name not in out or v.get("dispatches_per_frame", 0) > out[name].get("dispatches_per_frame", 0):
+            out[name] = v  # the timed variant (no visit counters) has more launches than the one statistics frame
+    out["_meta"] = {k: v for k, v in raw.items() if k != "kernels"}
     return out
 
 
 class TileRenderer:
-    """This rank's share of the frame loop: one context for a whole frame, or — on the tiled path — several
-    contexts over the same tile (interleaved stripes of rows), each with one frame in flight on its own stream."""
+    """This rank's share of the frame loop: `inflight` contexts over the same tile (interleaved stripes of rows; with
+    one rank the whole frame), each with one frame in flight on its own stream."""
 
-    def __init__(self, pkg, scene, W, H, D, mat, local_rank, world, rank, dist, tiled, inflight=0):
+    def __init__(self, pkg, scene, W, H, D, mat, local_rank, world, rank, dist, inflight=3):
         import torch
-        self.torch, self.pkg, self.dist, self.tiled = torch, pkg, dist, tiled
+        self.torch, self.pkg, self.dist = torch, pkg, dist
         self.W, self.H, self.world, self.rank = W, H, world, rank
         self.dev = torch.device("cuda", local_rank)
-        # Frames in flight: a tile leaves the chip underfilled (DESIGN.md section 5), so the tiled path keeps
-        # several frames going on separate streams/contexts; frames stay independent until the running mean,
-        # which is applied in frame order.  One GPU rendering the whole frame is already full: one frame there.
-        self.inflight = (inflight if inflight > 0 else 3) if tiled else 1
-        # tile = this rank's stripes (pkg.tiling); the untiled N = 1 path renders the frame as one band
-        stripes = (pkg.tiling.stripe_rows(H, world), world, rank) if tiled else None
+        # Frames in flight: the persistent launches of one frame ramp up and drain (a sub-path is up to D rays in
+        # series), and a tile leaves the chip underfilled (DESIGN.md section 5), so several frames are kept going on
+        # separate streams/contexts; frames stay independent until the running mean, which is applied in frame order.
+        self.inflight = max(1, int(inflight))
+        stripes = (pkg.tiling.stripe_rows(H, world), world, rank)
         self.pipes = [pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, stripes=stripes,
-                                        accum_limit=10000) for _ in range(self.inflight)]
+                                        accum_limit=1 << 30) for _ in range(self.inflight)]
         self.pipe = self.pipes[0]
         self.ctx = self.pipe.ctx
         self.rows = self.pipe.rows
         self.num_pixels = sum(b - a for a, b in self.rows) * W
         self.state = {"frame": 0, "accum": 0, "accum_event": None}
-        if tiled:
-            info = self.ctx.tile_info()
-            self.exchange_bytes = int(info.splatU64) * 8  # what one rank hands to the reduce-scatter per frame
-            self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.inflight)]
-            self.splat_full = [torch.zeros(info.splatU64, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
-            self.splat_mine = [torch.zeros(info.chunkU64, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
-            for pp, sf in zip(self.pipes, self.splat_full):
-                pp.ctx.set_splat_buffer(C.c_void_p(sf.data_ptr()), sf.numel())
+        info = self.ctx.tile_info()
+        self.exchange_bytes = int(info.splatU64) * 8  # what one rank hands to the reduce-scatter per frame
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.inflight)]
+        self.splat_full = [torch.zeros(info.splatU64, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
+        # without a process group nothing is exchanged: this rank's own chunk is resolved where it is (one rank: the frame)
+        self.splat_mine = [self.splat_full[i][rank * info.chunkU64:(rank + 1) * info.chunkU64] if dist is None else
+                           torch.zeros(info.chunkU64, dtype=torch.int64, device=self.dev) for i in range(self.inflight)]
+        for pp, sf in zip(self.pipes, self.splat_full):
+            pp.ctx.set_splat_buffer(C.c_void_p(sf.data_ptr()), sf.numel())
         self.last_frame = self.pipe.last_frame  # the running mean is shared by all frames in flight
+        self.exchange_events = None               # set by time_exchange(): [(tail0, tail1, ex0, ex1)] of solo frames
 
     def step(self, flags=0):
-        """One pipeline frame on this rank's tile."""
+        """One pipeline frame on this rank's tile; returns the context that took it."""
         torch, pkg, state = self.torch, self.pkg, self.state
         f = state["frame"]
         state["frame"] += 1
-        if not self.tiled:
-            self.pipe.render_frame(accumulate=True, extra_flags=flags)
-            return
         i = f % self.inflight
         pp, s = self.pipes[i], self.streams[i]
         pp.gbuffer_frame, pp.bdpt_frame = 0xdeadbeef + f, 0x1337 + f
+        timing = self.exchange_events is not None
         with torch.cuda.stream(s):
             # phase 1: everything that writes the splat buffer; then the exchange starts on RCCL's stream while
             # phase 2 (zero-valued connection rounds) runs on ours
             _, p = pp.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
-            work = pkg.tiling.exchange_splats_async(self.dist, self.splat_full[i], self.splat_mine[i])
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timing else None
+            if timing:
+                ev[2].record(s)
+            work = pkg.tiling.exchange_splats_async(self.dist, self.splat_full[i], self.splat_mine[i]) if self.dist is not None else None
             st = C.c_void_p(s.cuda_stream)
+            if timing:
+                ev[0].record(s)
             pp.ctx.execute_tail(p, pp.gb, C.c_void_p(pp.output.data_ptr()), st)
+            if timing:
+                ev[1].record(s)
             if work is not None:
                 work.wait()
+            if timing:
+                ev[3].record(s)
+                self.exchange_events.append(ev)
             pp.ctx.resolve_tile(C.c_void_p(self.splat_mine[i].data_ptr()), C.c_void_p(pp.output.data_ptr()), st)
             if state["accum_event"] is not None:
                 s.wait_event(state["accum_event"])  # running mean in frame order
             n = state["accum"]
             state["accum"] += 1
             pp.ctx.accumulate_tile(C.c_void_p(self.last_frame.data_ptr()), C.c_void_p(pp.output.data_ptr()), n, pp.accum_limit, st)
-            ev = torch.cuda.Event()
-            ev.record(s)
-            state["accum_event"] = ev
+            done = torch.cuda.Event()
+            done.record(s)
+            state["accum_event"] = done
+        return pp.ctx
 
     def barrier(self):
         self.torch.cuda.synchronize(self.dev)
@@ -156,31 +167,111 @@ class TileRenderer:
 
     def rewind(self, frame, accum):
         self.state["frame"], self.state["accum"] = frame, accum
-        if not self.tiled:
-            self.pipe.gbuffer_frame, self.pipe.bdpt_frame, self.pipe.accum_count = 0xdeadbeef + frame, 0x1337 + frame, accum
 
     def close(self):
         for pp in self.pipes:
             pp.close()
 
 
+def solo_frames(R, pkg, torch, n, flags=0):
+    """n frames run alone (host-synchronised after each) with stage timing on: summed stage times, ray tallies per
+    stage, and the last frame's counters."""
+    stage_ms, rays, last = {}, {}, None
+    for pp in R.pipes:
+        pp.ctx.enable_stage_timing(True)
+    for _ in range(n):
+        cx = R.step(flags)
+        torch.cuda.synchronize(R.dev)
+        for name, ms in cx.stage_times():
+            stage_ms[name] = stage_ms.get(name, 0.0) + ms
+        last = cx.counters().as_dict()
+        for k in RAY_KEYS:
+            rays[k] = rays.get(k, 0) + last[k]
+    for pp in R.pipes:
+        pp.ctx.enable_stage_timing(False)
+    return stage_ms, rays, last
+
+
+def timed_frames(R, pkg, K):
+    """K frames, no host synchronisation inside; returns (seconds, rays traced by this rank)."""
+    R.barrier()
+    first = R.state["frame"]
+    t0 = time.perf_counter()
+    for k in range(K):
+        R.step(pkg.abi.PARAM_KEEP_COUNTERS if k >= R.inflight else 0)  # first use of each context zeroes its tallies
+    R.barrier()
+    dt = time.perf_counter() - t0
+    rays = 0
+    for i, pp in enumerate(R.pipes):
+        used = sum(1 for k in range(K) if (first + k) % R.inflight == i)  # frames this context rendered
+        if used:
+            c = pp.ctx.counters().as_dict()
+            rays += sum(c[k] for k in RAY_KEYS) + used * R.num_pixels  # + one primary ray per pixel
+    return dt, rays
+
+
+def other_config(pkg, torch, name, scene, W, H, D, mat, frames=3):
+    """One more BASELINE shape on this GPU, one frame in flight: ms per frame, Mrays/s, visits per ray, stage times."""
+    t0 = time.time()
+    pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, accum_limit=1 << 30)
+    torch.cuda.synchronize()
+    setup = time.time() - t0
+    pipe.render_frame(accumulate=True)
+    torch.cuda.synchronize()
+    pipe.ctx.enable_stage_timing(True)
+    agg = {}
+    pipe.render_frame(accumulate=True)
+    for k, v in pipe.ctx.stage_times():
+        agg[k] = v
+    pipe.ctx.enable_stage_timing(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        pipe.render_frame(accumulate=True, extra_flags=pkg.abi.PARAM_KEEP_COUNTERS if k else 0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    c = pipe.ctx.counters().as_dict()
+    rays = (sum(c[k] for k in RAY_KEYS) + frames * W * H) / frames
+    pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
+    torch.cuda.synchronize()
+    s = pipe.ctx.counters().as_dict()
+    shadow = max(1, s["raysNee"] + s["raysSplat"] + s["raysConnect"])
+    closest = max(1, s["raysEyeExtend"] + s["raysLightExtend"])
+    info = pipe.ctx.bvh_info()
+    free, total = torch.cuda.mem_get_info()
+    out = {"workload": name, "resolution": [W, H], "max_depth": D, "mat_index": mat, "frames_timed": frames, "frames_in_flight": 1,
+           "ms_per_frame": round(dt * 1e3, 3), "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
+           "visits_per_ray": {"closest_nodes": round(s["nodeVisitsClosest"] / closest, 2), "closest_tris": round(s["triTestsClosest"] / closest, 2),
+                              "shadow_nodes": round(s["nodeVisitsShadow"] / shadow, 2), "shadow_tris": round(s["triTestsShadow"] / shadow, 2)},
+           "stage_ms": {k: round(v, 2) for k, v in agg.items() if v >= 0.05},
+           "bvh": {"nodes": info.numNodes, "references": info.numReferences, "triangles": info.numTriangles,
+                   "alpha_mode_triangles": info.numAlphaMode, "always_pass": info.numAlwaysPass, "dropped": info.numDropped},
+           "setup_s": round(setup, 2), "device_memory_gb": round((total - free) / 2 ** 30, 1)}
+    pipe.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mat", type=int, default=None, help="0 GGX (default for atrium), 1 Lambertian (default for cornell)")
     ap.add_argument("--triangles", type=int, default=262144)
-    ap.add_argument("--inflight", type=int, default=0, help="frames in flight on the tiled path (0 = auto: 3 tiled, 1 otherwise)")
-    ap.add_argument("--no-pipelined-pass", dest="pipelined_pass", action="store_false",
-                    help="skip the informational three-frames-in-flight pass at N=1")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (contexts / streams per rank)")
+    ap.add_argument("--no-single-pass", dest="single_pass", action="store_false",
+                    help="skip the informational one-frame-in-flight pass at N=1")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip the other BASELINE shapes (configs 2, 4 and 5 on this one GPU) at N=1")
     ap.add_argument("--dump-frames", type=int, default=0, help="render this many frames from a fresh state, write the "
                     "accumulated image of all ranks to --dump-path (rank 0) and exit: lets runs with different N be compared")
     ap.add_argument("--dump-path", default="bench_image.npy")
+    ap.add_argument("--plain-loop", action="store_true", help="with --dump-frames at N=1: the reference's plain sequence instead "
+                    "(one whole-frame context, G-buffer pass -> BDPT pass -> accumulation pass, one frame at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -193,13 +284,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch N > 1 with torch.distributed.run, one rank per GPU "
+                         "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...)" % (args.gpus, world))
     dist = None
-    # BDPT_BENCH_TILED_AT_1=1 under torch.distributed.run makes a single rank take the tiled path with its RCCL
-    # exchange, so the N>1 code can be exercised on a one-GPU box; otherwise N=1 runs without any collective.
-    tiled = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("BDPT_BENCH_TILED_AT_1", "0") == "1")
-    if tiled:
+    # BDPT_BENCH_TILED_AT_1=1 under torch.distributed.run makes a single rank go through the RCCL exchange too, so the
+    # N>1 code can be exercised on a one-GPU box; otherwise N=1 runs without any collective.
+    use_dist = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("BDPT_BENCH_TILED_AT_1", "0") == "1")
+    backend = None
+    if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -207,144 +299,109 @@ def main():
         # BDPT_BENCH_BACKEND=gloo + BDPT_BENCH_DEVICE=0 rehearse several ranks on a one-GPU box (the exchange then goes
         # through gloo instead of RCCL; everything else is the N>1 path)
         backend = os.environ.get("BDPT_BENCH_BACKEND", "nccl")
-        if "BDPT_BENCH_DEVICE" in os.environ:
+        shared_device = "BDPT_BENCH_DEVICE" in os.environ
+        if shared_device:
             local_rank = int(os.environ["BDPT_BENCH_DEVICE"])
+        elif world > 1 and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: %d ranks but %d visible GPUs: every rank needs a GPU of its own "
+                             "(BDPT_BENCH_DEVICE=<ordinal> with BDPT_BENCH_BACKEND=gloo rehearses on a shared one)" % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render pass has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if use_dist and world > 1 and "BDPT_BENCH_DEVICE" not in os.environ:
+        # no two ranks on one device: gather (hostname-free) PCI bus ids
+        mine = torch.cuda.get_device_properties(dev)
+        ident = "%s/%s" % (getattr(mine, "pci_bus_id", local_rank), getattr(mine, "uuid", local_rank))
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len(set(idents)) != world:
+            raise SystemExit("bench.py: two ranks share a device (%s)" % idents)
 
     W, H, D = args.width, args.height, args.depth
     mat = args.mat if args.mat is not None else (0 if args.scene == "atrium" else 1)
     scene = pkg.Scene.atrium(1, args.triangles) if args.scene == "atrium" else pkg.Scene.cornell()
 
-    R = TileRenderer(pkg, scene, W, H, D, mat, local_rank, world, rank, dist, tiled, args.inflight)
-    pipes, pipe, ctx, inflight, state = R.pipes, R.pipe, R.ctx, R.inflight, R.state
+    if args.dump_frames > 0 and args.plain_loop:
+        if world != 1 or dist is not None:
+            raise SystemExit("--plain-loop is the single-GPU reference sequence")
+        pp = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, accum_limit=1 << 30)
+        for _ in range(args.dump_frames):
+            pp.render_frame(accumulate=True)
+        torch.cuda.synchronize(dev)
+        import numpy as np
+        np.save(args.dump_path, pp.last_frame.cpu().numpy())
+        print(json.dumps({"dumped": args.dump_path, "frames": args.dump_frames, "n_gpus": 1, "frames_in_flight": 1, "tiled": False,
+                          "backend": None}), flush=True)
+        pp.close()
+        return
+
+    R = TileRenderer(pkg, scene, W, H, D, mat, local_rank, world, rank, dist, args.inflight)
+    pipe, ctx, inflight = R.pipe, R.ctx, R.inflight
     n_pix_tile = R.num_pixels
-    step, barrier, rewind = R.step, R.barrier, R.rewind
     info = ctx.bvh_info()
-    dev = R.dev
 
     if args.dump_frames > 0:
         for _ in range(args.dump_frames):
-            step()
-        barrier()
-        full = pkg.tiling.gather_frame(dist, torch, R.last_frame, H, world, rank) if tiled else R.last_frame
+            R.step()
+        R.barrier()
+        full = pkg.tiling.gather_frame(dist, torch, R.last_frame, H, world, rank) if dist is not None else R.last_frame
         if rank == 0:
             import numpy as np
             np.save(args.dump_path, full.cpu().numpy())
             print(json.dumps({"dumped": args.dump_path, "frames": args.dump_frames, "n_gpus": world, "frames_in_flight": inflight,
-                              "tiled": bool(tiled), "backend": dist.get_backend() if dist is not None else None}), flush=True)
+                              "tiled": True, "backend": dist.get_backend() if dist is not None else None}), flush=True)
         R.close()
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # ---- untimed: warm-up, then node/triangle visit statistics of the first timed frame (deterministic per frame)
+    # ---- untimed: warm-up, then frames run alone: node / triangle visit statistics (deterministic per frame), stage
+    # times from HIP events on the launch stream, exchange timing; the sequence is rewound afterwards
     for _ in range(args.warmup):
-        step()
-    barrier()
-    mark = (state["frame"], state["accum"] if tiled else pipe.accum_count)
-    step(pkg.abi.PARAM_COUNTERS)
-    torch.cuda.synchronize(dev)
-    stat = pipes[mark[0] % inflight].ctx.counters().as_dict()
-    rewind(*mark)
-    barrier()
+        R.step()
+    R.barrier()
+    mark = (R.state["frame"], R.state["accum"])
+    _, _, stat = solo_frames(R, pkg, torch, 1, pkg.abi.PARAM_COUNTERS)
+    R.rewind(*mark)
+    stage_frames = 3
+    R.exchange_events = []
+    stage_ms, per_stage_rays, _ = solo_frames(R, pkg, torch, stage_frames)
+    ex_ev, R.exchange_events = R.exchange_events, None
+    tail_ms = sum(e[0].elapsed_time(e[1]) for e in ex_ev) / max(1, len(ex_ev))
+    ex_plus_tail_ms = sum(e[2].elapsed_time(e[3]) for e in ex_ev) / max(1, len(ex_ev))
+    R.rewind(*mark)
 
-    rays_total = 0
-    stage_ms = {}
-    per_stage_rays = {}
-    stage_frames = args.steps
-    if inflight == 1:
-        # ---- timed region: exactly K steps, stage times from HIP events on the launch stream
-        ctx.enable_stage_timing(True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            for name, ms in ctx.stage_times():  # synchronises on this frame's last event
-                stage_ms[name] = stage_ms.get(name, 0.0) + ms
-            c = ctx.counters().as_dict()
-            rays_total += sum(c[k] for k in ("raysPrimary",) + RAY_KEYS)
-            for k in RAY_KEYS:
-                per_stage_rays[k] = per_stage_rays.get(k, 0) + c[k]
-        barrier()
-        elapsed = time.perf_counter() - t0
-        ctx.enable_stage_timing(False)
-    else:
-        # ---- stage times of the dominant kernel: two untimed frames run alone (with frames in flight the HIP events
-        # of one frame would also span the other frames' kernels)
-        stage_frames = 2
-        for pp in pipes:
-            pp.ctx.enable_stage_timing(True)
-        for _ in range(stage_frames):
-            f = state["frame"]
-            step()
-            torch.cuda.synchronize(dev)
-            cx = pipes[f % inflight].ctx
-            for name, ms in cx.stage_times():
-                stage_ms[name] = stage_ms.get(name, 0.0) + ms
-            c = cx.counters().as_dict()
-            for k in RAY_KEYS:
-                per_stage_rays[k] = per_stage_rays.get(k, 0) + c[k]
-        for pp in pipes:
-            pp.ctx.enable_stage_timing(False)
-        rewind(*mark)
-        barrier()
-        # ---- timed region: exactly K steps, no host synchronisation inside; ray tallies add up on the device
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(pkg.abi.PARAM_KEEP_COUNTERS if k >= inflight else 0)  # first use of each context zeroes its tallies
-        barrier()
-        elapsed = time.perf_counter() - t0
-        for i, pp in enumerate(pipes):
-            used = sum(1 for k in range(args.steps) if (mark[0] + k) % inflight == i)  # frames this context rendered
-            if used == 0:
-                continue
-            c = pp.ctx.counters().as_dict()
-            rays_total += sum(c[k] for k in RAY_KEYS) + used * n_pix_tile
-
-    # ---- informational second pass at N = 1: the same K frames with three frames in flight (the tiled loop on one
-    # band = the whole frame).  `value` stays the one-frame-in-flight figure the roofline durations belong to.
-    pipelined = None
-    if world == 1 and not tiled and args.pipelined_pass:
-        P3 = TileRenderer(pkg, scene, W, H, D, mat, local_rank, 1, 0, None, True, 3)
-        for _ in range(3):
-            P3.step()
-        P3.barrier()
-        P3.rewind(mark[0], mark[0])
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            P3.step(pkg.abi.PARAM_KEEP_COUNTERS if k >= P3.inflight else 0)
-        P3.barrier()
-        dt3 = time.perf_counter() - t1
-        rays3 = 0
-        for i, pp in enumerate(P3.pipes):
-            used = sum(1 for k in range(args.steps) if (mark[0] + k) % P3.inflight == i)
-            if used:
-                c = pp.ctx.counters().as_dict()
-                rays3 += sum(c[k] for k in RAY_KEYS) + used * H * W
-        pipelined = {"frames_in_flight": 3, "value": round(rays3 / dt3 / 1e6, 2), "unit": "Mrays/s",
-                     "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-                     "note": "same frames, three contexts on three streams, running mean in frame order; informational"}
-        P3.close()
+    # ---- timed region: exactly K steps, no host synchronisation inside
+    elapsed, rays_total = timed_frames(R, pkg, args.steps)
 
     t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device=dev)
+    per_rank = None
     if dist is not None:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, rays_all = float(tmax[0]), float(tsum[1])
+        gdev = dev if backend == "nccl" else torch.device("cpu")
+        tg = t.to(gdev)
+        allv = [torch.zeros_like(tg) for _ in range(world)]
+        dist.all_gather(allv, tg)
+        elapsed_max = max(float(v[0]) for v in allv)
+        rays_all = sum(float(v[1]) for v in allv)
+        rows_all = [None] * world
+        dist.all_gather_object(rows_all, n_pix_tile // W)
+        per_rank = {"ms_per_step": [round(float(v[0]) / args.steps * 1e3, 3) for v in allv],
+                    "ms_per_step_min": round(min(float(v[0]) for v in allv) / args.steps * 1e3, 3),
+                    "ms_per_step_max": round(elapsed_max / args.steps * 1e3, 3),
+                    "mrays": [round(float(v[1]) / float(v[0]) / 1e6, 1) for v in allv], "rows": rows_all}
     else:
         elapsed_max, rays_all = elapsed, float(rays_total)
 
+    out = None
     if rank == 0:
         K = args.steps
         mrays = rays_all / elapsed_max / 1e6
@@ -357,8 +414,6 @@ def main():
         # ---- roofline per kernel and for the whole frame.  Algorithmic bytes from the device tallies
         # of one frame of the same sequence; durations = HIP events on the launch stream around each kernel's launches
         # (bdpt_get_stage_times), summed over the frame, averaged over the frames named in stage_timing.
-        # SURVEY's per-unit figures (64 B per interior-node visit, 48 B per leaf triangle) whatever the build stores: the
-        # records of this build are 48 B each (config.bvh.node_bytes), so a node visit FETCHES 48 B and is COSTED at 64
         alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, SURVEY_NODE_BYTES, SURVEY_TRI_BYTES)
         ms = {k: v / stage_frames for k, v in stage_ms.items()}
         kernel_ms = {
@@ -369,29 +424,71 @@ def main():
             "per_pixel_kernels": ms.get("clear", 0.0) + ms.get("init_paths", 0.0) + ms.get("gather", 0.0) +
                                  ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0),
         }
-        traffic = load_traffic(args.scene, W, H, D, world)
-        sq = load_sq_summary(args.scene, W, H, D, world)
-        traffic_of = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
-                      "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
-                      "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
+        pmc = load_pmc(args.scene, W, H, D, world)
+        members = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
+                   "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
+                   "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
+        # bytes the build really loads per unit: 48-byte records for nodes and triangles (bvh.h), a 28-byte ray + 1
+        # visibility byte per any-hit ray, origin + direction + 16-byte hit record per closest-hit ray, SURVEY's 388 B per shade
+        closest_rays = stat["raysEyeExtend"] + stat["raysLightExtend"]
+        fetched = {"walk_kernel": 44 * closest_rays + info.nodeBytes * stat["nodeVisitsClosest"] + info.triBytes * stat["triTestsClosest"] + 388 * closest_rays,
+                   "trace_shadow_kernel": 29 * n_shadow + info.nodeBytes * stat["nodeVisitsShadow"] + info.triBytes * stat["triTestsShadow"]}
 
         def roof(name):
             t_ms, by = kernel_ms[name], alg[name]
-            ach = by / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
-            tr = sum(traffic.get(k, 0) for k in traffic_of[name]) if traffic else None
+            sec = t_ms * 1e-3
+            ach = by / sec / 1e9 if sec > 0 else 0.0
             r = {"ms_per_frame": round(t_ms, 3), "bytes_per_frame": int(by), "achieved": round(ach, 1),
-                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr}
-            if tr:
-                r["traffic_over_algorithmic"] = round(tr / by, 3)
-            c = sq.get(traffic_of[name][0]) if len(traffic_of[name]) == 1 else None
-            if c and "valu_busy" in c:
-                r["counters"] = {k: c[k] for k in ("lane_util", "valu_busy", "wait_any", "l2_hit", "waves_per_simd") if k in c}
-                # what the counters say: each SIMD's VALU is busy most of the time although only a third of the lanes work
-                # per instruction, and the fabric side moves a fraction of the algorithmic bytes (the BVH lives in L2 / MALL):
-                # bound by VALU issue under lane divergence, not by HBM
-                r["bound"] = "valu" if c["valu_busy"] >= 0.7 else ("hbm" if tr and tr >= 0.5 * by else "latency")
-            elif tr:
-                r["bound"] = "hbm" if tr >= 0.5 * by else "latency"
+                 "frac": round(ach / HBM_PEAK_GBS, 4)}
+            if r["frac"] > 1.0:
+                r["frac_note"] = "above 1: cache-served (algorithmic bytes exceed what leaves the chip's caches; see fractions)"
+            have = [pmc[k] for k in members[name] if k in pmc]
+            if not have or sec <= 0:
+                r["traffic"] = None
+                return r
+
+            def tot(c):
+                return sum(p.get(c, 0.0) for p in have)
+
+            # HBM / fabric side: 2 x FETCH_SIZE + WRITE_SIZE.  FETCH_SIZE tallies 64 B per 128-byte request on gfx950
+            # (MI355X_MICROARCH.md, measured there on coalesced streams); tools/microbench/fetch_calib.hip shows the same
+            # for 16-byte gathers (profiles/r3/fetch_calib.txt), so the factor applies to the traversal kernels too.
+            fetch_factor = pmc["_meta"].get("fetch_factor", {}).get(name, 2.0)
+            traffic = fetch_factor * tot("FETCH_SIZE_bytes") + tot("WRITE_SIZE_bytes")
+            r["traffic"] = int(traffic)
+            r["traffic_over_algorithmic"] = round(traffic / by, 3)
+            fr = {"hbm": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 3)}
+            if name in fetched:
+                fb = fetched[name]
+                r["fetched"] = {"bytes_per_frame": int(fb), "rate_gbs": round(fb / sec / 1e9, 1),
+                                "note": "bytes at the record sizes this build loads (48-B nodes and triangles) / time; most are served by L1 / L2"}
+                req = tot("TCP_TCC_READ_REQ_sum")
+                l1 = tot("TCP_TOTAL_CACHE_ACCESSES_sum")
+                miss = tot("TCC_MISS_sum")
+                r["l2_side"] = {"l1_to_l2_requests_per_frame": int(req), "request_bytes": 128,
+                                "rate_gbs": round(req * 128 / sec / 1e9, 1), "l2_gather_peak_gbs": L2_GATHER_GBS,
+                                "l2_misses_per_frame": int(miss), "fabric_rate_gbs": round(miss * 128 / sec / 1e9, 1),
+                                "infinity_cache_gather_peak_gbs": MALL_GATHER_GBS,
+                                "l1_hit": round(1.0 - req / l1, 3) if l1 else None,
+                                "l2_hit": round(1.0 - miss / max(1.0, tot("TCC_HIT_sum") + miss), 3)}
+                fr["l2_gather"] = round(req * 128 / sec / 1e9 / L2_GATHER_GBS, 3)
+                fr["infinity_cache_gather"] = round(miss * 128 / sec / 1e9 / MALL_GATHER_GBS, 3)
+                clks = sec * SHADER_CLK_HZ
+                lane_loads = l1 / (NUM_CUS * clks) if clks else 0.0
+                fast = tot("SQ_INSTS_VALU_FAST")
+                valu = tot("SQ_INSTS_VALU")
+                slow = max(0.0, valu - fast)
+                r["issue"] = {"lane_loads_per_clk_per_cu": round(lane_loads, 3), "lane_load_ceiling": LANE_LOADS_PER_CLK_PER_CU,
+                              "valu_wave_instructions_per_frame": int(valu), "valu_fast_share": round(fast / valu, 3) if valu else None,
+                              "valu_clk_fast_slow": [VALU_CLK_FAST, VALU_CLK_SLOW],
+                              "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / (64.0 * tot("SQ_ACTIVE_INST_VALU")), 3)
+                              if tot("SQ_ACTIVE_INST_VALU") else None,
+                              "wait_any": round(tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"), 3) if tot("SQ_WAVE_CYCLES") else None,
+                              "shader_clock_hz_assumed": SHADER_CLK_HZ}
+                fr["vmem_address_unit"] = round(lane_loads / LANE_LOADS_PER_CLK_PER_CU, 3)
+                fr["valu_issue"] = round((fast * VALU_CLK_FAST + slow * VALU_CLK_SLOW) / (NUM_SIMDS * clks), 3) if clks else None
+            r["fractions"] = fr
+            r["bound"] = max(((v, k) for k, v in fr.items() if v is not None), default=(0, "hbm"))[1]
             return r
 
         kernels = {k: roof(k) for k in kernel_ms}
@@ -421,20 +518,26 @@ def main():
                 if args.scene == "atrium" else "Cornell box, 32 triangles, Lambertian",
                 "resolution": [W, H], "max_depth": D, "spp_per_step": 1, "mat_index": mat,
                 "parallelism": "tile%d" % world,
-                "tiling": None if not tiled else {"stripe_rows": pkg.tiling.stripe_rows(H, world), "rows_this_rank": n_pix_tile // W,
-                                                  "exchange": "reduce_scatter_tensor(int64 SUM) of the owner-major splat buffer",
-                                                  "exchange_bytes_per_rank_per_frame": R.exchange_bytes},
+                "tiling": {"stripe_rows": pkg.tiling.stripe_rows(H, world), "rows_this_rank": n_pix_tile // W,
+                           "exchange": "reduce_scatter_tensor(int64 SUM) of the owner-major splat buffer" if dist is not None else None,
+                           "exchange_bytes_per_rank_per_frame": R.exchange_bytes if dist is not None else 0,
+                           "backend": backend,
+                           # one frame run alone on rank 0: the zero-valued connection rounds that run beside the exchange,
+                           # exchange + those rounds (enqueue of the collective to its completion on the render stream),
+                           # and what of the exchange the rounds did not cover
+                           "tail_ms": round(tail_ms, 3), "exchange_plus_tail_ms": round(ex_plus_tail_ms, 3),
+                           "exchange_exposed_ms": round(max(0.0, ex_plus_tail_ms - tail_ms), 3),
+                           "per_rank": per_rank},
                 "rays_per_frame": int(rays_all / K),
                 "rays_reference_equivalent_per_frame": int(stat["pixelsValid"] * ((D + 1) ** 2 - 1) + n_pix_tile)
                 if world == 1 else None,
                 "bvh": {"nodes": info.numNodes, "node_bytes": info.nodeBytes, "tri_bytes": info.triBytes,
-                        "max_depth": info.maxDepth, "sah_cost": round(info.sahCost, 2)},
+                        "references": info.numReferences, "max_depth": info.maxDepth, "sah_cost": round(info.sahCost, 2)},
                 "visits_per_ray": {"shadow_nodes": round(n_int_s, 2), "shadow_tris": round(n_tri_s, 2),
                                    "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
                 "frames_in_flight": inflight,
-                "pipelined_pass": pipelined,
-                "stage_timing": "HIP events over the timed region" if inflight == 1 else
-                                "HIP events over %d untimed frames run alone on rank 0's band (timed frames overlap)" % stage_frames,
+                "stage_timing": "HIP events over %d untimed frames run alone on rank 0's tile before the timed region "
+                                "(timed frames overlap each other)" % stage_frames,
                 "stage_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
                 "stage_mrays": {"walk_kernel": round(closest_per_frame / (kernel_ms["walk_kernel"] * 1e-3) / 1e6, 1)
                                 if kernel_ms["walk_kernel"] > 0 else None,
@@ -443,34 +546,66 @@ def main():
                 "dominant_kernel": dominant,
             },
             # the kernel with the largest summed duration in the frame; every figure below can be recomputed from
-            # profiles/<round>/ (kernel stats csv for the durations, hbm_traffic_pmc.json for the traffic)
+            # profiles/<round>/ (kernel_stats.csv for the durations, roofline_pmc.json <- the pmc_*.csv passes for the counts)
             "roofline": {
                 "kernel": dominant, "bound": dom.get("bound", "hbm"), "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac"], "traffic": dom["traffic"],
+                "frac": dom["frac"], "traffic": dom.get("traffic"),
+                "fractions": dom.get("fractions"),
                 "peak_achievable_copy": 6290.0,  # float4 copy rate MI355X_MICROARCH.md reports (79 % of spec)
                 "bytes_per_frame": dom["bytes_per_frame"], "ms_per_frame": dom["ms_per_frame"],
                 "kernels": kernels,
                 "frame": {"ms_per_frame": round(frame_ms, 3), "bytes_per_frame": int(frame_bytes),
                           "achieved": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 1) if frame_ms > 0 else 0.0,
                           "frac": round(frame_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms > 0 else 0.0,
-                          "traffic": sum(traffic.values()) if traffic else None},
+                          "traffic": sum(k["traffic"] for k in kernels.values() if k.get("traffic")) or None},
                 "node_bytes_costed": SURVEY_NODE_BYTES, "node_bytes_fetched": info.nodeBytes,
-                "note": "achieved = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit; an interior-node visit costed at "
-                        "SURVEY's 64 B although this build's node records are 48 B) / measured time, against HBM peak; "
-                        "traffic = HBM-side bytes from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE).  The BVH of this scene "
-                        "lives in L2/MALL, so traffic << algorithmic bytes for the two traversal kernels: HBM does not bound them; "
-                        "they sit at about 0.7 of the vector-memory address rate and 0.6-0.7 of VALU issue at half of the lanes "
-                        "(DESIGN.md section 4: measured sensitivities; `bound` is the largest counter fraction); frac says how "
-                        "close node/triangle delivery is to what HBM could stream.  gen_kernels exceed 1: SURVEY's 200 B per connection pair assumes both vertices are fetched per "
-                        "pair, the generator fetches every vertex record once per pixel and shares it through LDS",
+                "note": "achieved / frac = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit, an interior-node visit costed at 64 B) / "
+                        "measured time against HBM peak: the contract's figure; it exceeds the HBM-side traffic (PMC) because the BVH "
+                        "is served from L1 / L2 / Infinity Cache, so it can pass 1 and does not say what binds.  `fractions` does: each "
+                        "is a measured rate over the ceiling that applies to it — hbm: 2 x FETCH_SIZE + WRITE_SIZE over 8 TB/s; l2_gather: "
+                        "L1-to-L2 read requests x 128 B (the request size, profiles/r3/fetch_calib.txt) over the guide's L2 gather rate; "
+                        "infinity_cache_gather: L2 misses x 128 B over its random-row Infinity-Cache rate; vmem_address_unit: L1 accesses (lane-loads) per clock per CU over this repo's "
+                        "microbenchmarked ceiling; valu_issue: VALU wave-instructions x measured issue clocks (2.4 for the fma/mul/add "
+                        "class, 4.3 for the rest) over SIMD clocks.  `bound` names the largest; none of them can exceed 1 by "
+                        "construction except through the assumed 2.4 GHz clock.  Counts come from the committed PMC passes of this "
+                        "command (profiles/%s/), durations from this run." % PROFILE_ROUND,
             },
         }
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            base, parity = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds)
+
+    # ---- informational passes at N = 1 (rank 0 only; the headline above is already final)
+    if rank == 0 and world == 1 and dist is None:
+        if args.single_pass:
+            R1 = TileRenderer(pkg, scene, W, H, D, mat, local_rank, 1, 0, None, 1)
+            for _ in range(2):
+                R1.step()
+            R1.barrier()
+            R1.rewind(*mark)
+            dt1, rays1 = timed_frames(R1, pkg, args.steps)
+            out["config"]["single_frame_in_flight"] = {
+                "frames_in_flight": 1, "value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 3),
+                "note": "same frames, one context, no host synchronisation either; informational (the kernels' solo durations of the roofline block add up to this loop)"}
+            R1.close()
+        if not args.no_cpu_baseline:  # rank 0 at N=1 only
+            base, parity = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds, mark[0])
             out["cpu_baseline"] = base
             out.update(parity)
-        print(json.dumps(out), flush=True)
     R.close()
+    if rank == 0 and world == 1 and dist is None and args.other_configs and args.scene == "atrium" and (W, H, D) == (1920, 1080, 8):
+        others = []
+        s2 = pkg.Scene.cornell()
+        others.append(other_config(pkg, torch, "BASELINE configs[1]: Cornell box 1920x1080 depth 8, Lambertian", s2, 1920, 1080, 8, 1))
+        s2.close()
+        s4 = pkg.Scene.atrium(1, 2800000)
+        others.append(other_config(pkg, torch, "BASELINE configs[3] shape on ONE GPU: 2.8 M triangles (atrium generator, Bistro stand-in) 3840x2160 depth 12",
+                                   s4, 3840, 2160, 12, 0))
+        s4.close()
+        s5 = pkg.Scene.courtyard(2, 10000000, 0.5)
+        others.append(other_config(pkg, torch, "BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "
+                                   "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", s5, 3840, 2160, 16, 0))
+        s5.close()
+        out["config"]["other_configs"] = others
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -493,7 +628,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s):
+def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s, frame):
     """The oracle (scalar C++ restatement, kind "port") on this box's host cores, on a band of rows of the same frame
     in the middle of the image, sized from a short probe to take about budget_s.  The rows it rendered are then
     rendered by the HIP path as a tile with the same frame counters and jitter, and compared: `rmse` (linear fp32
@@ -503,6 +638,7 @@ def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     cores = effective_cpus()
+    pipe.gbuffer_frame, pipe.bdpt_frame = 0xdeadbeef + frame, 0x1337 + frame
     gp = pipe.gbuffer_params()
     p = pipe.bdpt_params()
 

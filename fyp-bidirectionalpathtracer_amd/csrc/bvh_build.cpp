@@ -64,13 +64,14 @@ struct TmpNode {
 // Default budgets.  Opaque triangles: none — measured on the bench atrium (tools/bvh_eval.py, profiles/README.md r3)
 // pre-splitting by priority makes an evenly tessellated scene's tree worse at every setting tried (SAH cost 31.3 ->
 // 31.5-35.2, +0-14 % node visits); the knob (also the environment variable BDPT_SPLIT_BUDGET) stays for scenes that
-// mix huge and tiny triangles.  Non-opaque triangles: two extra references each — the 10 M-triangle courtyard's
-// closest-hit rays go from 82 node visits + 59 triangle tests to 48 + 18.
+// mix huge and tiny triangles.  Non-opaque triangles: four extra references each — the 10 M-triangle
+// courtyard's closest-hit rays go from 76 node visits + 55 triangle tests to 40 + 12 and its 4K depth-16 frame from 905 ms to
+// 373 ms (budgets 2 / 4 / 8: 435 / 373 / 361 ms at 7 / 13 / 16 s of scene set-up).
 #ifndef BDPT_SPLIT_BUDGET
 #define BDPT_SPLIT_BUDGET 0.0f
 #endif
 #ifndef BDPT_SPLIT_BUDGET_ALPHA
-#define BDPT_SPLIT_BUDGET_ALPHA 2.0f
+#define BDPT_SPLIT_BUDGET_ALPHA 4.0f
 #endif
 // Opaque triangles are only split when their box is an outlier — at least this many times the median box area of the
 // scene's opaque triangles — and only down to about that size: the Karras-Aila priority ranks triangles against each

@@ -238,7 +238,7 @@ def test_rccl_exchange_path_single_rank_reproduces_plain_run(pkg, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--dump-frames", "5", "--width", "480", "--height", "270", "--depth", "6", "--triangles", "40000"]
     plain, tiled = tmp_path / "plain.npy", tmp_path / "rccl.npy"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-path", str(plain)] + common,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--plain-loop", "--dump-path", str(plain)] + common,
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     env = dict(os.environ, BDPT_BENCH_TILED_AT_1="1")

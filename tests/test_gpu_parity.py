@@ -319,13 +319,13 @@ def test_frames_in_flight_tiled_loop_equals_plain_loop(pkg):
     import bench
     scene = pkg.Scene.atrium(2, 20000)
     W, H, D, frames = 128, 72, 5, 7
-    plain = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, 1, 0, None, False)
+    plain = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=0, accum_limit=1 << 30)  # the reference's sequence, one frame at a time
     for _ in range(frames):
-        plain.step()
+        plain.render_frame(accumulate=True)
     torch.cuda.synchronize()
     ref = plain.last_frame.cpu().numpy().copy()
     plain.close()
-    tiled = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, 1, 0, None, True, 3)
+    tiled = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, 1, 0, None, 3)  # what bench.py times at N = 1
     assert tiled.inflight == 3
     for _ in range(frames):
         tiled.step()
@@ -579,7 +579,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(pkg, tmp_path):
     common = ["--dump-frames", "4", "--width", "320", "--height", "180", "--depth", "5", "--triangles", "30000"]
     one = tmp_path / "n1.npy"
     two = tmp_path / "n2.npy"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-path", str(one)] + common,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--plain-loop", "--dump-path", str(one)] + common,
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     env = dict(os.environ, BDPT_BENCH_BACKEND="gloo", BDPT_BENCH_DEVICE="0")

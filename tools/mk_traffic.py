@@ -27,7 +27,7 @@ fe, nf = load(sys.argv[1], "FETCH_SIZE")
 wr, nw = load(sys.argv[2], "WRITE_SIZE")
 frames = [v for k, v in nf.items() if "gbuffer_kernel" in k][0]
 out = {"frames": frames, "unit": "bytes per frame (raw counters x 1024; FETCH_SIZE not yet doubled)",
-       "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined-pass"}
+       "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate runs) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-pass --no-other-configs"}
 for k in sorted(fe):
     if "bdpt" in k:
         out[k] = {"fetch_bytes_per_frame": fe[k] / frames, "write_bytes_per_frame": wr.get(k, 0.0) / frames,

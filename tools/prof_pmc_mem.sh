@@ -3,7 +3,7 @@
 # levels, instruction fetch, LDS conflicts) for `python3 bench.py`; each pass is its own rocprofv3 --pmc run without trace
 # domains, under a timeout (the TA_* / TCP_* stall counters of this ROCm abort rocprofv3 on gfx950 and are not used).
 tag=$1; shift
-args="--steps 2 --warmup 1 --no-cpu-baseline --no-pipelined-pass $*"
+args="--steps 2 --warmup 1 --no-cpu-baseline --no-single-pass --no-other-configs $*"
 export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_IFETCH" \

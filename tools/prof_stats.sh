@@ -4,7 +4,7 @@
 set -e
 tag=$1; shift
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pipelined-pass "$@" > gpurun_out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-single-pass --no-other-configs "$@" > gpurun_out/${tag}_stats.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/${tag}_stats/*kernel_stats.csv")+glob.glob("gpurun_out/${tag}_stats/*/*kernel_stats.csv")

@@ -77,6 +77,15 @@ class Gui {
   void addText(const char* text) { log.push_back(std::string("text:") + text); }
 };
 
+// Falcor::SampleConfig as far as Main.cpp:20-25 fills it in.  There is no window: width / height size the channels.
+struct SampleConfig {
+  struct WindowDesc {
+    bool resizableWindow = false;
+    uint32_t width = 1920, height = 1080;
+    std::string title;
+  } windowDesc;
+};
+
 struct KeyboardEvent { int key = 0; };
 struct MouseEvent { int button = 0; float x = 0, y = 0; };
 

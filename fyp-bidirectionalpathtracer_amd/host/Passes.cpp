@@ -1,7 +1,9 @@
 // Passes.cpp — host mirror of the reference's pass framework and passes over the C ABI.
 #include "Passes.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -545,9 +547,40 @@ void BlockwiseMultiOrderFeatureRegression::execute(RenderContext* pRenderContext
 // ------------------------------------------------------------------------------------------------
 // RenderingPipeline (headless subset of SharedUtils/RenderingPipeline.cpp)
 // ------------------------------------------------------------------------------------------------
-RenderingPipeline::RenderingPipeline(uint32_t width, uint32_t height, int device) : mContext(device, nullptr), mWidth(width), mHeight(height) {
+RenderingPipeline::RenderingPipeline() : mContext(0, nullptr), mWidth(0), mHeight(0) {}
+RenderingPipeline::RenderingPipeline(uint32_t width, uint32_t height, int device) : mContext(0, nullptr), mWidth(0), mHeight(0) {
+  setSize(width, height, device);
+}
+void RenderingPipeline::setSize(uint32_t width, uint32_t height, int device) {
+  mContext = RenderContext(device, nullptr);
+  mWidth = width;
+  mHeight = height;
   (void)hipSetDevice(device);
   mpResourceManager = ResourceManager::create(width, height, &mContext);
+}
+void RenderingPipeline::run(RenderingPipeline* pipe, SampleConfig& config) {
+  if (!pipe) return;
+  pipe->setSize(config.windowDesc.width, config.windowDesc.height, 0);
+  const char* sceneName = std::getenv("BDPT_SCENE");
+  Scene::SharedPtr pScene;
+  if (sceneName && std::strchr(sceneName, '.')) {
+    std::string err;
+    pScene = Scene::loadFromFile(sceneName, &err);
+    if (!pScene) std::fprintf(stderr, "[RenderingPipeline] %s\n", err.c_str());
+  } else if (sceneName && std::strcmp(sceneName, "atrium") == 0) {
+    pScene = Scene::createAtrium(1, 262144);
+  }
+  if (!pScene) pScene = Scene::createCornellBox();
+  if (pipe->initialize(pScene)) {
+    const char* f = std::getenv("BDPT_FRAMES");
+    const int frames = f ? std::max(1, std::atoi(f)) : 1;
+    for (int i = 0; i < frames; i++) pipe->renderFrame();
+    pipe->getRenderContext()->flush(true);
+    std::printf("%s: %d frame(s) of %ux%u rendered\n", config.windowDesc.title.c_str(), frames, config.windowDesc.width, config.windowDesc.height);
+  } else {
+    std::fprintf(stderr, "[RenderingPipeline] initialisation failed (no GPU?)\n");
+  }
+  delete pipe;
 }
 RenderingPipeline::~RenderingPipeline() {
   for (auto& p : mActivePasses)
@@ -559,6 +592,7 @@ void RenderingPipeline::setPass(uint32_t passNum, RenderPass::SharedPtr pTargetP
   mActivePasses[passNum] = pTargetPass;
 }
 bool RenderingPipeline::initialize(Scene::SharedPtr pScene) {
+  if (!mpResourceManager) return false;  // no size yet (default-constructed and neither run() nor setSize() called)
   mpScene = pScene;
   mpResourceManager->requestTextureResource(ResourceManager::kOutputChannel);
   mpResourceManager->updateEnvironmentMap("");  // the HDR probe blob is absent: default constant environment
@@ -590,9 +624,10 @@ void RenderingPipeline::renderFrame() {
   for (auto& p : mActivePasses)
     if (p) p->onExecute(&mContext);
 }
-// ---- checkpoints: [magic][pass count] then per pass [name length][name][state length][state]
+// ---- checkpoints
 namespace {
 constexpr uint32_t kCheckpointMagic = 0x42445054u;  // "BDPT"
+constexpr uint32_t kCheckpointVersion = 2u;
 void put32(std::vector<uint8_t>& o, uint32_t v) {
   for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i)));
 }
@@ -603,15 +638,40 @@ uint32_t get32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8)
 uint64_t get64(const uint8_t* p) { return (uint64_t)get32(p) | ((uint64_t)get32(p + 4) << 32); }
 }  // namespace
 
-void LightProbeGBufferPass::saveState(RenderContext*, std::vector<uint8_t>& out) { put32(out, mFrameCount); }
+static uint32_t floatBits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+// Each pass writes the settings its frames depend on beside its counters and refuses a state written under others:
+// a run resumed with another ray depth, material model or lens would blend unrelated frames into the restored mean.
+void LightProbeGBufferPass::saveState(RenderContext*, std::vector<uint8_t>& out) {
+  put32(out, mFrameCount);
+  put32(out, (mUseThinLens ? 1u : 0u) | (mUseJitter ? 2u : 0u));
+  put32(out, floatBits(mFStop));
+  put32(out, floatBits(mFocalLength));
+}
 bool LightProbeGBufferPass::loadState(RenderContext*, const uint8_t* data, size_t size) {
-  if (size != 4) return false;
+  if (size != 16) return false;
+  if (get32(data + 4) != ((mUseThinLens ? 1u : 0u) | (mUseJitter ? 2u : 0u))) return false;
+  if (mUseThinLens && (get32(data + 8) != floatBits(mFStop) || get32(data + 12) != floatBits(mFocalLength))) return false;
   mFrameCount = get32(data);
   return true;
 }
-void BDPTPass::saveState(RenderContext*, std::vector<uint8_t>& out) { put32(out, mFrameCount); }
+void BDPTPass::saveState(RenderContext*, std::vector<uint8_t>& out) {
+  put32(out, mFrameCount);
+  put32(out, (uint32_t)mUserSpecifiedRayDepth);
+  put32(out, (uint32_t)mMaterialIndex);
+  put32(out, floatBits(mClampUpper));
+  put32(out, mParamFlags);
+  put32(out, floatBits(mpResManager ? mpResManager->getMinTDist() : 0.0f));
+}
 bool BDPTPass::loadState(RenderContext*, const uint8_t* data, size_t size) {
-  if (size != 4) return false;
+  if (size != 24) return false;
+  if (get32(data + 4) != (uint32_t)mUserSpecifiedRayDepth || get32(data + 8) != (uint32_t)mMaterialIndex ||
+      get32(data + 12) != floatBits(mClampUpper) || get32(data + 16) != mParamFlags ||
+      get32(data + 20) != floatBits(mpResManager ? mpResManager->getMinTDist() : 0.0f))
+    return false;
   mFrameCount = get32(data);
   return true;
 }
@@ -630,14 +690,49 @@ bool SimpleAccumulationPass::loadState(RenderContext* pRenderContext, const uint
   return mpLastFrame->uploadRaw(pRenderContext->getStream(), data + 4, size - 4);
 }
 
+// What a checkpoint belongs to besides its passes: FNV-1a over the scene's geometry, materials, lights and camera.
+uint64_t RenderingPipeline::sceneIdentity() const {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  if (!mpScene) return h;
+  bdpt_scene_desc d;
+  mpScene->getDesc(&d);
+  mix(&d.numVertices, 4);
+  mix(&d.numTriangles, 4);
+  if (d.positions) mix(d.positions, (size_t)d.numVertices * 12);
+  if (d.indices) mix(d.indices, (size_t)d.numTriangles * 12);
+  if (d.triMaterial) mix(d.triMaterial, (size_t)d.numTriangles * 4);
+  if (d.materials) mix(d.materials, (size_t)d.numMaterials * sizeof(bdpt_material));
+  if (d.lights) mix(d.lights, (size_t)d.numLights * sizeof(bdpt_light));
+  if (mpScene->getActiveCamera()) {
+    mpScene->getActiveCamera()->setAspectRatio((float)mWidth / (float)std::max(1u, mHeight));
+    const bdpt_camera& c = mpScene->getActiveCamera()->getData();
+    mix(&c, sizeof(c));
+  }
+  return h;
+}
+
+// [magic][version][width][height][scene identity][pass count] then per pass [name length][name][state length][state]
 bool RenderingPipeline::saveCheckpoint(const std::string& path) {
+  for (auto& pass : mActivePasses)
+    if (pass && pass->onHasUnsavedCrossFrameState()) {
+      std::fprintf(stderr, "[RenderingPipeline] pass '%s' holds cross-frame state that cannot be saved: no checkpoint written\n", pass->getName().c_str());
+      return false;
+    }
   std::vector<uint8_t> out;
   put32(out, kCheckpointMagic);
+  put32(out, kCheckpointVersion);
+  put32(out, mWidth);
+  put32(out, mHeight);
+  put64(out, sceneIdentity());
   put32(out, (uint32_t)mActivePasses.size());
   for (auto& pass : mActivePasses) {
-    const std::string name = pass->getName();
+    const std::string name = pass ? pass->getName() : std::string();
     std::vector<uint8_t> st;
-    pass->onSaveState(&mContext, st);
+    if (pass) pass->onSaveState(&mContext, st);
     put32(out, (uint32_t)name.size());
     out.insert(out.end(), name.begin(), name.end());
     put64(out, st.size());
@@ -650,32 +745,53 @@ bool RenderingPipeline::saveCheckpoint(const std::string& path) {
 }
 
 bool RenderingPipeline::loadCheckpoint(const std::string& path) {
+  for (auto& pass : mActivePasses)
+    if (pass && pass->onHasUnsavedCrossFrameState()) {
+      std::fprintf(stderr, "[RenderingPipeline] pass '%s' holds cross-frame state no checkpoint carries: not resuming\n", pass->getName().c_str());
+      return false;
+    }
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
   std::vector<uint8_t> d;
   uint8_t buf[65536];
   for (size_t n; (n = std::fread(buf, 1, sizeof(buf), f)) > 0;) d.insert(d.end(), buf, buf + n);
   std::fclose(f);
-  size_t p = 0;
-  if (d.size() < 8 || get32(&d[0]) != kCheckpointMagic || get32(&d[4]) != mActivePasses.size()) return false;
-  // deliver the refresh notification a first frame would (it resets the accumulation) BEFORE the state comes in
+  constexpr size_t kHeader = 28;
+  if (d.size() < kHeader || get32(&d[0]) != kCheckpointMagic || get32(&d[4]) != kCheckpointVersion) return false;
+  if (get32(&d[8]) != mWidth || get32(&d[12]) != mHeight || get64(&d[16]) != sceneIdentity()) return false;
+  if (get32(&d[24]) != mActivePasses.size()) return false;
+  // first pass over the file: every section must be there, named after its pass, and inside the file (the lengths come
+  // from the file: compare against what is LEFT, never add them to the cursor first)
+  struct Section {
+    size_t at, size;
+  };
+  std::vector<Section> sections;
+  size_t p = kHeader;
   for (auto& pass : mActivePasses) {
-    pass->onStateRefresh();
-    pass->resetRefreshFlag();
-  }
-  p = 8;
-  for (auto& pass : mActivePasses) {
-    if (p + 4 > d.size()) return false;
+    if (d.size() - p < 4) return false;
     const uint32_t nl = get32(&d[p]);
     p += 4;
-    if (p + nl + 8 > d.size() || std::string(d.begin() + (long)p, d.begin() + (long)(p + nl)) != pass->getName()) return false;
+    if ((size_t)nl > d.size() - p || d.size() - p - nl < 8) return false;
+    if (std::string(d.begin() + (long)p, d.begin() + (long)(p + nl)) != (pass ? pass->getName() : std::string())) return false;
     p += nl;
     const uint64_t sl = get64(&d[p]);
     p += 8;
-    if (p + sl > d.size() || !pass->onLoadState(&mContext, sl ? &d[p] : nullptr, (size_t)sl)) return false;
+    if (sl > (uint64_t)(d.size() - p)) return false;
+    sections.push_back(Section{p, (size_t)sl});
     p += (size_t)sl;
   }
-  return p == d.size();
+  if (p != d.size()) return false;
+  // deliver the refresh notification a first frame would (it resets the accumulation) BEFORE the state comes in
+  for (auto& pass : mActivePasses)
+    if (pass) {
+      pass->onStateRefresh();
+      pass->resetRefreshFlag();
+    }
+  for (size_t i = 0; i < mActivePasses.size(); i++) {
+    if (!mActivePasses[i]) continue;
+    if (!mActivePasses[i]->onLoadState(&mContext, sections[i].size ? &d[sections[i].at] : nullptr, sections[i].size)) return false;
+  }
+  return true;
 }
 
 std::vector<float> RenderingPipeline::readOutput() {

@@ -147,6 +147,9 @@ class BlockwiseMultiOrderFeatureRegression : public RenderPass {
   void resize(uint32_t width, uint32_t height) override;
   bool appliesPostprocess() override { return true; }
   bool hasAnimation() override { return false; }
+  // the temporal history (frame number, previous position / normal / noisy / filtered frames, accept masks) lives
+  // inside the context and has no serializer: a pipeline with the denoiser switched on cannot be checkpointed
+  bool hasUnsavedCrossFrameState() override { return mDoDenoise; }
 
   std::string mDenoiseChannel;
   RayLaunch::SharedPtr mpRays;
@@ -163,8 +166,14 @@ class BlockwiseMultiOrderFeatureRegression : public RenderPass {
 // RenderingPipeline.cpp:421-471, 611-695); the window, GUI rendering and final blit are out of scope.
 class RenderingPipeline {
  public:
+  RenderingPipeline();  // as Main.cpp:12 constructs it; the size comes with run()'s SampleConfig or with setSize()
   RenderingPipeline(uint32_t width, uint32_t height, int device = 0);
   ~RenderingPipeline();
+  void setSize(uint32_t width, uint32_t height, int device = 0);  // before initialize()
+  // RenderingPipeline::run (RenderingPipeline.cpp:697-712) without a window: size the channels from the config,
+  // load the scene named by BDPT_SCENE (a .fscene / .obj path, "atrium", default the Cornell box), render BDPT_FRAMES
+  // frames (default 1), and delete the pipeline.
+  static void run(RenderingPipeline* pipe, SampleConfig& config);
   void setPass(uint32_t passNum, RenderPass::SharedPtr pTargetPass);
   // onLoad (initialize every pass, drop those that fail), onFirstRun (scene), onResize
   bool initialize(Scene::SharedPtr pScene);
@@ -174,12 +183,16 @@ class RenderingPipeline {
   RenderContext* getRenderContext() { return &mContext; }
   std::vector<float> readOutput();    // "PipelineOutput" as RGBA32F
   // every pass's cross-frame state (frame counters, accumulated frame) to / from a file: a run resumed from a
-  // checkpoint continues the frame sequence bit for bit.  false on I/O errors or a file that does not match the passes.
+  // checkpoint continues the frame sequence bit for bit.  false on I/O errors, when a pass holds cross-frame state it
+  // cannot serialise (the BMFR denoiser when switched on), or for a file that does not match this pipeline: other
+  // passes, frame size, scene, or pass settings (ray depth, material model, clamp, lens, accumulation limit).  After a
+  // failed load the pipeline's state is unspecified: discard it.
   bool saveCheckpoint(const std::string& path);
   bool loadCheckpoint(const std::string& path);
   size_t getPassCount() const { return mActivePasses.size(); }
 
  private:
+  uint64_t sceneIdentity() const;
   RenderContext mContext;
   uint32_t mWidth, mHeight;
   ResourceManager::SharedPtr mpResourceManager;

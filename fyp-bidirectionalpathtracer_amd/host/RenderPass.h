@@ -93,6 +93,9 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   // texture — as raw bytes.  A pass without cross-frame state keeps the defaults.
   virtual void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) {}
   virtual bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) { return size == 0; }
+  // true when the pass carries state from frame to frame that saveState does NOT capture: a pipeline holding such a
+  // pass refuses to write or read a checkpoint instead of resuming into a silently different sequence
+  virtual bool hasUnsavedCrossFrameState() { return false; }
 
  public:
   virtual bool requiresScene() { return false; }
@@ -118,6 +121,7 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   void onPassDeactivation() { deactivatePass(); }
   void onSaveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) { saveState(pRenderContext, out); }
   bool onLoadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) { return loadState(pRenderContext, data, size); }
+  bool onHasUnsavedCrossFrameState() { return hasUnsavedCrossFrameState(); }
 
   void setName(const std::string& name) { mName = name; }
   std::string getName() const { return mName; }

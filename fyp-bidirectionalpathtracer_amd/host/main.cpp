@@ -7,9 +7,7 @@
 #include <cstring>
 #include <string>
 
-#include "Passes.h"
-
-using namespace bdpt;
+#include "ReferenceNames.h"  // the mirror's classes under the reference's global names: no `using namespace`
 
 static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t w, uint32_t h) {
   FILE* f = std::fopen(path, "wb");
@@ -65,11 +63,18 @@ int main(int argc, char** argv) {
   }
 
   // Create our rendering pipeline and add the passes, as Main.cpp:12-18 does
-  RenderingPipeline* pipeline = new RenderingPipeline(W, H, device);
+  RenderingPipeline* pipeline = new RenderingPipeline();
   pipeline->setPass(0, LightProbeGBufferPass::create());
   pipeline->setPass(1, BDPTPass::create(ResourceManager::kOutputChannel));
   pipeline->setPass(2, SimpleAccumulationPass::create(ResourceManager::kOutputChannel));
   pipeline->setPass(3, BlockwiseMultiOrderFeatureRegression::create());
+  // the window parameters of Main.cpp:20-25 size the channels (there is no window)
+  SampleConfig config;
+  config.windowDesc.resizableWindow = true;
+  config.windowDesc.width = W;
+  config.windowDesc.height = H;
+  config.windowDesc.title = "Bidirectional Path Tracing (headless)";
+  pipeline->setSize(config.windowDesc.width, config.windowDesc.height, device);
   if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 4) {
     std::fprintf(stderr, "pipeline initialisation failed (no GPU?)\n");
     return 1;

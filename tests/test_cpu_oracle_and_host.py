@@ -427,3 +427,19 @@ def test_bvh_build_does_not_depend_on_thread_count(pkg, which):
     if which == "atrium":
         assert hashes[0] == 0x846303e1b318d0c5 and infos[0][0] == 68725  # nodes, leaf entries + their boxes and the packed 48-byte records
     scene.close()
+
+
+def test_reference_style_program_compiles_against_the_host_mirror():
+    """host/ReferenceNames.h exports the mirror's classes at global scope: a program written like the reference's
+    Main.cpp (global ::RenderingPipeline, ::BDPTPass ..., SampleConfig, RenderingPipeline::run, a user pass derived from
+    ::RenderPass) compiles without `using namespace bdpt`."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    host = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd", "host")
+    src = os.path.join(ROOT, "tests", "host_compile", "reference_style_main.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + host, src],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "using namespace" not in open(src).read().split("int main")[1]

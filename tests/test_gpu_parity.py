@@ -619,3 +619,22 @@ def test_cpp_host_checkpoint_resume_continues_bit_for_bit(pkg, tmp_path):
     r = subprocess.run([exe, "--scene", "cornell", "--width", "48", "--height", "40", "--depth", "4", "--frames", "1", "--out", str(tmp_path / "o.pfm"),
                         "--resume", str(tmp_path / "c.ckpt")], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "cannot resume" in r.stderr
+    # the file also names what it was rendered with: another ray depth, material model or scene is refused instead of
+    # blending unrelated frames into the restored running mean
+    for other in (["--depth", "5"], ["--mat", "1"], ["--scene", "atrium"]):
+        args = [exe] + common + ["--frames", "1", "--resume", str(tmp_path / "c.ckpt")]
+        for k in range(0, len(other), 2):
+            args[args.index(other[k]) + 1] = other[k + 1]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "cannot resume" in r.stderr, (other, r.stderr)
+    # the BMFR denoiser keeps a temporal history no checkpoint carries: with it switched on, neither writing nor resuming
+    r = run(["--frames", "2", "--denoise", "--checkpoint", str(tmp_path / "d.ckpt")])
+    assert r.returncode != 0 and "cannot write" in r.stderr and not os.path.exists(tmp_path / "d.ckpt")
+    r = run(["--frames", "2", "--denoise", "--resume", str(tmp_path / "c.ckpt")])
+    assert r.returncode != 0 and "cannot resume" in r.stderr
+    # a truncated or corrupt file is refused (section lengths are checked against what is left of the file)
+    blob = open(tmp_path / "c.ckpt", "rb").read()
+    for bad in (blob[:len(blob) // 2], blob[:40] + b"\xff" * 8 + blob[48:], blob + b"x"):
+        open(tmp_path / "bad.ckpt", "wb").write(bad)
+        r = run(["--frames", "1", "--resume", str(tmp_path / "bad.ckpt")])
+        assert r.returncode != 0 and "cannot resume" in r.stderr

@@ -126,6 +126,15 @@ class Context:
     def set_camera(self, cam):
         self._check(self._lib.bdpt_set_camera(self._h, C.byref(cam)), "bdpt_set_camera")
 
+    def set_environment(self, env_map_ptr=None, width=0, height=0, color=(0.0, 0.0, 0.0, 0.0)):
+        """What BDPT_PARAM_ENV_ON_MISS looks up: a device RGBA32F lat-long map, or a constant colour."""
+        e = abi.Environment()
+        e.envMap = env_map_ptr
+        e.width, e.height = int(width), int(height)
+        for i in range(4):
+            e.color[i] = float(color[i])
+        self._check(self._lib.bdpt_set_environment(self._h, C.byref(e)), "bdpt_set_environment")
+
     def resize(self, width, height, y0, y1, max_depth):
         self._check(self._lib.bdpt_resize(self._h, width, height, Tile(y0, y1), max_depth), "bdpt_resize")
 

@@ -22,6 +22,8 @@ PARAM_MIS_POWER = 64
 PARAM_MIS_LINEAR = 128
 PARAM_DEFER_TAIL = 256
 PARAM_KEEP_COUNTERS = 512
+PARAM_ENV_ON_MISS = 1024
+PARAM_EMISSIVE_HITS = 2048
 PREPARE_PRIMARY = 1
 PREPARE_BMFR = 2
 
@@ -111,6 +113,10 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Environment(C.Structure):
+    _fields_ = [("envMap", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("color", C.c_float * 4)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("numNodes", C.c_uint32), ("numTriangles", C.c_uint32), ("maxDepth", C.c_uint32),
                 ("nodeBytes", C.c_uint32), ("triBytes", C.c_uint32), ("sahCost", C.c_float), ("maxStack", C.c_uint32),
@@ -126,6 +132,7 @@ PROTOTYPES = {
     "bdpt_set_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "bdpt_get_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(BvhInfo)]),
     "bdpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
+    "bdpt_set_environment": (C.c_int, [C.c_void_p, C.POINTER(Environment)]),
     "bdpt_bvh_build_check": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BvhInfo), C.c_char_p, C.c_uint32]),
     "bdpt_host_bvh_create": (C.c_void_p, [C.POINTER(SceneDesc), C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(BvhInfo)]),
     "bdpt_host_bvh_destroy": (None, [C.c_void_p]),

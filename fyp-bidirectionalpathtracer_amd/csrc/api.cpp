@@ -48,6 +48,7 @@ struct bdpt_ctx {
   std::vector<void*> sceneAllocs;
   bdpt_bvh_info bvhInfo{};
   bdpt_camera cam{};
+  bdpt_environment env{};  // bdpt_set_environment: what BDPT_PARAM_ENV_ON_MISS looks up (none: black)
   // frame
   uint32_t W = 0, H = 0, maxDepth = 0;
   // the tile: which frame rows this context renders (a contiguous band, or the stripes of one owner) and where
@@ -479,6 +480,17 @@ int bdpt_set_camera(bdpt_ctx* c, const bdpt_camera* cam) {
   return BDPT_OK;
 }
 
+int bdpt_set_environment(bdpt_ctx* c, const bdpt_environment* env) {
+  if (!c) return BDPT_E_INVALID;
+  if (env && env->envMap && (!env->width || !env->height)) {
+    fail(c, "environment: a map needs a width and a height");
+    return BDPT_E_INVALID;
+  }
+  c->env = env ? *env : bdpt_environment{};
+  if (!c->env.envMap) c->env.width = c->env.height = 0;
+  return BDPT_OK;
+}
+
 namespace {
 int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth);
 }
@@ -587,7 +599,9 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightLast, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightReal, np))) return rc;
   // a path queue = kNumSubQueues lists; workgroup b appends to list b % kNumSubQueues
-  P.pathSubCap = (uint32_t)((((np + kWave - 1) / kWave + kNumSubQueues - 1) / kNumSubQueues) * kWave);
+  // (+ one workgroup's worth: a list may also be fed by image region, kernels.hip BDPT_REGION_LISTS, whose share of the
+  // workgroups rounds up once more)
+  P.pathSubCap = (uint32_t)((((np + kWave - 1) / kWave + kNumSubQueues - 1) / kNumSubQueues + 1) * kWave);
   const size_t qcap = (size_t)P.pathSubCap * kNumSubQueues;
   for (int q = 0; q < 3; q++)
     if ((rc = devAlloc(c, c->frameAllocs, &P.queue[q], qcap))) return rc;
@@ -730,6 +744,10 @@ int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float*
   F.splat = c->splat;
   F.gb = *in;
   F.counters = c->counters;  // ray tallies are always on; node/triangle visits need BDPT_PARAM_COUNTERS
+  F.envMap = c->env.envMap;
+  F.envW = c->env.width;
+  F.envH = c->env.height;
+  for (int k = 0; k < 3; k++) F.envColor[k] = c->env.color[k];
   return BDPT_OK;
 }
 

@@ -153,6 +153,10 @@ struct FrameDev {
   unsigned long long* splat;  // 4 x u64 per pixel, SplatLayout order
   bdpt_gbuffer gb;
   DevCounters* counters;
+  // environment of the BDPT pass (BDPT_PARAM_ENV_ON_MISS; bdpt_set_environment): RGBA32F lat-long map or constant colour
+  const float* envMap;
+  uint32_t envW, envH;
+  float envColor[3];
 };
 
 struct GBufferDev {
@@ -186,7 +190,7 @@ void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 // Persistent-grid sizes of one context's device, filled on first use (occupancy query per kernel variant).
 struct LaunchGrids {
-  uint32_t walk[4] = {0, 0, 0, 0};    // [GGX][COUNT]
+  uint32_t walk[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [EXT][GGX][COUNT]
   uint32_t shadow[2] = {0, 0};        // [COUNT]
 };
 // both random walks of the frame: one persistent launch (trace + hit/miss shading in place)

@@ -28,6 +28,10 @@
 #include "device_scene.hpp"
 #include "device_trace.hpp"
 
+#ifndef BDPT_REGION_LISTS
+#define BDPT_REGION_LISTS 0
+#endif
+
 namespace bdpt {
 
 #define BD __device__ __forceinline__
@@ -38,12 +42,13 @@ namespace bdpt {
 // every wave of a launch hitting one atomic word caps the chip near 90 M appends/s.
 //   item of list q at offset i lives at items[q*subCap + i]; count[q*kCursorStride] = list length
 // ------------------------------------------------------------------------------------------------
-BD void wavePush(bool active, uint32_t value, uint32_t* items, uint32_t* count, uint32_t subCap) {
+// q: the list the wave appends to (default: workgroup b -> list b % kNumSubQueues)
+BD void wavePush(bool active, uint32_t value, uint32_t* items, uint32_t* count, uint32_t subCap, uint32_t q = 0xffffffffu) {
   unsigned long long mask = __ballot(active);
   if (mask == 0ull) return;
   const int lane = (int)(threadIdx.x & 63u);
   const int leader = __ffsll((long long)mask) - 1;
-  const uint32_t q = blockIdx.x % kNumSubQueues;
+  if (q == 0xffffffffu) q = blockIdx.x % kNumSubQueues;
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(&count[q * kCursorStride], (uint32_t)__popcll(mask));
   base = (uint32_t)__shfl((int)base, leader);
@@ -159,6 +164,17 @@ BD float atan2_WAR(float y, float x) {  // CP lightProbeGBufferUtils.hlsli:45-58
   return 0.f;
 }
 
+// lat-long lookup of PrimaryMiss (CP lightProbeGBuffer.rt.hlsl:63-74): texel of the RGBA32F map, 0 outside
+BD f3 envLookup(const float* envMap, uint32_t envW, uint32_t envH, f3 d) {
+  const f3 pd = normalize(d);
+  const float u = (1.f + atan2_WAR(pd.x, -pd.z) * kInvPi) * 0.5f;
+  const float v = det_acos(pd.y) * kInvPi;
+  const uint32_t ex = (uint32_t)(u * (float)envW), ey = (uint32_t)(v * (float)envH);
+  f3 c = mk(0);
+  if (ex < envW && ey < envH) c = ld3(envMap + ((size_t)ey * envW + ex) * 4);
+  return c;
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G) {
   __shared__ int s_stack[kStackEntries * kWave];
@@ -195,16 +211,7 @@ __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G
   }
   float4* oP = reinterpret_cast<float4*>(G.gb.worldPosition);
   if (h.prim < 0) {
-    f3 pd = normalize(d);
-    float u = (1.f + atan2_WAR(pd.x, -pd.z) * kInvPi) * 0.5f;
-    float v = det_acos(pd.y) * kInvPi;
-    f3 c = mk(0);
-    if (G.gp.envMap) {
-      uint32_t ex = (uint32_t)(u * (float)G.gp.envWidth), ey = (uint32_t)(v * (float)G.gp.envHeight);
-      if (ex < G.gp.envWidth && ey < G.gp.envHeight) c = ld3(G.gp.envMap + ((size_t)ey * G.gp.envWidth + ex) * 4);
-    } else {
-      c = ld3(G.gp.envColor);
-    }
+    const f3 c = G.gp.envMap ? envLookup(G.gp.envMap, G.gp.envWidth, G.gp.envHeight, d) : ld3(G.gp.envColor);
     oP[pix] = make_float4(0, 0, 0, 0);
     packHalf4(G.gb.worldNormal, pix, 0, 0, 0, 0);
     packHalf4(G.gb.materialDiffuse, pix, c.x, c.y, c.z, 1.0f);
@@ -304,7 +311,14 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
       out4[pix] = em ? make_float4(0.0f + er, 0.0f + eg, 0.0f + eb, 0.0f + ea) : make_float4(0, 0, 0, 0);
     }
   }
+#if BDPT_REGION_LISTS
+  // Experiment (profiles/README.md r3): valid-pixel list q holds pixels of image region q % 8 (eighths of the tile in row
+  // order), so that the walk waves of XCD x (workgroup b -> XCD b % 8, first list b % 64) start on eye sub-paths of ONE
+  // region and their first hits share that XCD's L2.
+  wavePush(geom, p, P.queue[0], P.qcount, P.pathSubCap, (uint32_t)(((uint64_t)blockIdx.x * 8u) / gridDim.x) + 8u * (blockIdx.x % 4u));
+#else
   wavePush(geom, p, P.queue[0], P.qcount, P.pathSubCap);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -329,7 +343,12 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
 // Work list: virtual list vq in [0, 2*kNumSubQueues): pixel list vq % kNumSubQueues of the valid-pixel
 // queue, path vq / kNumSubQueues (eye first).  `head` holds one fetch cursor per virtual list.
 // A miss stores the reference's "ghost" vertex (quirk 2): colour 0, previous payload geometry.
-// A path id packs pixel (24 bits), path (bit 24) and vertex index k (bits 25-29): tiles are < 2^24 pixels.
+// A path id packs pixel (24 bits), path (bit 24) and vertex index k (bits 25-29): tiles are < 2^24 pixels; bit 30 of
+// a PARKED record's id says "miss" (the record then carries the ray's direction instead of primitive + barycentrics).
+// EXT (BDPT_PARAM_ENV_ON_MISS / _EMISSIVE_HITS; build definitions, include/bdpt.h) is its own instantiation, so the
+// reference's path pays nothing for it: the eye walk's shading pass adds what the ray found where it ended —
+// environment radiance on a miss, emissive on a hit — to the path's own pixel, in bounce order (a sub-path is shaded
+// by one lane at a time, and init_paths has written the pixel before this launch starts).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kPoolEntries = 128;
 #ifndef BDPT_WALK_ORDER
@@ -359,7 +378,8 @@ BD uint32_t packPath(uint32_t p, int path, int k) { return p | ((uint32_t)path <
 #define BDPT_WALK_STACK_LDS kStackEntries
 #endif
 constexpr int kWalkStackLds = BDPT_WALK_STACK_LDS;
-template <bool GGX, bool COUNT>
+constexpr uint32_t kParkedMiss = 1u << 30;
+template <bool GGX, bool COUNT, bool EXT>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK_WAVES_PER_EU, 8))) void walk_kernel(SceneDev S, FrameDev F, PathBuf P, uint32_t* __restrict__ head) {
   __shared__ int s_stack[kWalkStackLds * kWave];
   __shared__ uint4 s_pool[kPoolEntries];
@@ -393,14 +413,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
       if (act) rec = s_pool[nParked + (uint32_t)lane];
       __syncthreads();  // the slots may be overwritten by ready rays below
       const uint32_t p = rec.x & 0xffffffu;
-      const int path = (int)((rec.x >> 24) & 1u), k = (int)(rec.x >> 25);
+      const int path = (int)((rec.x >> 24) & 1u), k = (int)((rec.x >> 25) & 31u);
       nEye += (uint32_t)__popcll(__ballot(act && path == PATH_EYE));
       nLight += (uint32_t)__popcll(__ballot(act && path == PATH_LIGHT));
       bool survive = false;
       f3 L = mk(0);
       if (act) {
-        const int prim = (int)rec.y;
+        const bool miss = EXT ? (rec.x & kParkedMiss) != 0u : (int)rec.y < 0;
+        const int prim = miss ? -1 : (int)rec.y;
         const f3 o = ldPlane3(P, path, k, F_POS, p);
+        // what the eye ray that left vertex k found where it ended (EXT): added to the path's pixel below
+        f3 found = mk(0);
+        bool haveFound = false;
         if (prim >= 0) {
           const uint32_t seed = (path == PATH_EYE) ? P.seedE[p] : P.seedL[p];
           const f3 thr = ldPlane3(P, path, k, F_COL, p);
@@ -420,7 +444,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
           v.pdf = pdf;
           storeVtx(P, path, k + 1, p, v);
           survive = (k + 2 <= D);  // k + 1 < maxK
+          if (EXT && path == PATH_EYE && (F.p.flags & BDPT_PARAM_EMISSIVE_HITS) &&
+              (sd.emissive.x > 0.0f || sd.emissive.y > 0.0f || sd.emissive.z > 0.0f)) {
+            found = thr * sd.emissive;
+            haveFound = true;
+          }
         } else {
+          if (EXT && path == PATH_EYE && (F.p.flags & BDPT_PARAM_ENV_ON_MISS)) {
+            const f3 dir = mk(__uint_as_float(rec.y), __uint_as_float(rec.z), __uint_as_float(rec.w));
+            const f3 env = F.envMap ? envLookup(F.envMap, F.envW, F.envH, dir) : ld3(F.envColor);
+            found = ldPlane3(P, path, k, F_COL, p) * env;
+            haveFound = true;
+          }
           Vtx g = zeroVtx();
           if (path == PATH_EYE && k == 1) {
             g.pos = o;  // payload still holds initPayload's values (RayPathData.hlsli:69-86)
@@ -437,6 +472,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
             P.lightLast[p] = (uint8_t)(k + 1);
             P.lightReal[p] = (uint8_t)k;
           }
+        }
+        if (EXT && haveFound) {  // path-tracing strategy of k + 1 edges: uniform 1/edges, clamped, no saturate (as NEE terms)
+          f3 term = clampVec(found / (float)(k + 1), F.p.clampUpper);
+          if (isnan3(term)) term = mk(0);
+          float4* out4 = reinterpret_cast<float4*>(F.out);
+          const size_t pix = P.pix[p];
+          float4 acc = out4[pix];
+          acc.x = acc.x + term.x;
+          acc.y = acc.y + term.y;
+          acc.z = acc.z + term.z;
+          acc.w = acc.w + 1.0f;
+          out4[pix] = acc;
         }
       }
       // survivors -> ready rays (origin = the stored vertex k+1, re-read at pick-up)
@@ -563,8 +610,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
     const unsigned long long finMask = __ballot(finished);
     if (finMask) {
       if (finished) {
+        const bool miss = T.best.prim < 0;
         s_pool[nParked + (uint32_t)__popcll(finMask & laneBelow)] =
-            make_uint4(id, (uint32_t)T.best.prim, __float_as_uint(T.best.u), __float_as_uint(T.best.v));
+            (EXT && miss) ? make_uint4(id | kParkedMiss, __float_as_uint(T.d.x), __float_as_uint(T.d.y), __float_as_uint(T.d.z))
+                          : make_uint4(id, (uint32_t)T.best.prim, __float_as_uint(T.best.u), __float_as_uint(T.best.v));
         trav = false;
       }
       nParked += (uint32_t)__popcll(finMask);
@@ -1311,18 +1360,26 @@ void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hip
 void launchWalk(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st) {
   if (!P.Np || F.p.maxDepth < 1) return;
   const bool cnt = (F.p.flags & BDPT_PARAM_COUNTERS) != 0, ggx = F.p.matIndex == 0;
-  uint32_t& g = G.walk[(ggx ? 2 : 0) + (cnt ? 1 : 0)];
+  const bool ext = (F.p.flags & (BDPT_PARAM_ENV_ON_MISS | BDPT_PARAM_EMISSIVE_HITS)) != 0;
+  uint32_t& g = G.walk[(ext ? 4 : 0) + (ggx ? 2 : 0) + (cnt ? 1 : 0)];
   // at most two sub-paths per pixel: a small tile does not need the whole persistent grid
   const uint32_t need = blocksFor((uint64_t)2 * P.Np);
-#define BDPT_LAUNCH_WALK(GGX, CNT)                                                                        \
-  {                                                                                                      \
-    if (!g) g = persistentGrid(walk_kernel<GGX, CNT>, numCUs);                                            \
-    hipLaunchKernelGGL((walk_kernel<GGX, CNT>), dim3(std::min(g, need)), dim3(kWave), 0, st, S, F, P, P.qhead); \
+#define BDPT_LAUNCH_WALK(GGX, CNT, EXT)                                                                        \
+  {                                                                                                           \
+    if (!g) g = persistentGrid(walk_kernel<GGX, CNT, EXT>, numCUs);                                            \
+    hipLaunchKernelGGL((walk_kernel<GGX, CNT, EXT>), dim3(std::min(g, need)), dim3(kWave), 0, st, S, F, P, P.qhead); \
   }
-  if (ggx && cnt) BDPT_LAUNCH_WALK(true, true)
-  else if (ggx) BDPT_LAUNCH_WALK(true, false)
-  else if (cnt) BDPT_LAUNCH_WALK(false, true)
-  else BDPT_LAUNCH_WALK(false, false)
+  if (ext) {
+    if (ggx && cnt) BDPT_LAUNCH_WALK(true, true, true)
+    else if (ggx) BDPT_LAUNCH_WALK(true, false, true)
+    else if (cnt) BDPT_LAUNCH_WALK(false, true, true)
+    else BDPT_LAUNCH_WALK(false, false, true)
+  } else {
+    if (ggx && cnt) BDPT_LAUNCH_WALK(true, true, false)
+    else if (ggx) BDPT_LAUNCH_WALK(true, false, false)
+    else if (cnt) BDPT_LAUNCH_WALK(false, true, false)
+    else BDPT_LAUNCH_WALK(false, false, false)
+  }
 #undef BDPT_LAUNCH_WALK
 }
 

@@ -203,6 +203,17 @@ typedef struct bdpt_params {
  * without the flag (lets a host keep several frames in flight without a per-frame read-back;
  * raysPrimary in bdpt_get_counters stays one frame's worth). */
 #define BDPT_PARAM_KEEP_COUNTERS 512u
+/* Lighting the reference leaves out of its walks (RayMiss returns black, globalIlluminationRay.hlsli:14-19; emissive is
+ * only added for the primary hit, BDPTMain.rt.hlsl:155-158).  Off by default = the
+ * reference's image.  Build definitions, both for the EYE walk only and both weighted like the path-tracing strategy
+ * of the same length (uniform 1/edges, as the reference weights its NEE terms), clamped with gClampUpper, added
+ * without saturate after the pixel's own emissive term and before the NEE terms, in bounce order:
+ *   ENV_ON_MISS    a ray leaving eye vertex k that misses adds cameraPath[k].color * environment(dir) / (k + 1); the
+ *                  environment is the lat-long lookup of the G-buffer pass's miss shader
+ *                  (lightProbeGBuffer.rt.hlsl:63-74) on the map given to bdpt_set_environment, else its constant colour
+ *   EMISSIVE_HITS  a ray leaving eye vertex k that hits an emissive surface adds cameraPath[k].color * emissive / (k + 1) */
+#define BDPT_PARAM_ENV_ON_MISS 1024u
+#define BDPT_PARAM_EMISSIVE_HITS 2048u
 
 /* RayGenCB of lightProbeGBuffer.rt.hlsl:45-52 + the miss shader's env map. */
 typedef struct bdpt_gbuffer_params {
@@ -270,6 +281,14 @@ typedef struct bdpt_counters {
   uint64_t raysConnectLazy;   /* subset of raysConnect traced by the gather stage for zero-valued pairs */
 } bdpt_counters;
 
+/* The environment secondary misses see (BDPT_PARAM_ENV_ON_MISS): an RGBA32F lat-long map (device pointer for
+ * bdpt_set_environment, host pointer for the oracle) or, when envMap is NULL, a constant colour. */
+typedef struct bdpt_environment {
+  const float* envMap;
+  uint32_t width, height;
+  float color[4];
+} bdpt_environment;
+
 typedef struct bdpt_bvh_info {
   uint32_t numNodes;
   uint32_t numTriangles;
@@ -294,6 +313,9 @@ const char* bdpt_last_error(const bdpt_ctx* ctx);
 int bdpt_set_scene(bdpt_ctx* ctx, const bdpt_scene_desc* scene);
 int bdpt_get_bvh_info(const bdpt_ctx* ctx, bdpt_bvh_info* out);
 int bdpt_set_camera(bdpt_ctx* ctx, const bdpt_camera* cam);
+/* ResourceManager's "EnvironmentMap" channel as the BDPT pass would bind it (BDPTPass.cpp:29 requests it; no shader of
+ * the pass reads it in the reference).  NULL = none (black).  Only read with BDPT_PARAM_ENV_ON_MISS. */
+int bdpt_set_environment(bdpt_ctx* ctx, const bdpt_environment* env);
 
 /* Host-only (no GPU, no context): run the acceleration-structure builder on a scene (geometry only: every triangle
  * opaque) and check its invariants — every triangle referenced, every leaf entry in exactly one leaf, the pieces of

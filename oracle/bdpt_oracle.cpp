@@ -242,6 +242,10 @@ struct oracle_scene {
   std::vector<BNode> nodes;
   std::vector<uint32_t> order;  // BVH leaf order -> triangle id
   bool hasUv = false, hasBit = false;
+  // environment of the BDPT pass (BDPT_PARAM_ENV_ON_MISS: a build definition, include/bdpt.h)
+  std::vector<float> envMap;
+  uint32_t envW = 0, envH = 0;
+  float envColor[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -823,6 +827,8 @@ struct RayPayload {
   float pdfForward;
   f3 rayOrigin, rayDir;
   bool terminated;
+  f3 extra;       // not in the reference: radiance the ray picked up where it ended (environment on a miss, emissive
+  bool hasExtra;  // on a hit), for BDPT_PARAM_ENV_ON_MISS / BDPT_PARAM_EMISSIVE_HITS
 };
 inline RayPayload initPayload(f3 rayOrigin, f3 rayDir, f3 color, uint32_t seed) {
   RayPayload p;
@@ -836,6 +842,8 @@ inline RayPayload initPayload(f3 rayOrigin, f3 rayDir, f3 color, uint32_t seed) 
   p.isSpecular = false;
   p.pdfForward = 0;
   p.terminated = false;
+  p.extra = mk(0);
+  p.hasExtra = false;
   return p;
 }
 inline PathVertex fromPayload(const RayPayload& p) {
@@ -852,18 +860,40 @@ inline PathVertex fromPayload(const RayPayload& p) {
   return v;
 }
 
+inline float atan2_WAR(float y, float x);
+// The environment a ray that leaves the scene sees: the lat-long lookup of the G-buffer pass's miss shader
+// (CP/lightProbeGBuffer.rt.hlsl:63-74) on the BDPT pass's own environment (BDPT_PARAM_ENV_ON_MISS, a build definition).
+inline f3 environmentOf(const oracle_scene& s, f3 dir) {
+  if (s.envMap.empty()) return mk(s.envColor[0], s.envColor[1], s.envColor[2]);
+  f3 p = normalize(dir);
+  float u = (1.f + atan2_WAR(p.x, -p.z) * kInvPi) * 0.5f;
+  float v = det_acos(p.y) * kInvPi;
+  uint32_t ex = (uint32_t)(u * (float)s.envW), ey = (uint32_t)(v * (float)s.envH);
+  if (ex < s.envW && ey < s.envH) return ld3(s.envMap.data() + ((size_t)ey * s.envW + ex) * 4);
+  return mk(0);
+}
+
 // BDPT/globalIlluminationRay.hlsli:1-45 (shootRay + RayMiss + RayAnyHit + RayClosestHit + handleIndirectRayHit)
 void shootRay(const Globals& g, Tally& tl, int stage, RayPayload& pl) {
   Ray r{pl.rayOrigin, pl.rayDir, g.p.minT, 1.0e38f};
   tl.rays[stage]++;
+  pl.hasExtra = false;
   Hit h = traceRay(*g.s, r, 0, g.flags, &tl.nodeC, &tl.triC);
   if (h.prim < 0) {  // RayMiss
+    if (stage == 1 && (g.p.flags & BDPT_PARAM_ENV_ON_MISS)) {  // not in the reference
+      pl.extra = environmentOf(*g.s, pl.rayDir);
+      pl.hasExtra = true;
+    }
     pl.color = mk(0);
     pl.terminated = true;
     return;
   }
   // RayClosestHit: getHitShadingData(attribs, WorldRayOrigin()) — V points at the ray origin
   ShadingData sd = prepareShadingData(*g.s, (uint32_t)h.prim, h.u, h.v, pl.rayOrigin, false);
+  if (stage == 1 && (g.p.flags & BDPT_PARAM_EMISSIVE_HITS) && (sd.emissive.x > 0.0f || sd.emissive.y > 0.0f || sd.emissive.z > 0.0f)) {
+    pl.extra = sd.emissive;  // not in the reference
+    pl.hasExtra = true;
+  }
   f3 L;
   float pdf;
   bool isSpecular;
@@ -1023,8 +1053,14 @@ void bdptPixel(const Globals& g, Tally& tl, oracle_frame* f, uint32_t x, uint32_
     cameraPath[1] = v;
   }
   RayPayload payload = initPayload(worldPos, outDir, hitThroughput, randSeed);
+  f3 walkTerms[BDPT_MAX_DEPTH + 2];  // BDPT_PARAM_ENV_ON_MISS / _EMISSIVE_HITS: what the ray that left eye vertex `depth` found
+  uint32_t numWalkTerms = 0;
   for (uint32_t depth = 1; depth < D && !payload.terminated; depth++) {  // :106-112
     shootRay(g, tl, 1, payload);
+    if (payload.hasExtra) {  // path-tracing strategy of depth + 1 edges, weighted like the NEE terms (uniform 1/edges)
+      f3 term = clampVec(g, (cameraPath[depth].color * payload.extra) / (float)(depth + 1));
+      walkTerms[numWalkTerms++] = isnan3(term) ? mk(0) : term;
+    }
     cameraPath[depth + 1] = fromPayload(payload);
   }
   randSeed = payload.rndSeed;  // :115 (never advanced: quirk 1)
@@ -1059,6 +1095,12 @@ void bdptPixel(const Globals& g, Tally& tl, oracle_frame* f, uint32_t x, uint32_
     out[1] += ge[1];
     out[2] += ge[2];
     out[3] += ge[3];
+  }
+  for (uint32_t i = 0; i < numWalkTerms; i++) {  // after the pixel's own emissive, before the NEE terms, bounce order
+    out[0] = out[0] + walkTerms[i].x;
+    out[1] = out[1] + walkTerms[i].y;
+    out[2] = out[2] + walkTerms[i].z;
+    out[3] = out[3] + 1.0f;
   }
   const bool doNee = !(g.p.flags & BDPT_PARAM_NO_NEE);
   const bool doSplat = !(g.p.flags & BDPT_PARAM_NO_SPLAT);
@@ -1316,6 +1358,18 @@ oracle_scene* oracle_scene_create(const bdpt_scene_desc* d) {
 }
 
 void oracle_scene_destroy(oracle_scene* s) { delete s; }
+
+void oracle_set_environment(oracle_scene* s, const bdpt_environment* env) {
+  if (!s) return;
+  s->envMap.clear();
+  s->envW = s->envH = 0;
+  for (int k = 0; k < 4; k++) s->envColor[k] = env ? env->color[k] : 0.0f;
+  if (env && env->envMap && env->width && env->height) {
+    s->envW = env->width;
+    s->envH = env->height;
+    s->envMap.assign(env->envMap, env->envMap + (size_t)env->width * env->height * 4);
+  }
+}
 
 int oracle_gbuffer(const oracle_scene* s, const bdpt_camera* cam, const bdpt_gbuffer_params* gp, const float* envMapHost,
                    oracle_frame* f, uint32_t flags, int threads) {

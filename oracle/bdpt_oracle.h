@@ -38,6 +38,8 @@ typedef struct oracle_scene oracle_scene;
 /* Copies the scene, builds the oracle's own (median-split) BVH. */
 oracle_scene* oracle_scene_create(const bdpt_scene_desc* desc);
 void oracle_scene_destroy(oracle_scene* s);
+/* Environment for BDPT_PARAM_ENV_ON_MISS (include/bdpt.h); envMap is a HOST pointer here and is copied. NULL = black. */
+void oracle_set_environment(oracle_scene* s, const bdpt_environment* env);
 
 #define ORACLE_BRUTE_FORCE 1u /* intersect every triangle instead of using the BVH */
 /* Cross-check hook (tests/test_oracle_cross_check.py): treat every vertex-connection shadow ray as unoccluded.

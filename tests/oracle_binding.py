@@ -30,6 +30,7 @@ def load_oracle(abi):
     lib.oracle_scene_create.restype = C.c_void_p
     lib.oracle_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
     lib.oracle_scene_destroy.argtypes = [C.c_void_p]
+    lib.oracle_set_environment.argtypes = [C.c_void_p, C.POINTER(abi.Environment)]
     lib.oracle_gbuffer.restype = C.c_int
     lib.oracle_gbuffer.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.GBufferParams), C.c_void_p,
                                    C.POINTER(OracleFrame), C.c_uint32, C.c_int]
@@ -82,6 +83,17 @@ class OracleRender:
         if self.scene:
             self.lib.oracle_scene_destroy(self.scene)
             self.scene = None
+
+    def set_environment(self, env_map=None, color=(0.0, 0.0, 0.0, 0.0)):
+        """env_map: float32 [h, w, 4] host array (lat-long) or None for the constant colour."""
+        e = self.abi.Environment()
+        if env_map is not None:
+            self._env_keep = np.ascontiguousarray(env_map, np.float32)
+            e.envMap = self._env_keep.ctypes.data
+            e.height, e.width = self._env_keep.shape[0], self._env_keep.shape[1]
+        for i in range(4):
+            e.color[i] = float(color[i])
+        self.lib.oracle_set_environment(self.scene, C.byref(e))
 
     def gbuffer(self, cam, gparams, env=None, flags=0, threads=8):
         rc = self.lib.oracle_gbuffer(self.scene, C.byref(cam), C.byref(gparams), _p(env) if env is not None else None,

@@ -434,6 +434,49 @@ def test_thin_lens_random_jitter_and_env_map(pkg, ob):
     scene.close()
 
 
+def test_environment_and_emissive_lighting_on_secondary_rays(pkg, ob):
+    """SURVEY.md §8f-3, second half (BDPT_PARAM_ENV_ON_MISS / BDPT_PARAM_EMISSIVE_HITS, build definitions in
+    include/bdpt.h; the reference's RayMiss returns black and only the primary hit's emissive is added): eye-walk rays
+    that leave the scene pick up the environment (constant colour or lat-long map), those that hit an emissive surface
+    its emission; bit-exact against the oracle for both material models, and the default image is untouched."""
+    import torch
+    A = pkg.abi
+    scene = pkg.Scene.atrium(3, 20000)  # open to the sky, with emissive lamp bodies
+    rng = np.random.default_rng(77)
+    ew, eh = 48, 24
+    env = (rng.random((eh, ew, 4), dtype=np.float32) * 1.5).astype(np.float32)
+    env_dev = torch.from_numpy(env).cuda()
+    for mat in (0, 1):
+        pipe = pkg.FramePipeline(scene, 96, 64, max_depth=6, mat_index=mat)
+        images = {}
+        for name, flags, use_map in (("default", 0, False), ("env_colour", A.PARAM_ENV_ON_MISS, False), ("env_map", A.PARAM_ENV_ON_MISS, True),
+                                     ("emissive", A.PARAM_EMISSIVE_HITS, False), ("both", A.PARAM_ENV_ON_MISS | A.PARAM_EMISSIVE_HITS, True)):
+            if use_map:
+                pipe.ctx.set_environment(env_dev.data_ptr(), ew, eh)
+            else:
+                pipe.ctx.set_environment(None, 0, 0, (0.5, 0.5, 0.8, 1.0))
+            pipe.gbuffer_frame, pipe.bdpt_frame = 0xdeadbeef, 0x1337
+            gp, p = pipe.render_frame(extra_flags=flags)
+            torch.cuda.synchronize()
+            orc = ob.OracleRender(pkg.abi, scene.desc, pipe.W, pipe.H)
+            orc.set_environment(env if use_map else None, (0.5, 0.5, 0.8, 1.0))
+            orc.gbuffer(pipe.cam, gp)
+            orc.bdpt(pipe.cam, p)
+            orc.resolve()
+            gpu, ref = pipe.output.cpu().numpy().copy(), orc.image()
+            assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), (mat, name, int((gpu != ref).any(axis=-1).sum()))
+            images[name] = gpu
+            orc.close()
+        valid = images["default"][..., 3] > 0
+        for name in ("env_colour", "env_map", "emissive", "both"):
+            changed = (images[name] != images["default"]).any(axis=-1)
+            assert changed.any(), name          # the switch does something on this scene ...
+            assert (images[name][..., :3] >= images["default"][..., :3] - 1e-6)[valid & ~changed].all()
+        assert images["env_colour"][..., :3].sum() > images["default"][..., :3].sum()  # ... and it adds light
+        pipe.close()
+    scene.close()
+
+
 def test_hip_path_against_committed_golden_fixtures(pkg, gpu_ctx):
     """The same comparisons without the live oracle: tests/golden/oracle_golden.npz (written by make_golden.py)
     holds RNG streams, BSDF records, hit records and Cornell images; the HIP path must reproduce them bit for bit."""

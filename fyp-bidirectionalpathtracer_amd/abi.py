@@ -177,6 +177,7 @@ PROTOTYPES = {
     "bdpt_scene_destroy": (None, [C.c_void_p]),
     "bdpt_image_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64,
                                   C.c_char_p, C.c_uint32]),
+    "bdpt_image_load_hdr": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint32]),
     "bdpt_scene_get_desc": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "bdpt_scene_get_camera": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(Camera)]),
 }

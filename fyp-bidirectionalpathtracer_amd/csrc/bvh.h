@@ -63,12 +63,13 @@ constexpr uint32_t kTriNonOpaque = 1u, kTriDoubleSided = 2u;
 //   word 10   childBase: record index of the first child
 //   word 11   record offset of child c from childBase in byte c (child 0: 0)
 // Device references: ref >= 0 interior record index; ref < 0 leaf, ~ref = record index of its first triangle; the last
-// triangle of a leaf carries kTriLastOfLeaf in its flags.  The root is record 0; one zero pad record ends the array.
+// triangle of a leaf carries kTriLastOfLeaf in its flags.  The root is record 0; kBvhPadRecs zero pad records end the array.
 struct alignas(16) BvhRec {
   uint32_t w[12];
 };
 static_assert(sizeof(BvhRec) == 48, "record must be 48 bytes");
 constexpr uint32_t kTriLastOfLeaf = 4u;  // BvhTri::flags bit set by packBvh (device-side records only)
+constexpr uint32_t kBvhPadRecs = 4;      // zero records behind the array (a leaf fetch reads past a leaf's last triangle)
 
 struct Bvh {
   std::vector<BvhNode> nodes;

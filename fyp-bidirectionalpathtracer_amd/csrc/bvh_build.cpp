@@ -1088,7 +1088,7 @@ bool packBvh(Bvh& bvh, int threads) {
     }
     if (next >= 0x7fffffffull) return false;
   }
-  bvh.recs.assign((size_t)next + 1, BvhRec{});  // + one pad record: the device fetches two records per leaf visit
+  bvh.recs.assign((size_t)next + kBvhPadRecs, BvhRec{});  // + zero pad records: the device fetches up to four records per leaf visit
   bool ok = true;
   std::mutex failMutex;
   parallelFor(nn, threads, [&](size_t i0, size_t i1, int) {

@@ -415,9 +415,11 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   };
   walkPacked(0, 0, 0);
   if (!ok) return say(why);
-  for (size_t i = 0; i + 1 < used.size(); i++)  // (the last record is the pad behind the array)
+  if (used.size() < kBvhPadRecs) return say("pad records missing");
+  for (size_t i = 0; i + kBvhPadRecs < used.size(); i++)  // (the last kBvhPadRecs records are the pad behind the array)
     if (!used[i]) return say("a packed record is not referenced");
-  if (used.back()) return say("the pad record is referenced");
+  for (size_t i = used.size() - kBvhPadRecs; i < used.size(); i++)
+    if (used[i]) return say("a pad record is referenced");
   return BDPT_OK;
 }
 

@@ -16,11 +16,16 @@
 // What the loader does with the channel count follows Bitmap.cpp:104-126: 32-bit images keep their alpha (and so
 // make a material's alpha mode Mask, Material.cpp:120-126), 24-bit and grey images have none.
 #include <cstdint>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
 namespace bdpt {
+// Header dimensions are not trusted: a few hundred bytes can announce a 65535 x 65535 image.
+constexpr uint32_t kMaxImageSide = 16384;
+constexpr uint64_t kMaxImageTexels = 1ull << 28;
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -181,7 +186,7 @@ bool zlibInflate(const uint8_t* d, size_t n, std::vector<uint8_t>& out, size_t e
   if (n < 6 || (d[0] & 0x0f) != 8 || ((d[0] << 8) | d[1]) % 31 != 0 || (d[1] & 0x20)) return false;
   BitReader br(d + 2, n - 2);
   out.clear();
-  out.reserve(expected);
+  out.reserve(std::min<size_t>(expected, n * 1032 + 64));  // (a stored header's size is not trusted: DEFLATE expands at most 1032 : 1)
   if (!inflateRaw(br, out, expected)) return false;
   // Adler-32 of the output closes the stream
   br.alignByte();
@@ -245,8 +250,8 @@ bool decodePng(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, st
     }
     p += 12 + (size_t)len;
   }
-  if (!w || !h || w > 32768 || h > 32768 || ctype < 0) {
-    err = "bad PNG header";
+  if (!w || !h || w > kMaxImageSide || h > kMaxImageSide || (uint64_t)w * h > kMaxImageTexels || ctype < 0) {
+    err = "bad PNG header (or dimensions beyond the loader's limit)";
     return false;
   }
   if (interlace) {
@@ -373,10 +378,12 @@ struct JBits {
   uint32_t acc = 0;
   int cnt = 0;
   bool marker = false;  // ran into a marker: feed zeros (T.81 F.2.2.5)
+  int starved = 0;      // zero bytes fed after a marker or the end of the file
   JBits(const uint8_t* d, size_t len, size_t at) : p(d), n(len), pos(at) {}
   void fill() {
     while (cnt <= 24) {
       int b = 0;
+      if (marker || pos >= n) starved++;
       if (!marker && pos < n) {
         b = p[pos];
         if (b == 0xff) {
@@ -407,7 +414,11 @@ struct JBits {
     acc = 0;
     cnt = 0;
     marker = false;
+    starved = 0;
   }
+  // The entropy data ended (marker or end of file) well before the block being decoded: a truncated or corrupt scan.
+  // (A few zero bytes are legitimate: the decoder reads ahead of the last MCU.)
+  bool ranDry() const { return starved > 8; }
 };
 
 inline int jDecode(JBits& br, const JHuff& h) {
@@ -541,7 +552,7 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
   JHuff dc[4], ac[4];
   JComp comp[3];
   int ncomp = 0, W = 0, H = 0, restart = 0;
-  bool adobe = false;
+  bool adobe = false, sofBaseline = true, wideTables = false;
   int adobeTransform = -1;
   size_t p = 2;
   while (p + 4 <= n) {
@@ -570,6 +581,7 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
       while (q < sl) {
         const int pq = s[q] >> 4, tq = s[q] & 15;
         q++;
+        wideTables = wideTables || pq != 0;
         if (tq > 3 || q + (pq ? 128u : 64u) > sl) {
           err = "bad JPEG quantisation table";
           return false;
@@ -614,6 +626,11 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
         err = "unsupported JPEG component count";
         return false;
       }
+      if (W > (int)kMaxImageSide || H > (int)kMaxImageSide || (uint64_t)W * (uint64_t)H > kMaxImageTexels) {
+        err = "JPEG dimensions exceed the loader's limit";
+        return false;
+      }
+      sofBaseline = (m == 0xc0);
       for (int i = 0; i < ncomp; i++) {
         comp[i].id = s[6 + i * 3];
         comp[i].h = s[7 + i * 3] >> 4;
@@ -635,6 +652,10 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
     } else if (m == 0xda) {  // SOS: the one scan of a baseline file
       if (!ncomp || sl < 1 + (size_t)s[0] * 2 + 3 || s[0] != ncomp) {
         err = "unsupported JPEG scan layout";
+        return false;
+      }
+      if (wideTables && sofBaseline) {  // T.81 B.2.4.1: Pq = 0 for 8-bit sample precision
+        err = "16-bit quantisation tables in a baseline JPEG";
         return false;
       }
       for (int i = 0; i < ncomp; i++) {
@@ -688,13 +709,17 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
               for (int bx = 0; bx < c.h; bx++) {
                 std::memset(coef, 0, sizeof(coef));
                 const int t = jDecode(br, dc[c.td]);
-                if (t < 0 || t > 15) {
+                if (t < 0 || t > 11 || br.ranDry()) {  // T.81 F.1.2.1.1: DC difference categories 0-11 for 8-bit samples
                   err = "corrupt JPEG entropy data";
                   return false;
                 }
                 const int diff = t ? jExtend(br.get(t), t) : 0;
                 c.pred += diff;
-                coef[0] = c.pred * qt[c.tq][0];
+                if (c.pred > 32767 || c.pred < -32768) {  // the prediction of valid data stays within 11 + 3 bits
+                  err = "corrupt JPEG entropy data";
+                  return false;
+                }
+                coef[0] = c.pred * (int)qt[c.tq][0];
                 for (int k = 1; k < 64;) {
                   const int rs = jDecode(br, ac[c.ta]);
                   if (rs < 0) {
@@ -702,6 +727,10 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
                     return false;
                   }
                   const int r = rs >> 4, sz = rs & 15;
+                  if (sz > 10 || br.ranDry()) {  // AC categories 1-10 for 8-bit samples
+                    err = "corrupt JPEG entropy data";
+                    return false;
+                  }
                   if (sz == 0) {
                     if (r == 15) {
                       k += 16;
@@ -811,6 +840,124 @@ bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, s
   }
   err = "JPEG file has no scan";
   return false;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Radiance .hdr (RGBE), the format of the reference's light probes (Data/ MonValley_*.hdr; loaded through
+// createTextureFromFile -> FreeImage, SharedUtils/ResourceManager.cpp:96-110).  Flat and new-style run-length
+// scanlines, "-Y h +X w" (top row first) and "+Y h +X w" (bottom row first) orientations.  RGBE -> float as
+// FreeImage's PluginHDR does: mantissa * 2^(e - 136), no half-unit offset; rgba32f: row 0 = top, alpha 1.
+// ---------------------------------------------------------------------------------------------------------------
+bool decodeHdr(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<float>& rgba32f, std::string& err) {
+  if (n < 11 || (std::memcmp(d, "#?RADIANCE", 10) != 0 && std::memcmp(d, "#?RGBE", 6) != 0)) {
+    err = "not a Radiance .hdr file";
+    return false;
+  }
+  size_t p = 0;
+  auto line = [&](std::string& out) {
+    out.clear();
+    while (p < n && d[p] != '\n') {
+      if (out.size() < 512) out.push_back((char)d[p]);
+      p++;
+    }
+    if (p >= n) return false;
+    p++;
+    if (!out.empty() && out.back() == '\r') out.pop_back();
+    return true;
+  };
+  std::string ln;
+  bool formatOk = false;
+  for (;;) {  // header lines up to the empty one
+    if (!line(ln)) {
+      err = "truncated .hdr header";
+      return false;
+    }
+    if (ln.empty()) break;
+    if (ln.rfind("FORMAT=", 0) == 0) {
+      if (ln != "FORMAT=32-bit_rle_rgbe") {
+        err = "unsupported .hdr pixel format (only 32-bit_rle_rgbe)";
+        return false;
+      }
+      formatOk = true;
+    }
+  }
+  (void)formatOk;  // (files without a FORMAT line are RGBE by definition)
+  if (!line(ln)) {
+    err = "truncated .hdr header";
+    return false;
+  }
+  char sy = 0, sx = 0;
+  unsigned long hh = 0, ww = 0;
+  if (std::sscanf(ln.c_str(), "%cY %lu %cX %lu", &sy, &hh, &sx, &ww) != 4 || (sy != '-' && sy != '+') || sx != '+' || !hh || !ww) {
+    err = "unsupported .hdr orientation (expected -Y h +X w or +Y h +X w)";
+    return false;
+  }
+  if (ww > kMaxImageSide || hh > kMaxImageSide || (uint64_t)ww * hh > kMaxImageTexels) {
+    err = ".hdr dimensions exceed the loader's limit";
+    return false;
+  }
+  const uint32_t W = (uint32_t)ww, H = (uint32_t)hh;
+  std::vector<uint8_t> row((size_t)W * 4);
+  rgba32f.assign((size_t)W * H * 4, 1.0f);
+  for (uint32_t y = 0; y < H; y++) {
+    if (n - p < 4) {
+      err = "truncated .hdr pixel data";
+      return false;
+    }
+    if (W >= 8 && W < 32768 && d[p] == 2 && d[p + 1] == 2 && (((uint32_t)d[p + 2] << 8) | d[p + 3]) == W) {
+      p += 4;  // new-style RLE: the four channels of the scanline one after another
+      for (int c = 0; c < 4; c++) {
+        uint32_t x = 0;
+        while (x < W) {
+          if (p >= n) {
+            err = "truncated .hdr pixel data";
+            return false;
+          }
+          uint32_t count = d[p++];
+          if (count > 128) {  // a run
+            count -= 128;
+            if (!count || x + count > W || p >= n) {
+              err = "corrupt .hdr run";
+              return false;
+            }
+            const uint8_t v = d[p++];
+            for (uint32_t k = 0; k < count; k++) row[(size_t)(x++) * 4 + (size_t)c] = v;
+          } else {  // literals
+            if (!count || x + count > W || n - p < count) {
+              err = "corrupt .hdr run";
+              return false;
+            }
+            for (uint32_t k = 0; k < count; k++) row[(size_t)(x++) * 4 + (size_t)c] = d[p++];
+          }
+        }
+      }
+    } else {  // flat scanline (old-style repeat markers are not produced by any current writer and are refused)
+      if (n - p < (size_t)W * 4) {
+        err = "truncated .hdr pixel data";
+        return false;
+      }
+      for (uint32_t x = 0; x < W; x++)
+        if (d[p + (size_t)x * 4] == 1 && d[p + (size_t)x * 4 + 1] == 1 && d[p + (size_t)x * 4 + 2] == 1) {
+          err = "old-style run-length .hdr scanlines are not supported";
+          return false;
+        }
+      std::memcpy(row.data(), d + p, (size_t)W * 4);
+      p += (size_t)W * 4;
+    }
+    const uint32_t oy = (sy == '-') ? y : H - 1 - y;
+    float* o = rgba32f.data() + (size_t)oy * W * 4;
+    for (uint32_t x = 0; x < W; x++) {
+      const uint8_t* q = &row[(size_t)x * 4];
+      const float f = q[3] ? std::ldexp(1.0f, (int)q[3] - 136) : 0.0f;
+      o[(size_t)x * 4] = (float)q[0] * f;
+      o[(size_t)x * 4 + 1] = (float)q[1] * f;
+      o[(size_t)x * 4 + 2] = (float)q[2] * f;
+    }
+  }
+  width = W;
+  height = H;
+  return true;
 }
 
 }  // namespace bdpt

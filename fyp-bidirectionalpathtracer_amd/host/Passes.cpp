@@ -1,6 +1,8 @@
 // Passes.cpp — host mirror of the reference's pass framework and passes over the C ABI.
 #include "Passes.h"
 
+#include "../../include/bdpt_scene.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -200,7 +202,32 @@ void ResourceManager::clearTexture(Texture::SharedPtr& tex, const vec4& c) {
   if (tex) tex->clear(c, mpContext->getStream());
 }
 bool ResourceManager::updateEnvironmentMap(const std::string& filename) {
-  if (filename != "" && filename != "Black") return false;  // image files: out of scope (no loader, HDR blob absent)
+  if (filename != "" && filename != "Black") {
+    // createTextureFromFile(filename, false, false): a Radiance .hdr probe as it is, any other supported image as
+    // 8-bit values / 255 without sRGB decoding (loadAsSrgb = false), both as RGBA32F
+    uint32_t w = 0, h = 0;
+    std::vector<float> px;
+    char msg[256] = {0};
+    const bool isHdr = filename.size() > 4 && (filename.substr(filename.size() - 4) == ".hdr" || filename.substr(filename.size() - 4) == ".HDR");
+    if (isHdr) {
+      if (bdpt_image_load_hdr(filename.c_str(), &w, &h, nullptr, 0, msg, sizeof(msg)) != BDPT_OK) return false;
+      px.resize((size_t)w * h * 4);
+      if (bdpt_image_load_hdr(filename.c_str(), &w, &h, px.data(), px.size(), msg, sizeof(msg)) != BDPT_OK) return false;
+    } else {
+      uint32_t alpha = 0;
+      if (bdpt_image_load(filename.c_str(), &w, &h, &alpha, nullptr, 0, msg, sizeof(msg)) != BDPT_OK) return false;
+      std::vector<uint8_t> b((size_t)w * h * 4);
+      if (bdpt_image_load(filename.c_str(), &w, &h, &alpha, b.data(), b.size(), msg, sizeof(msg)) != BDPT_OK) return false;
+      px.resize(b.size());
+      for (size_t i = 0; i < b.size(); i++) px[i] = (float)b[i] / 255.0f;
+    }
+    Texture::SharedPtr envMap = Texture::create2D(w, h, ResourceFormat::RGBA32Float);
+    if (!envMap || !envMap->uploadRaw(mpContext->getStream(), reinterpret_cast<const uint8_t*>(px.data()), px.size() * sizeof(float))) return false;
+    const size_t found = filename.find_last_of("/\\");
+    mEnvMapFilename = found == std::string::npos ? filename : filename.substr(found + 1);
+    manageTextureResource(kEnvironmentMap, envMap);
+    return true;
+  }
   Texture::SharedPtr tmpEnv = Texture::create2D(128, 128, ResourceFormat::RGBA32Float);
   if (!tmpEnv) return false;
   tmpEnv->clear(filename == "" ? vec4{0.5f, 0.5f, 0.8f, 1.0f} : vec4{0.0f, 0.0f, 0.0f, 1.0f}, mpContext->getStream());
@@ -435,6 +462,16 @@ void BDPTPass::execute(RenderContext* pRenderContext) {
   Camera::SharedPtr cam = mpScene->getActiveCamera();
   cam->setJitter((p.pixelJitter[0] - 0.5f) / (float)pDstTex->getWidth(), (p.pixelJitter[1] - 0.5f) / (float)pDstTex->getHeight());
   bdpt_set_camera(mpRays->ctx(), &cam->getData());
+  {  // the "EnvironmentMap" channel the pass requests (BDPTPass.cpp:29); only read with BDPT_PARAM_ENV_ON_MISS
+    Texture::SharedPtr env = mpResManager->getTexture(ResourceManager::kEnvironmentMap);
+    bdpt_environment e{};
+    if (env && env->getFormat() == ResourceFormat::RGBA32Float) {
+      e.envMap = (const float*)env->getDevicePointer();
+      e.width = env->getWidth();
+      e.height = env->getHeight();
+    }
+    bdpt_set_environment(mpRays->ctx(), &e);
+  }
   if (bdpt_execute(mpRays->ctx(), &p, &gb, (float*)pDstTex->getDevicePointer(), pRenderContext->getStream()) != BDPT_OK)
     std::fprintf(stderr, "[BDPTPass] %s\n", mpRays->lastError());
 }

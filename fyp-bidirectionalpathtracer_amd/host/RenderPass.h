@@ -34,7 +34,7 @@ class ResourceManager : public std::enable_shared_from_this<ResourceManager> {
   int32_t getTextureIndex(const std::string& channelName) const;
   uint32_t getTextureCount() const { return uint32_t(mTextures.size()); }
 
-  bool updateEnvironmentMap(const std::string& filename);  // "" = default (0.5,0.5,0.8), "Black" = black; files unsupported
+  bool updateEnvironmentMap(const std::string& filename);  // "" = default (0.5,0.5,0.8), "Black" = black, else an image file (.hdr, .png, .jpg ...)
   Texture::SharedPtr getEnvironmentMap() { return getTexture(kEnvironmentMap); }
   uvec2 getEnvironmentMapSize() const;
 

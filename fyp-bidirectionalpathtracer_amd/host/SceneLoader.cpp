@@ -164,6 +164,7 @@ bool endsWith(const std::string& s, const std::string& suf) { return s.size() >=
 // ImageDecode.cpp
 bool decodePng(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba8, int& channels, std::string& err);
 bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba8, int& channels, std::string& err);
+bool decodeHdr(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<float>& rgba32f, std::string& err);
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -781,35 +782,88 @@ struct bdpt_scene {
   bdpt::Scene::SharedPtr scene;
 };
 
+// Allocation failures and anything else thrown while decoding a file stay on this side of the C boundary.
 extern "C" int bdpt_image_load(const char* path, uint32_t* width, uint32_t* height, uint32_t* hasAlpha, uint8_t* rgba8, uint64_t cap, char* msg,
                                uint32_t msgCap) {
   if (!path || !width || !height) return BDPT_E_INVALID;
-  bdpt::Scene::Texture t;
-  bool a = false;
-  std::string why;
-  if (!bdpt::loadImage(path, t, a, &why)) {
-    if (msg && msgCap) std::snprintf(msg, msgCap, "%s", why.empty() ? "cannot read or recognise the image" : why.c_str());
+  try {
+    bdpt::Scene::Texture t;
+    bool a = false;
+    std::string why;
+    if (!bdpt::loadImage(path, t, a, &why)) {
+      if (msg && msgCap) std::snprintf(msg, msgCap, "%s", why.empty() ? "cannot read or recognise the image" : why.c_str());
+      return BDPT_E_INVALID;
+    }
+    *width = t.width;
+    *height = t.height;
+    if (hasAlpha) *hasAlpha = a ? 1u : 0u;
+    if (rgba8) {
+      if (cap < t.rgba8.size()) return BDPT_E_LIMIT;
+      std::memcpy(rgba8, t.rgba8.data(), t.rgba8.size());
+    }
+    return BDPT_OK;
+  } catch (const std::bad_alloc&) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "out of memory while decoding the image");
+    return BDPT_E_NOMEM;
+  } catch (...) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "internal error while decoding the image");
     return BDPT_E_INVALID;
   }
-  *width = t.width;
-  *height = t.height;
-  if (hasAlpha) *hasAlpha = a ? 1u : 0u;
-  if (rgba8) {
-    if (cap < t.rgba8.size()) return BDPT_E_LIMIT;
-    std::memcpy(rgba8, t.rgba8.data(), t.rgba8.size());
+}
+
+extern "C" int bdpt_image_load_hdr(const char* path, uint32_t* width, uint32_t* height, float* rgba32f, uint64_t capFloats, char* msg,
+                                   uint32_t msgCap) {
+  if (!path || !width || !height) return BDPT_E_INVALID;
+  try {
+    std::vector<uint8_t> d;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) {
+      if (msg && msgCap) std::snprintf(msg, msgCap, "cannot open %s", path);
+      return BDPT_E_INVALID;
+    }
+    uint8_t buf[65536];
+    for (size_t n; (n = std::fread(buf, 1, sizeof(buf), f)) > 0;) d.insert(d.end(), buf, buf + n);
+    std::fclose(f);
+    std::vector<float> px;
+    std::string why;
+    uint32_t w = 0, h = 0;
+    if (!bdpt::decodeHdr(d.data(), d.size(), w, h, px, why)) {
+      if (msg && msgCap) std::snprintf(msg, msgCap, "%s", why.c_str());
+      return BDPT_E_INVALID;
+    }
+    *width = w;
+    *height = h;
+    if (rgba32f) {
+      if (capFloats < px.size()) return BDPT_E_LIMIT;
+      std::memcpy(rgba32f, px.data(), px.size() * sizeof(float));
+    }
+    return BDPT_OK;
+  } catch (const std::bad_alloc&) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "out of memory while decoding the image");
+    return BDPT_E_NOMEM;
+  } catch (...) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "internal error while decoding the image");
+    return BDPT_E_INVALID;
   }
-  return BDPT_OK;
 }
 
 extern "C" bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap) {
   if (!path) return nullptr;
-  std::string err;
-  bdpt::Scene::SharedPtr s = bdpt::Scene::loadFromFile(path, &err);
-  if (!s) {
-    if (msg && msgCap) std::snprintf(msg, msgCap, "%s", err.c_str());
+  try {
+    std::string err;
+    bdpt::Scene::SharedPtr s = bdpt::Scene::loadFromFile(path, &err);
+    if (!s) {
+      if (msg && msgCap) std::snprintf(msg, msgCap, "%s", err.c_str());
+      return nullptr;
+    }
+    bdpt_scene* h = new bdpt_scene();
+    h->scene = s;
+    return h;
+  } catch (const std::bad_alloc&) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "out of memory while loading the scene");
+    return nullptr;
+  } catch (...) {
+    if (msg && msgCap) std::snprintf(msg, msgCap, "internal error while loading the scene");
     return nullptr;
   }
-  bdpt_scene* h = new bdpt_scene();
-  h->scene = s;
-  return h;
 }

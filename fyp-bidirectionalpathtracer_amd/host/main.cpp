@@ -19,7 +19,7 @@ static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t 
 }
 
 int main(int argc, char** argv) {
-  std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume;
+  std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume, envFile;
   uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
   int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100;
   bool denoise = false, denoiseRegression = false;
@@ -42,10 +42,11 @@ int main(int argc, char** argv) {
     else if (const char* v = next("--raw")) raw = v;
     else if (const char* v = next("--checkpoint")) checkpoint = v;
     else if (const char* v = next("--resume")) resume = v;
+    else if (const char* v = next("--env")) envFile = v;
     else {
       std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
                            "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32] "
-                           "[--resume file.ckpt] [--checkpoint file.ckpt]\n");
+                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black]\n");
       return 2;
     }
   }
@@ -77,6 +78,11 @@ int main(int argc, char** argv) {
   pipeline->setSize(config.windowDesc.width, config.windowDesc.height, device);
   if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 4) {
     std::fprintf(stderr, "pipeline initialisation failed (no GPU?)\n");
+    return 1;
+  }
+  // the light probe a user would pick in the file dialog (RenderingPipeline.cpp:229-243 -> ResourceManager::updateEnvironmentMap)
+  if (!envFile.empty() && !pipeline->getResourceManager()->updateEnvironmentMap(envFile)) {
+    std::fprintf(stderr, "bdpt_render: cannot load the environment map %s\n", envFile.c_str());
     return 1;
   }
   Gui gui;  // what a user would have set in the GUI windows

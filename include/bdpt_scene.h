@@ -52,6 +52,12 @@ bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap);
 int bdpt_image_load(const char* path, uint32_t* width, uint32_t* height, uint32_t* hasAlpha, uint8_t* rgba8, uint64_t cap, char* msg,
                     uint32_t msgCap);
 
+/* A Radiance .hdr (RGBE) light probe as RGBA32F, row 0 = top, alpha 1 — what ResourceManager::updateEnvironmentMap
+ * (SharedUtils/ResourceManager.cpp:96-110) gets from createTextureFromFile -> FreeImage for the reference's
+ * MonValley_*.hdr probes.  Flat and run-length-encoded scanlines, -Y / +Y orientations; mantissa * 2^(e-136) as
+ * FreeImage converts.  rgba32f may be NULL to query the size; capFloats counts floats. */
+int bdpt_image_load_hdr(const char* path, uint32_t* width, uint32_t* height, float* rgba32f, uint64_t capFloats, char* msg, uint32_t msgCap);
+
 void bdpt_scene_destroy(bdpt_scene* s);
 
 /* Pointers stay valid until bdpt_scene_destroy. */

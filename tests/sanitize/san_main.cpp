@@ -165,7 +165,8 @@ int main(int argc, char** argv) {
     uint32_t state = 12345u;
     auto rnd = [&]() { return state = state * 1664525u + 1013904223u; };
     int decoded = 0, refused = 0;
-    for (const char* name : {"san_rgba.png", "san_pal.png", "san_420.jpg", "san_grey.jpg", "san_rst.jpg"}) {
+    for (const char* name : {"san_rgba.png", "san_pal.png", "san_420.jpg", "san_grey.jpg", "san_rst.jpg", "san_probe.hdr"}) {
+      const bool hdr = std::strstr(name, ".hdr") != nullptr;
       std::ifstream f(tmp + "/" + name, std::ios::binary);
       if (!f) continue;
       std::vector<char> good((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -180,6 +181,17 @@ int main(int argc, char** argv) {
         std::ofstream(path, std::ios::binary).write(d.data(), (std::streamsize)d.size());
         uint32_t w = 0, h = 0, a = 0;
         char msg[128];
+        if (hdr) {  // the light-probe reader (Radiance RGBE)
+          if (bdpt_image_load_hdr(path.c_str(), &w, &h, nullptr, 0, msg, sizeof(msg)) == BDPT_OK) {
+            std::vector<float> px((size_t)w * h * 4);
+            if (bdpt_image_load_hdr(path.c_str(), &w, &h, px.data(), px.size(), msg, sizeof(msg)) != BDPT_OK) rc |= 1;
+            decoded++;
+          } else {
+            refused++;
+            if (k == 0) rc |= 1;
+          }
+          continue;
+        }
         if (bdpt_image_load(path.c_str(), &w, &h, &a, nullptr, 0, msg, sizeof(msg)) == BDPT_OK) {
           std::vector<uint8_t> px((size_t)w * h * 4);
           if (bdpt_image_load(path.c_str(), &w, &h, &a, px.data(), px.size(), msg, sizeof(msg)) != BDPT_OK) rc |= 1;

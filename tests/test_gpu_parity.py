@@ -681,3 +681,47 @@ def test_cpp_host_checkpoint_resume_continues_bit_for_bit(pkg, tmp_path):
         open(tmp_path / "bad.ckpt", "wb").write(bad)
         r = run(["--frames", "1", "--resume", str(tmp_path / "bad.ckpt")])
         assert r.returncode != 0 and "cannot resume" in r.stderr
+
+
+def test_cpp_host_loads_a_light_probe_file(pkg, tmp_path):
+    """ResourceManager::updateEnvironmentMap(file) (SharedUtils/ResourceManager.cpp:96-110) through the C++ host mirror:
+    `bdpt_render --env probe.hdr` must produce the frame the Python pipeline renders with the same texels handed to the
+    G-buffer pass's miss shader."""
+    import os
+    import subprocess
+    import torch
+    import __graft_entry__ as ge
+    import test_image_decode as tid
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe)
+    rng = np.random.default_rng(11)
+    eh, ew = 16, 32
+    img = (rng.random((eh, ew, 3)) * 3.0).astype(np.float64)
+    rgbe = tid._write_hdr(tmp_path / "probe.hdr", img, rle=True)
+    env = np.ones((eh, ew, 4), np.float32)
+    env[..., :3] = (rgbe[..., :3].astype(np.float64) * np.ldexp(1.0, rgbe[..., 3].astype(np.int32) - 136)[..., None]).astype(np.float32)
+    W, H, D = 96, 54, 3
+    r = subprocess.run([exe, "--scene", "atrium", "--width", str(W), "--height", str(H), "--depth", str(D), "--frames", "1", "--env",
+                        str(tmp_path / "probe.hdr"), "--out", str(tmp_path / "o.pfm"), "--raw", str(tmp_path / "o.f32")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    cpp = np.fromfile(tmp_path / "o.f32", np.float32).reshape(H, W, 4)
+    scene = pkg.Scene.atrium(1, 262144)
+    pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=0)
+    env_dev = torch.from_numpy(env).cuda()
+    gp = pipe.gbuffer_params()
+    gp.envMap, gp.envWidth, gp.envHeight = env_dev.data_ptr(), ew, eh
+    pipe.ctx.gbuffer_execute(gp, pipe.gb, pipe._stream_ptr())
+    p = pipe.bdpt_params()
+    pipe.ctx.execute(p, pipe.gb, C.c_void_p(pipe.output.data_ptr()), pipe._stream_ptr())
+    pipe.ctx.accumulate(C.c_void_p(pipe.last_frame.data_ptr()), C.c_void_p(pipe.output.data_ptr()), 0, 100, W * H, pipe._stream_ptr())
+    torch.cuda.synchronize()
+    ref = pipe.output.cpu().numpy()
+    assert np.array_equal(cpp.view(np.uint32), ref.view(np.uint32)), int((cpp != ref).any(axis=-1).sum())
+    sky = pipe.channels["WorldPosition"].cpu().numpy()[..., 3] == 0
+    assert sky.any() and len(np.unique(ref[sky][:, 0])) > 4  # the sky pixels show the probe's texels, not one colour
+    r = subprocess.run([exe, "--scene", "cornell", "--frames", "1", "--env", str(tmp_path / "missing.hdr"), "--out", str(tmp_path / "o.pfm")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "environment map" in r.stderr
+    pipe.close()
+    scene.close()

@@ -294,3 +294,95 @@ def test_png_jpeg_textured_scene_frame_matches_oracle(pkg, ob, tmp_path):
         orc.close()
         pipe.close()
     scene.close()
+
+
+def _write_hdr(path, img, rle, bottom_up=False, magic=b"#?RADIANCE"):
+    """float image [h, w, 3] -> Radiance RGBE file (what the encoder of any HDR tool writes); returns the RGBE bytes."""
+    h, w, _ = img.shape
+    mx = img.max(axis=-1)
+    e = np.zeros((h, w), np.int32)
+    nz = mx > 1e-32
+    e[nz] = np.floor(np.log2(mx[nz])).astype(np.int32) + 1
+    scale = np.where(nz, 256.0 / np.exp2(e.astype(np.float64)), 0.0)
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., :3] = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(nz, e + 128, 0).astype(np.uint8)
+    rows = rgbe[::-1] if bottom_up else rgbe
+    with open(path, "wb") as f:
+        f.write(magic + b"\n# written by the test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n")
+        f.write(("%sY %d +X %d\n" % ("+" if bottom_up else "-", h, w)).encode())
+        for r in rows:
+            if not rle:
+                f.write(r.tobytes())
+                continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                ch = r[:, c]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and ch[x + run] == ch[x]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, int(ch[x])]))
+                        x += run
+                    else:
+                        lit = 1
+                        while x + lit < w and lit < 128 and not (x + lit + 2 < w and ch[x + lit] == ch[x + lit + 1] == ch[x + lit + 2]):
+                            lit += 1
+                        f.write(bytes([lit]) + ch[x:x + lit].tobytes())
+                        x += lit
+    return rgbe
+
+
+@pytest.mark.parametrize("rle,bottom_up", [(False, False), (True, False), (True, True)])
+def test_radiance_hdr_light_probe_decodes_to_the_rgbe_values(pkg, tmp_path, rle, bottom_up):
+    """bdpt_image_load_hdr: what ResourceManager::updateEnvironmentMap gets for a .hdr light probe
+    (SharedUtils/ResourceManager.cpp:96-110 -> FreeImage): flat and run-length scanlines, both row orders; float =
+    mantissa * 2^(e - 136), alpha 1, row 0 = top."""
+    lib = pkg.load_library()
+    rng = np.random.default_rng(5)
+    h, w = 12, 40
+    img = (rng.random((h, w, 3)) ** 4 * 50.0).astype(np.float64)
+    img[3:6, 5:30] = (7.5, 0.25, 1e-3)   # runs for the RLE path
+    img[8, :] = 0.0                       # e = 0 -> exactly zero
+    path = tmp_path / "probe.hdr"
+    rgbe = _write_hdr(path, img, rle, bottom_up)
+    ww, hh = C.c_uint32(), C.c_uint32()
+    msg = C.create_string_buffer(256)
+    assert lib.bdpt_image_load_hdr(str(path).encode(), C.byref(ww), C.byref(hh), None, 0, msg, 256) == 0, msg.value
+    assert (ww.value, hh.value) == (w, h)
+    out = np.zeros((h, w, 4), np.float32)
+    assert lib.bdpt_image_load_hdr(str(path).encode(), C.byref(ww), C.byref(hh), out.ctypes.data, out.size, msg, 256) == 0
+    want = np.ones((h, w, 4), np.float32)
+    f = np.where(rgbe[..., 3] > 0, np.ldexp(1.0, rgbe[..., 3].astype(np.int32) - 136), 0.0)
+    want[..., :3] = (rgbe[..., :3].astype(np.float64) * f[..., None]).astype(np.float32)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert np.abs(out[..., :3] - img).max() <= np.abs(img).max() / 128  # and those are the image, to RGBE precision
+    # refusals: truncated data, a header that promises 60000 x 60000 texels, not an .hdr at all
+    blob = open(path, "rb").read()
+    for bad, why in ((blob[:len(blob) - 25], b"truncated"), (blob.replace(b"Y 12 +X 40", b"Y 60000 +X 60000"), b"limit"), (b"P6\n1 1\n255\nabc", b"not a Radiance")):
+        open(tmp_path / "bad.hdr", "wb").write(bad)
+        assert lib.bdpt_image_load_hdr(str(tmp_path / "bad.hdr").encode(), C.byref(ww), C.byref(hh), None, 0, msg, 256) != 0
+        assert why in msg.value or (why == b"truncated" and b"corrupt .hdr run" in msg.value), (why, msg.value)
+
+
+def test_decoders_refuse_oversized_headers_without_allocating(pkg, tmp_path):
+    """A few bytes of header must not make the loader allocate gigabytes: PNG and JPEG dimensions above the
+    loader's limit are refused before any plane is allocated."""
+    import struct
+    import zlib
+    lib = pkg.load_library()
+    w = h = C.c_uint32()
+    msg = C.create_string_buffer(256)
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 30000, 30000, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")
+    open(tmp_path / "big.png", "wb").write(png)
+    assert lib.bdpt_image_load(str(tmp_path / "big.png").encode(), C.byref(w), C.byref(h), None, None, 0, msg, 256) != 0
+    jpg = b"\xff\xd8" + b"\xff\xc0" + struct.pack(">HBHHB", 11, 8, 65535, 65535, 1) + b"\x01\x11\x00" + b"\xff\xd9"
+    open(tmp_path / "big.jpg", "wb").write(jpg)
+    assert lib.bdpt_image_load(str(tmp_path / "big.jpg").encode(), C.byref(w), C.byref(h), None, None, 0, msg, 256) != 0
+    assert b"limit" in msg.value, msg.value

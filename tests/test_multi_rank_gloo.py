@@ -1,4 +1,4 @@
-"""world_size-2 (and 3, 5) gloo test of the N>1 path on CPU: stripe tiles, owner-major splat exchange, resolve, gather.
+"""world_size-2 (and 3, 5, 8) gloo test of the N>1 path on CPU: stripe tiles, owner-major splat exchange, resolve, gather.
 
 Each rank renders its interleaved stripes with the ORACLE (there is no GPU here; the oracle is the checker
 and, in this test only, also the stand-in renderer), lays its fixed-point splats out owner-major, sums them through
@@ -44,8 +44,8 @@ def _worker(rank, world, port, q):
     frame_splat = np.zeros((W * H, 4), np.uint64)
     for (ya, yb) in mine_rows:
         orc = ob.OracleRender(pkg.abi, scene.desc, W, H, ya, yb)
-        orc.gbuffer(cam, gp, threads=2)
-        orc.bdpt(cam, p, threads=2)
+        orc.gbuffer(cam, gp, threads=1 if world > 4 else 2)
+        orc.bdpt(cam, p, threads=1 if world > 4 else 2)
         frame_splat += orc.splat
         orcs.append(orc)
     # frame order -> owner-major (the layout bdpt_resize_stripes gives the HIP path's splat buffer)
@@ -81,7 +81,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 5, 8])  # 8 = the driver's scaling run (8 CPUs here: one oracle thread per rank would do)
 def test_two_rank_tiled_frame_equals_single_rank(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

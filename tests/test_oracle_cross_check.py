@@ -157,3 +157,111 @@ def test_gbuffer_matches_float64_reading_of_the_primary_shaders(pkg, ob, thin_le
     assert hits > 0.9 * size * size
     orc.close()
     scene.close()
+
+
+def _relit_desc(pkg, scene):
+    """The scene's description with three lights of the three kinds Falcor's evalLight distinguishes: a spot light with
+    a penumbra (Lights.slang:75-102), a plain point light and a directional light."""
+    import ctypes as C
+    import math
+    A = pkg.abi
+    d = A.SceneDesc()
+    C.memmove(C.byref(d), C.byref(scene.desc), C.sizeof(A.SceneDesc))
+    lights = (A.Light * 3)()
+
+    def fill(l, typ, pos, direction, intensity, opening=math.pi, penumbra=0.0):
+        l.type = typ
+        n = math.sqrt(sum(x * x for x in direction))
+        for k in range(3):
+            l.posW[k], l.dirW[k], l.intensity[k] = pos[k], direction[k] / n, intensity[k]
+        l.openingAngle, l.cosOpeningAngle, l.penumbraAngle = opening, math.cos(opening), penumbra
+
+    fill(lights[0], A.LIGHT_POINT, (-3.0, 6.5, 0.4), (0.35, -1.0, -0.1), (60.0, 52.0, 40.0), opening=0.75, penumbra=0.3)
+    fill(lights[1], A.LIGHT_POINT, (6.0, 3.0, -0.8), (0.0, -1.0, 0.0), (14.0, 16.0, 22.0))
+    fill(lights[2], A.LIGHT_DIRECTIONAL, (0.0, 30.0, 0.0), (0.3, -1.0, 0.25), (0.9, 0.85, 0.7))
+    d.lights, d.numLights = lights, 3
+    return d, lights
+
+
+def test_textured_alpha_masked_spot_lit_frame_matches_float64_reading(pkg, ob):
+    """The rows the Cornell cross-check cannot reach: vertex
+    fetch + material decode + sRGB / bilinear / wrap texture sampling (MetalRough and SpecGloss materials), the any-hit
+    alpha test on primary, extension and shadow rays, the primary hit's normal map, and the spot-light / penumbra branch
+    of evalPointLight — re-read in float64 from the HLSL / Slang (tests/hlsl_textured_numpy.py) and compared with the
+    oracle on a small frame of the foliage courtyard: every G-buffer channel, then the NEE image of a depth-3 pass.
+
+    Pixels are allowed to disagree only where a float32 and a float64 ray fall on different sides of a discontinuity
+    (triangle and leaf-silhouette edges, shadow boundaries, the light pick): a small share, asserted below."""
+    import hlsl_integrator_numpy as hi
+    import hlsl_textured_numpy as ht
+    A = pkg.abi
+    W, H, depth = 44, 28, 3
+    scene = pkg.Scene.courtyard(5, 7000, 0.35)
+    desc, keep = _relit_desc(pkg, scene)
+    cam = scene.camera(W / H)
+    gp, p = _frame_params(pkg, depth, 0, A.PARAM_NO_SPLAT | A.PARAM_NO_CONNECT, 2e-3)
+    orc = ob.OracleRender(A, desc, W, H)
+    orc.gbuffer(cam, gp)
+    orc.bdpt(cam, p)
+    nee = orc.image().astype(np.float64)
+    sc = ht.TexturedScene(desc)
+    assert len(sc.textures) >= 7 and (sc.tri_alpha_mode != 0).sum() > 1000
+    models = {int(m.flags) & 7 for m in sc.mats}
+    assert models == {0, 2}, models                       # both shading models occur
+    assert any(((int(m.flags) >> 12) & 3) != 0 for m in sc.mats)  # and a normal-mapped material
+    R = hi.Renderer(sc, cam, p, W, H)
+    f16 = lambda a: np.asarray(a, np.float64).astype(np.float16).astype(np.float64)  # the channel's storage format
+    rel = lambda a, b: np.max(np.abs(np.asarray(a, np.float64) - b) / (1e-3 + np.abs(b)))
+
+    def half_err(stored, exact):
+        """A half-precision channel against the float64 value it should hold: the error beyond half a unit in the last
+        place of the half format (what rounding alone may cost), relative to the vector's largest component — the
+        float32 and float64 values differ by ~1e-6 of that and may round to neighbouring halves."""
+        stored, exact = np.asarray(stored, np.float64), np.asarray(exact, np.float64)
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(exact), 2.0 ** -14))) - 10)
+        return float(np.max(np.maximum(0.0, np.abs(stored - exact) - 0.5 * ulp)) / max(1e-3, float(np.max(np.abs(exact)))))
+    n_hit = n_gb_ok = n_pix = n_nee_ok = n_alpha_pixels = 0
+    worst_gb = worst_nee = 0.0
+    for y in range(H):
+        for x in range(W):
+            i = y * W + x
+            n_pix += 1
+            with np.errstate(all="ignore"):
+                g = ht.gbuffer_pixel(sc, cam, gp, W, H, x, y, (0.5, 0.5, 0.8))
+            wp = orc.chan["worldPosition"][i]
+            if not g["hit"] or wp[3] == 0.0:
+                same = (not g["hit"]) and wp[3] == 0.0 and np.allclose(orc.chan["materialDiffuse"][i], f16(g["dif"]), atol=1e-3)
+                n_gb_ok += bool(same)
+                n_nee_ok += bool(same)  # the pass copies the environment colour through (BDPTMain.rt.hlsl:62-66)
+                continue
+            n_hit += 1
+            n_alpha_pixels += int(sc.tri_alpha_mode[g["prim"]] != 0)
+            errs = [rel(wp[:3], g["pos"]),
+                    half_err(orc.chan["worldNormal"][i][:3], g["N"]), half_err(orc.chan["worldNormal"][i][3:], [g["dist"]]),
+                    half_err(orc.chan["materialDiffuse"][i], np.append(g["dif"], g["opacity"])),
+                    half_err(orc.chan["materialSpecRough"][i], np.append(g["spec"], g["linear_roughness"])),
+                    half_err(orc.chan["materialExtra"][i][:1], [g["ior"]]),
+                    half_err(orc.chan["emissive"][i][:3], g["emissive"])]
+            gb_ok = max(errs) < 1e-4
+            n_gb_ok += gb_ok
+            if gb_ok:
+                worst_gb = max(worst_gb, max(errs))
+                # the BDPT pass of the float64 reading starts from the ORACLE's G-buffer texels, as the shader would
+                with np.errstate(all="ignore"):
+                    o, _ = R.pixel(x, y, wp, orc.chan["worldNormal"][i], orc.chan["materialDiffuse"][i], orc.chan["materialSpecRough"][i],
+                                   orc.chan["emissive"][i], splat=False, connect=False)
+                e = float(np.max(np.abs(o[:3] - nee[y, x, :3]) / (1e-3 + np.abs(nee[y, x, :3]))))
+                ok = e < 5e-4 and o[3] == nee[y, x, 3]
+                n_nee_ok += ok
+                if ok:
+                    worst_nee = max(worst_nee, e)
+    assert n_hit > 0.6 * n_pix and n_alpha_pixels > 10, (n_hit, n_alpha_pixels)
+    assert n_gb_ok >= 0.985 * n_pix, (n_gb_ok, n_pix)
+    assert n_nee_ok >= 0.97 * n_pix, (n_nee_ok, n_pix)
+    assert worst_gb < 1e-4 and worst_nee < 5e-4
+    lit = nee[..., :3].sum(axis=-1) > 1e-4
+    assert lit.mean() > 0.2  # the comparison is not about black pixels
+    print("textured cross-check: %d px, %d hits (%d on alpha-masked triangles), G-buffer agrees on %d, NEE image on %d; worst %.2e / %.2e" % (
+        n_pix, n_hit, n_alpha_pixels, n_gb_ok, n_nee_ok, worst_gb, worst_nee))
+    orc.close()
+    scene.close()

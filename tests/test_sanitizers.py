@@ -38,6 +38,13 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
             pass
     except ImportError:
         pass
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import test_image_decode as tid
+    probe = (np.random.default_rng(2).random((10, 36, 3)) * 4.0)
+    probe[2:5, 4:30] = (1.0, 0.5, 0.25)
+    tid._write_hdr(tmp_path / "san_probe.hdr", probe, rle=True)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sanitizer run finished rc=0" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -36,6 +36,7 @@ class RenderContext {
   explicit RenderContext(int device = 0, hipStream_t stream = nullptr) : mDevice(device), mStream(stream) {}
   int getDevice() const { return mDevice; }
   hipStream_t getStream() const { return mStream; }
+  void setStream(hipStream_t s) { mStream = s; }  // frames in flight: the pipeline points the context at the frame's stream
   void flush(bool wait = true) { if (wait) (void)hipStreamSynchronize(mStream); }
  private:
   int mDevice;

@@ -161,6 +161,8 @@ int32_t ResourceManager::requestTextureResource(const std::string& channelName, 
   }
   existingIndex = int32_t(mTextures.size());
   mTextures.push_back(nullptr);  // created in initializeResources()
+  mManaged.push_back(false);
+  for (auto& v : mSlotTextures) v.push_back(nullptr);
   mTextureSizes.push_back(ivec2{channelWidth, channelHeight});
   mTextureNames.push_back(channelName);
   mTextureFlags.push_back(usageFlags);
@@ -177,19 +179,32 @@ int32_t ResourceManager::manageTextureResource(const std::string& channelName, T
   if (idx < 0) {
     idx = int32_t(mTextures.size());
     mTextures.push_back(tex);
+    mManaged.push_back(true);
+    for (auto& v : mSlotTextures) v.push_back(nullptr);
     mTextureNames.push_back(channelName);
     mTextureSizes.push_back(ivec2{(int)tex->getWidth(), (int)tex->getHeight()});
     mTextureFlags.push_back(kDefaultFlags);
     mTextureFormat.push_back(tex->getFormat());
   } else {
     mTextures[(size_t)idx] = tex;
+    if ((size_t)idx < mManaged.size()) mManaged[(size_t)idx] = true;
     mTextureSizes[(size_t)idx] = ivec2{(int)tex->getWidth(), (int)tex->getHeight()};
     mTextureFormat[(size_t)idx] = tex->getFormat();
   }
   mUpdatedFlag = true;
   return idx;
 }
-Texture::SharedPtr ResourceManager::getTexture(int32_t i) { return (i < 0 || i >= (int32_t)mTextures.size()) ? nullptr : mTextures[(size_t)i]; }
+Texture::SharedPtr ResourceManager::getTexture(int32_t i) {
+  if (i < 0 || i >= (int32_t)mTextures.size()) return nullptr;
+  if (mSlot > 0 && !(i < (int32_t)mManaged.size() && mManaged[(size_t)i])) return mSlotTextures[mSlot - 1][(size_t)i];
+  return mTextures[(size_t)i];
+}
+void ResourceManager::setSlotCount(uint32_t n) {
+  mSlotTextures.assign(n > 1 ? n - 1 : 0, std::vector<Texture::SharedPtr>());
+  for (auto& v : mSlotTextures) v.assign(mTextures.size(), nullptr);
+  mSlot = 0;
+  if (mIsInitialized) initializeResources();
+}
 Texture::SharedPtr ResourceManager::getTexture(const std::string& n) { return getTexture(getTextureIndex(n)); }
 Texture::SharedPtr ResourceManager::getClearedTexture(const std::string& n, const vec4& c) { return getClearedTexture(getTextureIndex(n), c); }
 Texture::SharedPtr ResourceManager::getClearedTexture(int32_t i, const vec4& c) {
@@ -245,6 +260,11 @@ void ResourceManager::initializeResources() {
     uint32_t w = mTextureSizes[i].x <= 0 ? mWidth : (uint32_t)mTextureSizes[i].x;
     uint32_t h = mTextureSizes[i].y <= 0 ? mHeight : (uint32_t)mTextureSizes[i].y;
     if (!mTextures[i]) mTextures[i] = Texture::create2D(w, h, mTextureFormat[i]);
+    if (!(i < mManaged.size() && mManaged[i]))
+      for (auto& v : mSlotTextures) {
+        if (v.size() < mTextures.size()) v.resize(mTextures.size());
+        if (!v[i]) v[i] = Texture::create2D(w, h, mTextureFormat[i]);
+      }
   }
   mIsInitialized = true;
   mUpdatedFlag = true;
@@ -259,6 +279,8 @@ void ResourceManager::resize(uint32_t width, uint32_t height) {
     if (mTextureSizes[i] != ivec2{-1, -1}) continue;
     if (mTextures[i] && mTextures[i]->getWidth() == mWidth && mTextures[i]->getHeight() == mHeight) continue;
     mTextures[i] = Texture::create2D(mWidth, mHeight, mTextureFormat[i]);
+    for (auto& v : mSlotTextures)
+      if (i < v.size()) v[i] = Texture::create2D(mWidth, mHeight, mTextureFormat[i]);
   }
   mUpdatedFlag = true;
 }
@@ -291,13 +313,36 @@ RayLaunch::SharedPtr RayLaunch::create(RenderContext* ctx) {
     std::fprintf(stderr, "[RayLaunch] bdpt_create(%d) failed: no usable HIP device\n", dev);
     return nullptr;
   }
+  r->mDevice = dev;
   perDevice[dev] = r;
   return r;
 }
 RayLaunch::~RayLaunch() {
+  for (bdpt_ctx* c : mMore)
+    if (c) bdpt_destroy(c);
   if (mCtx) bdpt_destroy(mCtx);
 }
-const char* RayLaunch::lastError() const { return bdpt_last_error(mCtx); }
+const char* RayLaunch::lastError() const { return bdpt_last_error(ctx()); }
+bool RayLaunch::setSlotCount(uint32_t n) {
+  while (mMore.size() + 1 > n && !mMore.empty()) {
+    bdpt_destroy(mMore.back());
+    mMore.pop_back();
+  }
+  while (mMore.size() + 1 < n) {
+    bdpt_ctx* c = nullptr;
+    if (bdpt_create(mDevice, &c) != BDPT_OK) return false;
+    mMore.push_back(c);
+  }
+  mSlot = 0;
+  mSceneSet = false;  // the new contexts have no scene yet
+  mW = mH = 0;
+  if (mpScene) {
+    Scene::SharedPtr sc = mpScene;
+    mpScene = nullptr;
+    setScene(sc);
+  }
+  return true;
+}
 void RayLaunch::setScene(Scene::SharedPtr pScene) {
   if (!pScene || !mCtx) return;
   if (pScene == mpScene && mSceneSet) return;
@@ -306,16 +351,24 @@ void RayLaunch::setScene(Scene::SharedPtr pScene) {
   bdpt_scene_desc d;
   pScene->getDesc(&d);
   mSceneSet = bdpt_set_scene(mCtx, &d) == BDPT_OK;
-  if (!mSceneSet) std::fprintf(stderr, "[RayLaunch] bdpt_set_scene failed: %s\n", lastError());
+  if (!mSceneSet) std::fprintf(stderr, "[RayLaunch] bdpt_set_scene failed: %s\n", bdpt_last_error(mCtx));
+  for (bdpt_ctx* c : mMore)
+    if (mSceneSet && bdpt_set_scene(c, &d) != BDPT_OK) {
+      std::fprintf(stderr, "[RayLaunch] bdpt_set_scene failed: %s\n", bdpt_last_error(c));
+      mSceneSet = false;
+    }
 }
 bool RayLaunch::ensureSize(uint32_t w, uint32_t h) {
   if (!mCtx) return false;
   if (w == mW && h == mH && mSizedDepth == mMaxDepth) return true;
   bdpt_tile tile{0, h};
-  if (bdpt_resize(mCtx, w, h, tile, mMaxDepth) != BDPT_OK) {
-    std::fprintf(stderr, "[RayLaunch] bdpt_resize failed: %s\n", lastError());
-    return false;
-  }
+  std::vector<bdpt_ctx*> all{mCtx};
+  all.insert(all.end(), mMore.begin(), mMore.end());
+  for (bdpt_ctx* c : all)
+    if (bdpt_resize(c, w, h, tile, mMaxDepth) != BDPT_OK) {
+      std::fprintf(stderr, "[RayLaunch] bdpt_resize failed: %s\n", bdpt_last_error(c));
+      return false;
+    }
   mW = w;
   mH = h;
   mSizedDepth = mMaxDepth;
@@ -620,9 +673,22 @@ void RenderingPipeline::run(RenderingPipeline* pipe, SampleConfig& config) {
   delete pipe;
 }
 RenderingPipeline::~RenderingPipeline() {
+  for (hipStream_t st : mSlotStreams)
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  for (hipEvent_t e : mOrderEvents)
+    if (e) (void)hipEventDestroy(e);
   for (auto& p : mActivePasses)
     if (p) p->onShutdown();
   mActivePasses.clear();
+}
+bool RenderingPipeline::inFlightActive() {
+  if (mFramesInFlight <= 1 || mSlotStreams.empty()) return false;
+  for (auto& p : mActivePasses)
+    if (p && p->onHasUnsavedCrossFrameState()) return false;  // a pass with temporal state of its own needs the frames one by one
+  return true;
 }
 void RenderingPipeline::setPass(uint32_t passNum, RenderPass::SharedPtr pTargetPass) {
   if (mActivePasses.size() <= passNum) mActivePasses.resize(passNum + 1);
@@ -638,6 +704,18 @@ bool RenderingPipeline::initialize(Scene::SharedPtr pScene) {
     if (!p->onInitialize(&mContext, mpResourceManager)) p = nullptr;  // a failing pass is dropped (RenderingPipeline.cpp:58-59)
   }
   mpResourceManager->initializeResources();
+  if (mFramesInFlight > 1) {  // frame slots: channels, launcher contexts and streams, one set per frame in flight
+    mpRays = RayLaunch::create(&mContext);
+    if (!mpRays || !mpRays->setSlotCount(mFramesInFlight)) return false;
+    mpResourceManager->setSlotCount(mFramesInFlight);
+    mSlotStreams.assign(mFramesInFlight, nullptr);
+    for (hipStream_t& st : mSlotStreams)
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    mOrderEvents.assign(mActivePasses.size(), nullptr);
+    for (size_t i = 0; i < mActivePasses.size(); i++)
+      if (mActivePasses[i] && mActivePasses[i]->onNeedsFrameOrder())
+        if (hipEventCreateWithFlags(&mOrderEvents[i], hipEventDisableTiming) != hipSuccess) return false;
+  }
   bool any = false;
   for (auto& p : mActivePasses) {
     if (!p) continue;
@@ -658,8 +736,26 @@ void RenderingPipeline::renderFrame() {
   if (refresh)
     for (auto& p : mActivePasses)
       if (p) p->onStateRefresh();  // RenderingPipeline.cpp:635-663
-  for (auto& p : mActivePasses)
-    if (p) p->onExecute(&mContext);
+  if (!inFlightActive()) {
+    for (auto& p : mActivePasses)
+      if (p) p->onExecute(&mContext);
+    mFrameIndex++;
+    return;
+  }
+  // this frame's slot: its stream (in order behind the frame that used the slot before), channels and launcher context
+  const uint32_t slot = (uint32_t)(mFrameIndex % mFramesInFlight);
+  mContext.setStream(mSlotStreams[slot]);
+  mpResourceManager->setCurrentSlot(slot);
+  mpRays->setCurrentSlot(slot);
+  for (size_t i = 0; i < mActivePasses.size(); i++) {
+    RenderPass::SharedPtr& p = mActivePasses[i];
+    if (!p) continue;
+    const bool ordered = mOrderEvents[i] != nullptr;
+    if (ordered && mFrameIndex > 0) (void)hipStreamWaitEvent(mSlotStreams[slot], mOrderEvents[i], 0);  // behind the previous frame's
+    p->onExecute(&mContext);
+    if (ordered) (void)hipEventRecord(mOrderEvents[i], mSlotStreams[slot]);
+  }
+  mFrameIndex++;
 }
 // ---- checkpoints
 namespace {
@@ -759,6 +855,7 @@ bool RenderingPipeline::saveCheckpoint(const std::string& path) {
       std::fprintf(stderr, "[RenderingPipeline] pass '%s' holds cross-frame state that cannot be saved: no checkpoint written\n", pass->getName().c_str());
       return false;
     }
+  for (hipStream_t st : mSlotStreams) (void)hipStreamSynchronize(st);  // frames in flight: everything submitted has landed
   std::vector<uint8_t> out;
   put32(out, kCheckpointMagic);
   put32(out, kCheckpointVersion);
@@ -832,7 +929,8 @@ bool RenderingPipeline::loadCheckpoint(const std::string& path) {
 }
 
 std::vector<float> RenderingPipeline::readOutput() {
-  Texture::SharedPtr t = mpResourceManager->getTexture(ResourceManager::kOutputChannel);
+  for (hipStream_t st : mSlotStreams) (void)hipStreamSynchronize(st);
+  Texture::SharedPtr t = mpResourceManager->getTexture(ResourceManager::kOutputChannel);  // the latest frame's slot
   return t ? t->download(mContext.getStream()) : std::vector<float>();
 }
 

@@ -23,13 +23,19 @@ class RayLaunch {
   bool readyToRender() const { return mCtx && mSceneSet; }
   // (re)size the per-pixel path state; called by execute when the screen size changed
   bool ensureSize(uint32_t w, uint32_t h);
-  bdpt_ctx* ctx() const { return mCtx; }
+  bdpt_ctx* ctx() const { return mSlot == 0 ? mCtx : mMore[mSlot - 1]; }
   Scene::SharedPtr scene() const { return mpScene; }
   const char* lastError() const;
+  // Frames in flight: one bdpt_ctx per frame slot (each owns its path state and traverses its own copy of the BVH)
+  bool setSlotCount(uint32_t n);
+  void setCurrentSlot(uint32_t s) { mSlot = s <= mMore.size() ? s : 0; }
 
  private:
   RayLaunch() = default;
   bdpt_ctx* mCtx = nullptr;
+  std::vector<bdpt_ctx*> mMore;  // slots 1..
+  uint32_t mSlot = 0;
+  int mDevice = 0;
   Scene::SharedPtr mpScene;
   bool mSceneSet = false;
   uint32_t mW = 0, mH = 0, mMaxDepth = 8, mSizedDepth = 0;
@@ -109,6 +115,7 @@ class SimpleAccumulationPass : public RenderPass {
   void stateRefreshed() override;
   bool appliesPostprocess() override { return true; }
   bool hasAnimation() override { return false; }
+  bool needsFrameOrder() override { return true; }  // the running mean is applied in frame order
   bool hasCameraMoved();
   void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) override;
   bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) override;
@@ -170,6 +177,12 @@ class RenderingPipeline {
   RenderingPipeline(uint32_t width, uint32_t height, int device = 0);
   ~RenderingPipeline();
   void setSize(uint32_t width, uint32_t height, int device = 0);  // before initialize()
+  // Offline accumulation runs (a 1024-sample image is a long job; the reference's loop is interactive,
+  // RenderingPipeline.cpp:611-695): keep n frames in flight, each on its own stream with its own channels and
+  // launcher context, the ordered passes (accumulation) chained by events.  Same image as n = 1, bit for bit.
+  // Call before initialize(); ignored (n = 1) while a pass holds temporal state of its own (the denoiser switched on).
+  void setFramesInFlight(uint32_t n) { mFramesInFlight = n < 1 ? 1 : (n > 8 ? 8 : n); }
+  uint32_t getFramesInFlight() const { return mFramesInFlight; }
   // RenderingPipeline::run (RenderingPipeline.cpp:697-712) without a window: size the channels from the config,
   // load the scene named by BDPT_SCENE (a .fscene / .obj path, "atrium", default the Cornell box), render BDPT_FRAMES
   // frames (default 1), and delete the pipeline.
@@ -198,6 +211,12 @@ class RenderingPipeline {
   ResourceManager::SharedPtr mpResourceManager;
   std::vector<RenderPass::SharedPtr> mActivePasses;
   Scene::SharedPtr mpScene;
+  uint32_t mFramesInFlight = 1;
+  uint64_t mFrameIndex = 0;
+  std::vector<hipStream_t> mSlotStreams;   // one per frame slot (slot 0 included)
+  std::vector<hipEvent_t> mOrderEvents;    // per ordered pass: recorded after it ran for the latest frame
+  RayLaunch::SharedPtr mpRays;             // kept to switch the launcher's slot
+  bool inFlightActive();
 };
 
 }  // namespace bdpt

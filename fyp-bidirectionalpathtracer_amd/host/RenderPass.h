@@ -53,9 +53,19 @@ class ResourceManager : public std::enable_shared_from_this<ResourceManager> {
   float getMinTDist() const { return mMinT; }
   void setMinTDist(float newMinT) { mMinT = newMinT; }
   RenderContext* getRenderContext() const { return mpContext; }
+  // Frames in flight (RenderingPipeline::setFramesInFlight; not in the reference, whose loop is interactive): every
+  // requested channel exists once per frame slot, and getTexture returns the current slot's.  Managed textures
+  // (manageTextureResource: the environment map) are shared by all slots.
+  void setSlotCount(uint32_t n);
+  void setCurrentSlot(uint32_t s) { mSlot = s <= mSlotTextures.size() ? s : 0; }
+  uint32_t getSlotCount() const { return (uint32_t)mSlotTextures.size() + 1u; }
 
  protected:
   ResourceManager(uint32_t width, uint32_t height, RenderContext* ctx) : mWidth(width), mHeight(height), mpContext(ctx) {}
+  std::vector<Texture::SharedPtr>& slotTextures() { return mSlot == 0 ? mTextures : mSlotTextures[mSlot - 1]; }
+  std::vector<std::vector<Texture::SharedPtr>> mSlotTextures;  // slots 1.. (slot 0 is mTextures)
+  std::vector<bool> mManaged;                                   // per channel: shared by all slots
+  uint32_t mSlot = 0;
   uint32_t mWidth = 0, mHeight = 0;
   bool mIsInitialized = false, mUpdatedFlag = true;
   float mMinT = 1.0e-4f;
@@ -96,6 +106,9 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   // true when the pass carries state from frame to frame that saveState does NOT capture: a pipeline holding such a
   // pass refuses to write or read a checkpoint instead of resuming into a silently different sequence
   virtual bool hasUnsavedCrossFrameState() { return false; }
+  // true when the pass must see the frames in their order (the running mean): with frames in flight the pipeline
+  // makes this pass of frame f + 1 wait for the same pass of frame f; every other pass only depends on its own frame
+  virtual bool needsFrameOrder() { return false; }
 
  public:
   virtual bool requiresScene() { return false; }
@@ -122,6 +135,7 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   void onSaveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) { saveState(pRenderContext, out); }
   bool onLoadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) { return loadState(pRenderContext, data, size); }
   bool onHasUnsavedCrossFrameState() { return hasUnsavedCrossFrameState(); }
+  bool onNeedsFrameOrder() { return needsFrameOrder(); }
 
   void setName(const std::string& name) { mName = name; }
   std::string getName() const { return mName; }

@@ -21,7 +21,7 @@ static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t 
 int main(int argc, char** argv) {
   std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume, envFile;
   uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
-  int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100;
+  int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100, inflight = 1;
   bool denoise = false, denoiseRegression = false;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
@@ -43,10 +43,11 @@ int main(int argc, char** argv) {
     else if (const char* v = next("--checkpoint")) checkpoint = v;
     else if (const char* v = next("--resume")) resume = v;
     else if (const char* v = next("--env")) envFile = v;
+    else if (const char* v = next("--inflight")) inflight = std::atoi(v);
     else {
       std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
                            "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32] "
-                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black]\n");
+                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black] [--inflight N]\n");
       return 2;
     }
   }
@@ -76,6 +77,7 @@ int main(int argc, char** argv) {
   config.windowDesc.height = H;
   config.windowDesc.title = "Bidirectional Path Tracing (headless)";
   pipeline->setSize(config.windowDesc.width, config.windowDesc.height, device);
+  pipeline->setFramesInFlight((uint32_t)(inflight < 1 ? 1 : inflight));  // offline accumulation: frames overlap, same image
   if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 4) {
     std::fprintf(stderr, "pipeline initialisation failed (no GPU?)\n");
     return 1;
@@ -99,7 +101,7 @@ int main(int argc, char** argv) {
 
   auto t0 = std::chrono::steady_clock::now();
   for (int f = 0; f < frames; f++) pipeline->renderFrame();
-  pipeline->getRenderContext()->flush(true);
+  (void)hipDeviceSynchronize();
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::vector<float> img = pipeline->readOutput();
   double mean = 0;

@@ -725,3 +725,31 @@ def test_cpp_host_loads_a_light_probe_file(pkg, tmp_path):
     assert r.returncode != 0 and "environment map" in r.stderr
     pipe.close()
     scene.close()
+
+
+def test_cpp_host_frames_in_flight_accumulate_the_same_image(pkg, tmp_path):
+    """RenderingPipeline::setFramesInFlight (host/Passes.cpp; `bdpt_render --inflight N`): an offline accumulation run
+    with three frames in flight — one stream, one set of channels and one launcher context per frame slot, the
+    accumulation pass chained by events — gives the image of the one-frame-at-a-time loop bit for bit, also across a
+    checkpoint; with the denoiser switched on the pipeline falls back to one frame at a time."""
+    import os
+    import subprocess
+    import __graft_entry__ as ge
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe)
+    common = ["--scene", "atrium", "--width", "96", "--height", "54", "--depth", "5", "--out", str(tmp_path / "o.pfm")]
+
+    def run(extra, raw):
+        r = subprocess.run([exe] + common + extra + ["--raw", str(tmp_path / raw)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return np.fromfile(tmp_path / raw, np.float32)
+
+    a = run(["--frames", "7"], "seq.f32")
+    b = run(["--frames", "7", "--inflight", "3"], "fly.f32")
+    assert a.size == 96 * 54 * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), int((a != b).sum())
+    run(["--frames", "3", "--inflight", "3", "--checkpoint", str(tmp_path / "c.ckpt")], "part.f32")
+    c = run(["--frames", "4", "--inflight", "2", "--resume", str(tmp_path / "c.ckpt")], "res.f32")
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    d = run(["--frames", "4", "--denoise"], "dn1.f32")
+    e = run(["--frames", "4", "--denoise", "--inflight", "3"], "dn3.f32")
+    assert np.array_equal(d.view(np.uint32), e.view(np.uint32))

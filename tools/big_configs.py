@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Frame time and ray rate of the two large BASELINE shapes on ONE GPU (stand-in generators at the configs' triangle
-counts): configs[3] 2.8 M triangles 3840x2160 depth 12 (atrium generator), configs[4] 10 M triangles, half of them
-alpha-masked cards, 3840x2160 depth 16 (courtyard generator).  Usage: python tools/big_configs.py [4|5|both]"""
+"""Frame time and ray rate of the other BASELINE shapes on ONE GPU (stand-in generators at the configs' triangle
+counts): configs[1] Cornell box 1920x1080 depth 8 Lambertian; configs[3] 2.8 M triangles 3840x2160 depth 12 (atrium
+generator); configs[4] 10 M triangles, half of them alpha-masked cards, 3840x2160 depth 16 (courtyard generator).
+Usage: python tools/big_configs.py [2|4|5|both]   (numbers = BASELINE.json configs, 1-based)"""
 import os
 import sys
 import time
@@ -13,9 +14,9 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 
 
-def run(name, scene, W, H, D, frames=3):
+def run(name, scene, W, H, D, frames=3, mat=0):
     t0 = time.time()
-    pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=0, accum_limit=10000)
+    pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, accum_limit=10000)
     torch.cuda.synchronize()
     setup = time.time() - t0
     pipe.ctx.enable_stage_timing(True)
@@ -46,6 +47,10 @@ def run(name, scene, W, H, D, frames=3):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
+if which == "2":
+    s = pkg.Scene.cornell()
+    run("configs[1] (Cornell 1080p depth 8, Lambertian)", s, 1920, 1080, 8, frames=8, mat=1)
+    s.close()
 if which in ("4", "both"):
     s = pkg.Scene.atrium(1, 2800000)
     run("configs[3] shape (Bistro-class)", s, 3840, 2160, 12)

@@ -12,6 +12,11 @@
  *                                   (SharedUtils/RayLaunch.cpp:105-167,
  *                                    Falcor/Framework/Source/Raytracing/RtModel.cpp:181-254,
  *                                    Falcor/Framework/Source/Raytracing/RtScene.cpp:220-308)
+ *   bdpt_set_environment            the "EnvironmentMap" channel BDPTPass requests (BDPTPass.cpp:29; bound by no shader
+ *                                   of the pass in the reference): read only with BDPT_PARAM_ENV_ON_MISS
+ *   bdpt_bvh_build_check / _hash, bdpt_host_bvh_*
+ *                                   (none in the reference: the DXR driver's acceleration structure is opaque) —
+ *                                   host-only checks of the builder and a CPU walk of its tree for tests and tools
  *   bdpt_set_camera                 gCamera constant buffer (CameraData,
  *                                   Falcor/Framework/Source/Data/HostDeviceSharedCode.h:69-99;
  *                                   Camera::calculateCameraParameters, Graphics/Camera/Camera.cpp:129-136)

@@ -242,8 +242,8 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
   }
   // traversal-stack overflow rows for the largest persistent grid (kMaxPersistentPerCU waves per CU)
   c->stackOvfStride = (uint32_t)c->numCUs * kMaxPersistentPerCU * kWave;
-  if (kStackLds < kStackEntries &&
-      hipMalloc(reinterpret_cast<void**>(&c->stackOvf), (size_t)(kStackEntries - kStackLds) * c->stackOvfStride * sizeof(int)) != hipSuccess) {
+  if (kStackOvfRows > 0 &&
+      hipMalloc(reinterpret_cast<void**>(&c->stackOvf), (size_t)kStackOvfRows * c->stackOvfStride * sizeof(int)) != hipSuccess) {
     bdpt_destroy(c);
     return BDPT_E_NOMEM;
   }

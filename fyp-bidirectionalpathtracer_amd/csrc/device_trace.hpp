@@ -685,5 +685,181 @@ __global__ __launch_bounds__(kWave) void trace_shadow_quad_kernel(SceneDev S, Ra
 }
 #endif  // BDPT_QUAD_ANYHIT
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 3, profiles/README.md): two rays per lane.  Every lane owns a LIVE ray (registers) and a PARKED
+// one (14 dwords in LDS); when the live ray reaches a leaf and the parked one can take node visits the two swap, so
+// the node bursts — nine tenths of the work — run with the lanes the deferred-leaf loop leaves idle.  Each ray keeps
+// only KL rows of its stack in LDS (the rest in the context's overflow area), so that the wave holds twice the rays
+// in about the LDS the one-ray kernel uses.  Any-hit answers are independent of the order of traversal: visibility
+// bytes identical to trace_shadow_kernel.  Built only with -DBDPT_TWO_RAYS=1.
+// ------------------------------------------------------------------------------------------------
+#if BDPT_TWO_RAYS
+constexpr int kParkFields = 14;  // o d idir (9) neg tmax cur sp rid
+template <bool COUNT, int KL>
+__global__ __launch_bounds__(kWave) void trace_shadow2_kernel(SceneDev S0, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
+                                                              float shadowTmin) {
+  __shared__ int s_stack[2 * KL * kWave];
+  __shared__ uint32_t s_park[kParkFields * kWave];
+  const int lane = (int)(threadIdx.x & 63u);
+  uint32_t* park = s_park + lane;  // field f at park[f * 64]
+  bool has = false, hasParked = false, exhausted = false;
+  uint32_t rid = 0, which = 0;  // which half of the stack (and of the overflow rows) the live ray uses
+  TravState T;
+  T.cur = kDone;
+  T.tmin = shadowTmin;
+  uint32_t nNodes = 0, nTris = 0;
+  int maxSp = 0;
+  SceneDev S = S0;  // stackOvf is offset per lane by the live ray's half
+  auto bindStack = [&]() { S.stackOvf = S0.stackOvf + (size_t)which * (size_t)(kStackEntries - KL) * S0.stackOvfStride; };
+  bindStack();
+  auto initRay = [&](TravState& R, uint32_t idx) {
+    const float* r = Q.rays + idx;
+    const size_t c = Q.cap;
+    travInit(R, mk(r[0], r[c], r[2 * c]), mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
+  };
+  auto storeParked = [&](const TravState& R, uint32_t id) {
+    park[0 * 64] = __float_as_uint(R.o.x);
+    park[1 * 64] = __float_as_uint(R.o.y);
+    park[2 * 64] = __float_as_uint(R.o.z);
+    park[3 * 64] = __float_as_uint(R.d.x);
+    park[4 * 64] = __float_as_uint(R.d.y);
+    park[5 * 64] = __float_as_uint(R.d.z);
+    park[6 * 64] = __float_as_uint(R.idir.x);
+    park[7 * 64] = __float_as_uint(R.idir.y);
+    park[8 * 64] = __float_as_uint(R.idir.z);
+    park[9 * 64] = R.neg;
+    park[10 * 64] = __float_as_uint(R.tmax);
+    park[11 * 64] = (uint32_t)R.cur;
+    park[12 * 64] = (uint32_t)R.sp;
+    park[13 * 64] = id;
+  };
+  auto loadParked = [&](TravState& R, uint32_t& id) {
+    R.o = mk(__uint_as_float(park[0 * 64]), __uint_as_float(park[1 * 64]), __uint_as_float(park[2 * 64]));
+    R.d = mk(__uint_as_float(park[3 * 64]), __uint_as_float(park[4 * 64]), __uint_as_float(park[5 * 64]));
+    R.idir = mk(__uint_as_float(park[6 * 64]), __uint_as_float(park[7 * 64]), __uint_as_float(park[8 * 64]));
+    R.neg = park[9 * 64];
+    R.tmin = shadowTmin;
+    R.tmax = __uint_as_float(park[10 * 64]);
+    R.cur = (int)park[11 * 64];
+    R.sp = (int)park[12 * 64];
+    R.best.prim = -1;
+    R.best.t = R.tmax;
+    R.best.u = R.best.v = 0.0f;
+    id = park[13 * 64];
+  };
+  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
+  const uint32_t wavesPerList = (gridDim.x + Q.numSub - 1) / Q.numSub;
+  for (;;) {
+    // ---- refill: empty live slots first, then empty parked slots
+    const unsigned long long liveEmpty = __ballot(!has), parkEmpty = __ballot(!hasParked);
+    const int nLE = __popcll(liveEmpty), nPE = __popcll(parkEmpty);
+    if (!exhausted && (nLE >= kRefillIdle || nLE + nPE >= 2 * kRefillIdle)) {
+      uint32_t want = (uint32_t)(nLE + nPE), taken = 0;
+      const uint32_t rankL = (uint32_t)__popcll(liveEmpty & ((1ull << lane) - 1ull));
+      const uint32_t rankP = (uint32_t)nLE + (uint32_t)__popcll(parkEmpty & ((1ull << lane) - 1ull));
+      bool gotL = false, gotP = false;
+      uint32_t idL = 0, idP = 0;
+      while (want > 0 && !exhausted) {
+        while (chunkPos >= chunkEnd && !exhausted) {
+          const uint32_t nq = Q.count[q * kCursorStride];
+          uint32_t base = nq;
+          if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
+            uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
+            chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
+            if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], chunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          }
+          if (base < nq) {
+            chunkPos = base;
+            chunkEnd = (base + chunk < nq) ? base + chunk : nq;
+            tried = 0;
+          } else {
+            q = (q + 1 == Q.numSub) ? 0u : q + 1;
+            if (++tried >= Q.numSub) exhausted = true;
+          }
+        }
+        if (exhausted) break;
+        const uint32_t avail = chunkEnd - chunkPos;
+        const uint32_t take = (want < avail) ? want : avail;
+        if (!has && !gotL && rankL >= taken && rankL < taken + take) {
+          idL = q * Q.subCap + chunkPos + (rankL - taken);
+          gotL = true;
+        }
+        if (!hasParked && !gotP && rankP >= taken && rankP < taken + take) {
+          idP = q * Q.subCap + chunkPos + (rankP - taken);
+          gotP = true;
+        }
+        chunkPos += take;
+        taken += take;
+        want -= take;
+      }
+      if (gotL) {
+        rid = idL;
+        initRay(T, idL);
+        has = true;
+      }
+      if (gotP) {
+        TravState R;
+        initRay(R, idP);
+        storeParked(R, idP);
+        hasParked = true;
+      }
+    }
+    if (__ballot(has || hasParked) == 0ull) break;
+    // ---- a lane whose live slot is empty, or whose live ray waits at a leaf while the parked one can take node visits, swaps
+    {
+      const int parkedCur = hasParked ? (int)park[11 * 64] : kDone;
+      const bool swapIn = hasParked && (!has || (T.cur < 0 && parkedCur >= 0));
+      if (swapIn) {
+        TravState R;
+        uint32_t id2;
+        loadParked(R, id2);
+        if (has) storeParked(T, rid);
+        hasParked = has;
+        T = R;
+        rid = id2;
+        has = true;
+        which ^= 1u;
+        bindStack();
+      }
+    }
+    int* stk = s_stack + (int)which * KL * kWave + lane;
+    // ---- node visits in bursts; leaves once half of the live rays wait at one (device_trace.hpp trace_shadow_kernel)
+    if (has) {
+#pragma unroll 1
+      for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
+        if (COUNT) nNodes++;
+        nodeStep<0, KL>(S, T, stk);
+        if (COUNT) maxSp = T.sp > maxSp ? T.sp : maxSp;
+      }
+    }
+    const unsigned long long waitMask = __ballot(has && T.cur < 0), nodeMask = __ballot(has && T.cur >= 0);
+    const int waitNeed = (__popcll(waitMask | nodeMask) * BDPT_LEAF_WAIT_FRAC8 + 7) >> 3;
+    if ((int)__popcll(waitMask) >= waitNeed || nodeMask == 0ull) {
+      if (has && T.cur < 0) {
+        bool finished = (T.cur == kDone);
+        if (!finished) {
+          finished = leafStep<2, COUNT>(S, T, nTris);
+          if (!finished) {
+            T.cur = travPop<KL>(S, T, stk);
+            finished = (T.cur == kDone);
+          }
+        }
+        if (finished) {
+          vis[rid] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
+          has = false;
+          T.cur = kDone;
+        }
+      }
+    }
+  }
+  if (COUNT) {
+    waveAddCount(counters, C_NODE_SHADOW, nNodes);
+    waveAddCount(counters, C_TRI_SHADOW, nTris);
+    if (maxSp > 0) atomicMax(&counters->v[blockIdx.x % kCounterShards][C_STACK_MAX], (unsigned long long)maxSp);
+  }
+}
+#endif  // BDPT_TWO_RAYS
+
 #undef BD
 }  // namespace bdpt

@@ -1420,7 +1420,15 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
              P.rayHead + (size_t)cls * kRayCursorBlock};
   uint8_t* vis = P.rayVis + P.rayBase[cls];
   uint32_t& g = G.shadow[cnt ? 1 : 0];
-#if BDPT_QUAD_ANYHIT
+#if BDPT_TWO_RAYS
+  if (cnt) {
+    if (!g) g = persistentGrid(trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>, numCUs);
+    hipLaunchKernelGGL((trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>), dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
+  } else {
+    if (!g) g = persistentGrid(trace_shadow2_kernel<false, BDPT_TWO_RAYS_KL>, numCUs);
+    hipLaunchKernelGGL((trace_shadow2_kernel<false, BDPT_TWO_RAYS_KL>), dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
+  }
+#elif BDPT_QUAD_ANYHIT
   if (cnt) {
     if (!g) g = persistentGrid(trace_shadow_quad_kernel<true>, numCUs);
     hipLaunchKernelGGL(trace_shadow_quad_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
@@ -1492,7 +1500,10 @@ void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode,
 void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap, const uint32_t* count, uint32_t* head, uint8_t* vis,
                            DevCounters* counters, float tmin, int numCUs, hipStream_t st) {
   RayQueue Q{planes, cap, cap, 1u, count, head};
-#if BDPT_QUAD_ANYHIT
+#if BDPT_TWO_RAYS
+  const uint32_t g = persistentGrid(trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>, numCUs);
+  hipLaunchKernelGGL((trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>), dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
+#elif BDPT_QUAD_ANYHIT
   const uint32_t g = persistentGrid(trace_shadow_quad_kernel<true>, numCUs);
   hipLaunchKernelGGL(trace_shadow_quad_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
 #else

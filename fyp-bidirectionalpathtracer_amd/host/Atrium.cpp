@@ -529,7 +529,7 @@ Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, fl
   Builder b{*s, lo, seed};
   buildGeometry(b);
   if (s->getTriangleCount() < targetTriangles) addPebbles(*s, targetTriangles - s->getTriangleCount(), seed);
-  if (foliage) addFoliage(*s, total - s->getTriangleCount(), seed);
+  if (foliage) addFoliage(*s, total > s->getTriangleCount() ? total - s->getTriangleCount() : 0u, seed);  // (never below zero: the base may overshoot a small target)
   addTexturesAndMaterials(*s, seed);
   if (foliage) addLeafMaterial(*s, seed);
 

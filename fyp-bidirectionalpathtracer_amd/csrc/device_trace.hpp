@@ -283,7 +283,8 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   // quads, fetched side by side (the test has no side effect, so running the second one although the first triangle may
   // end an any-hit query changes nothing but a little traffic).
   const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(uint32_t)~T.cur * 3;
-  const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2], a1 = tp[3], b1 = tp[4], c1 = tp[5];
+  const float4 a0 = ldMaybeNt4<2>(tp), b0 = ldMaybeNt4<2>(tp + 1), c0 = ldMaybeNt4<2>(tp + 2), a1 = ldMaybeNt4<2>(tp + 3), b1 = ldMaybeNt4<2>(tp + 4),
+               c1 = ldMaybeNt4<2>(tp + 5);
   if (COUNT) nTris++;
   TriCand k0 = triGeom<MODE>(T, a0, b0, c0), k1;
   k1.ok = false;
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
           rid = idx;
           const float* r = Q.rays + idx;
           const size_t c = Q.cap;
-          travInit(T, mk(r[0], r[c], r[2 * c]), mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
+          travInit(T, mk(ldMaybeNt<1>(r), ldMaybeNt<1>(r + c), ldMaybeNt<1>(r + 2 * c)),
+                   mk(ldMaybeNt<1>(r + 3 * c), ldMaybeNt<1>(r + 4 * c), ldMaybeNt<1>(r + 5 * c)), shadowTmin, ldMaybeNt<1>(r + 6 * c));
           has = true;
         }
         chunkPos += take;

@@ -105,12 +105,24 @@ BD Vtx zeroVtx() {
 }
 BD void storeVtx(const PathBuf& P, int path, int k, uint32_t p, const Vtx& v) {
   float4* r = vtxPtr(P, path, k, p);
-  r[0] = make_float4(v.pos.x, v.pos.y, v.pos.z, v.rough);
-  r[1] = make_float4(v.N.x, v.N.y, v.N.z, v.isSpec ? 1.0f : 0.0f);
-  r[2] = make_float4(v.dif.x, v.dif.y, v.dif.z, v.pdf);
-  r[3] = make_float4(v.spec.x, v.spec.y, v.spec.z, 0.0f);
-  r[4] = make_float4(v.color.x, v.color.y, v.color.z, 0.0f);
-  r[5] = make_float4(v.V.x, v.V.y, v.V.z, 0.0f);
+  const float4 q0 = make_float4(v.pos.x, v.pos.y, v.pos.z, v.rough), q1 = make_float4(v.N.x, v.N.y, v.N.z, v.isSpec ? 1.0f : 0.0f),
+               q2 = make_float4(v.dif.x, v.dif.y, v.dif.z, v.pdf), q3 = make_float4(v.spec.x, v.spec.y, v.spec.z, 0.0f),
+               q4 = make_float4(v.color.x, v.color.y, v.color.z, 0.0f), q5 = make_float4(v.V.x, v.V.y, v.V.z, 0.0f);
+  if (BDPT_NT & 4) {
+    stNt4(r, q0);
+    stNt4(r + 1, q1);
+    stNt4(r + 2, q2);
+    stNt4(r + 3, q3);
+    stNt4(r + 4, q4);
+    stNt4(r + 5, q5);
+  } else {
+    r[0] = q0;
+    r[1] = q1;
+    r[2] = q2;
+    r[3] = q3;
+    r[4] = q4;
+    r[5] = q5;
+  }
 }
 // geometry + material of a stored vertex (no colour, no V); GGX = false skips the fields Lambert never reads
 template <bool GGX = true>

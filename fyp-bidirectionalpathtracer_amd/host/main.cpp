@@ -21,7 +21,7 @@ static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t 
 int main(int argc, char** argv) {
   std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume, envFile;
   uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
-  int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100, inflight = 1;
+  int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100, inflight = 1, warmup = 0;
   bool denoise = false, denoiseRegression = false;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
@@ -44,10 +44,11 @@ int main(int argc, char** argv) {
     else if (const char* v = next("--resume")) resume = v;
     else if (const char* v = next("--env")) envFile = v;
     else if (const char* v = next("--inflight")) inflight = std::atoi(v);
+    else if (const char* v = next("--warmup")) warmup = std::atoi(v);  // of --frames: rendered before the clock starts (first-use allocations)
     else {
       std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
                            "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32] "
-                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black] [--inflight N]\n");
+                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black] [--inflight N] [--warmup N]\n");
       return 2;
     }
   }
@@ -99,15 +100,18 @@ int main(int argc, char** argv) {
     return 1;
   }
 
+  if (warmup < 0 || warmup >= frames) warmup = 0;
+  for (int f = 0; f < warmup; f++) pipeline->renderFrame();
+  (void)hipDeviceSynchronize();
   auto t0 = std::chrono::steady_clock::now();
-  for (int f = 0; f < frames; f++) pipeline->renderFrame();
+  for (int f = warmup; f < frames; f++) pipeline->renderFrame();
   (void)hipDeviceSynchronize();
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::vector<float> img = pipeline->readOutput();
   double mean = 0;
   for (size_t i = 0; i < img.size(); i += 4) mean += img[i] + img[i + 1] + img[i + 2];
   std::printf("%s %ux%u depth %d mat %d: %d frames in %.2f ms (%.2f ms/frame), mean radiance %.6f\n", scene.c_str(), W, H, depth, mat,
-              frames, ms, ms / frames, mean / (3.0 * (double)(img.size() / 4)));
+              frames - warmup, ms, ms / (frames - warmup), mean / (3.0 * (double)(img.size() / 4)));
   writePfm(out.c_str(), img, W, H);
   if (!checkpoint.empty() && !pipeline->saveCheckpoint(checkpoint)) {
     std::fprintf(stderr, "bdpt_render: cannot write %s\n", checkpoint.c_str());

@@ -189,3 +189,59 @@ def test_pre_splitting_cuts_visits_on_overlapping_cards(pkg):
     assert (res[0][0] == res[1][0]).all() and (res[0][1].view(np.uint32) == res[1][1].view(np.uint32)).all()
     assert res[1][2][1] < 0.75 * res[0][2][1], (res[0][2], res[1][2])
     scene.close()
+
+
+def test_builder_edge_cases_all_dropped_no_texcoords_huge_tiling_degenerate(pkg):
+    """Corners of the reference-building code: a scene whose every triangle fails the alpha test everywhere (an empty
+    tree), an alpha-mode material on a mesh without texture coordinates (nothing can be classified: every hit is
+    tested, at uv = 0), texture coordinates tiled hundreds of times over one triangle (the footprint covers the whole
+    texture), and zero-area triangles among the split ones — the tree must still answer like the linear scan."""
+    lib = pkg.load_library()
+    rays = _grid_rays(24)
+    # 1. only the card, all texels transparent
+    d, keep = _card_scene(pkg, [[0] * 4] * 4)
+    d.numTriangles = 2
+    info = pkg.abi.BvhInfo()
+    h = lib.bdpt_host_bvh_create(C.byref(d), 1, -1.0, -1.0, 1, C.byref(info))
+    assert h and info.numDropped == 2 and info.numReferences == 0
+    for mode in (0, 1, 2):
+        prim, _, vis = _trace(lib, h, rays, mode, 0)
+        assert (prim < 0).all() and vis[1] == 0  # nothing to test
+        assert (_trace(lib, h, rays, mode, 1)[0] < 0).all()
+    lib.bdpt_host_bvh_destroy(h)
+    # 2. no texture coordinates at all
+    d, keep = _card_scene(pkg, [[255, 0, 255, 0]] * 4)
+    d.texcoords = None
+    h0 = lib.bdpt_host_bvh_create(C.byref(d), 1, 0.0, 0.0, 0, C.byref(info))
+    h1 = lib.bdpt_host_bvh_create(C.byref(d), 1, 1.0, 6.0, 1, C.byref(info))
+    assert info.numAlwaysPass == 0 and info.numDropped == 0
+    for mode in (0, 2):
+        a, b = _trace(lib, h0, rays, mode, 1), _trace(lib, h1, rays, mode, 0)
+        assert ((a[0] >= 0) == (b[0] >= 0)).all() and (mode == 2 or (a[0] == b[0]).all())
+    lib.bdpt_host_bvh_destroy(h0)
+    lib.bdpt_host_bvh_destroy(h1)
+    # 3. the texture repeated 300 times across the card: mixed texels -> nothing classified, everything answers the same
+    d, keep = _card_scene(pkg, [[255, 0, 0, 255]] * 4, uv_scale=300.0)
+    h0 = lib.bdpt_host_bvh_create(C.byref(d), 1, 0.0, 0.0, 0, C.byref(info))
+    h1 = lib.bdpt_host_bvh_create(C.byref(d), 1, 0.0, 16.0, 1, C.byref(info))
+    assert info.numAlwaysPass == 0 and info.numDropped == 0
+    fine = _grid_rays(96)
+    for mode in (0, 2):
+        a, b = _trace(lib, h0, fine, mode, 1), _trace(lib, h1, fine, mode, 0)
+        assert ((a[0] >= 0) == (b[0] >= 0)).all() and (mode == 2 or ((a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all()))
+    first = _trace(lib, h1, fine, 0, 0)[0]
+    on_card = (fine[:, 0] > 0.02) & (fine[:, 0] < 0.98) & (fine[:, 1] > 0.02) & (fine[:, 1] < 0.98)
+    assert 0.2 < (first[on_card] < 2).mean() < 0.8  # about half of the card lets rays through to the floor
+    lib.bdpt_host_bvh_destroy(h0)
+    lib.bdpt_host_bvh_destroy(h1)
+    # 4. zero-area triangles: collapse the card's second triangle onto an edge; it can never be hit, the rest still is
+    d, keep = _card_scene(pkg, [[255] * 4, [0] * 4, [255] * 4, [0] * 4])
+    pos = keep[1]
+    pos[3] = pos[2]  # vertex 3 := vertex 2: triangle (0, 2, 3) degenerates
+    h0 = lib.bdpt_host_bvh_create(C.byref(d), 1, 0.0, 0.0, 0, C.byref(info))
+    h1 = lib.bdpt_host_bvh_create(C.byref(d), 1, 2.0, 12.0, 1, C.byref(info))
+    for mode in (0, 1, 2):
+        a, b = _trace(lib, h0, rays, mode, 1), _trace(lib, h1, rays, mode, 0)
+        assert ((a[0] >= 0) == (b[0] >= 0)).all() and (mode == 2 or (a[0] == b[0]).all())
+    lib.bdpt_host_bvh_destroy(h0)
+    lib.bdpt_host_bvh_destroy(h1)

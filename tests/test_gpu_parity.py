@@ -753,3 +753,65 @@ def test_cpp_host_frames_in_flight_accumulate_the_same_image(pkg, tmp_path):
     d = run(["--frames", "4", "--denoise"], "dn1.f32")
     e = run(["--frames", "4", "--denoise", "--inflight", "3"], "dn3.f32")
     assert np.array_equal(d.view(np.uint32), e.view(np.uint32))
+
+
+def test_per_piece_alpha_classification_on_the_device(pkg, ob):
+    """The acceleration structure bdpt_set_scene uploads is built over clipped / dropped pieces (csrc/alpha_clip.cpp):
+    a card whose texels all fail leaves an EMPTY tree (every ray misses: the frame is the environment colour), one with
+    a cut-out pattern keeps only the pieces that can be hit — and the frames still equal the oracle's, which runs the
+    alpha test on every candidate of every alpha-mode triangle as the reference does."""
+    import torch
+    import test_bvh_builder as tb
+    A = pkg.abi
+    lib = pkg.load_library()
+    W, H, D = 64, 48, 4
+    cam = A.Camera()
+    f3 = C.c_float * 3
+    assert lib.bdpt_camera_look_at(f3(0.4, 0.45, 2.2), f3(0.5, 0.5, 0.0), f3(0.0, 1.0, 0.0), 30.0, 24.0, W / H, 1.0, C.byref(cam)) == 0
+    stripes = [[255, 255, 0, 0, 255, 0, 0, 0]] * 4 + [[0, 0, 0, 0, 0, 0, 255, 255]] * 4
+    for name, rows, card_only in (("all_fail_card_only", [[0] * 8] * 8, True), ("pattern", stripes, False), ("all_pass", [[255] * 8] * 8, False)):
+        d, keep = tb._card_scene(pkg, rows)
+        if card_only:
+            d.numTriangles = 2
+        ctx = pkg.Context(0)
+        ctx.set_scene(d)
+        info = ctx.bvh_info()
+        if name == "all_fail_card_only":
+            assert info.numDropped == 2 and info.numReferences == 0
+        if name == "all_pass":
+            assert info.numAlwaysPass == 2
+        if name == "pattern":
+            assert info.numReferences > 4 and info.numDropped == 0
+        ctx.set_camera(cam)
+        ctx.resize(W, H, 0, H, D)
+        chans = {"WorldPosition": torch.zeros(H, W, 4, dtype=torch.float32, device="cuda")}
+        for n in ("WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams", "Emissive"):
+            chans[n] = torch.zeros(H, W, 4, dtype=torch.float16, device="cuda")
+        out = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda")
+        gb = A.GBuffer(*[chans[n].data_ptr() for n in ("WorldPosition", "WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams", "Emissive")])
+        gp = A.GBufferParams()
+        gp.pixelJitter[0] = gp.pixelJitter[1] = 0.5
+        gp.frameCount, gp.focalLen = 0xdeadbeef, 1.0
+        for i, c in enumerate((0.5, 0.5, 0.8, 1.0)):
+            gp.envColor[i] = c
+        p = A.Params()
+        p.minT, p.frameCount, p.matIndex, p.maxDepth = 1e-4, 0x1337, 0, D
+        p.refractiveIndex, p.emitMult, p.clampUpper = 1.0, 1.0, 0.9
+        p.pixelJitter[0] = p.pixelJitter[1] = 0.5
+        ctx.gbuffer_execute(gp, gb, None)
+        ctx.execute(p, gb, C.c_void_p(out.data_ptr()), None)
+        torch.cuda.synchronize()
+        orc = ob.OracleRender(A, d, W, H)
+        orc.gbuffer(cam, gp)
+        orc.bdpt(cam, p)
+        orc.resolve()
+        gpu, ref = out.cpu().numpy(), orc.image()
+        assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), (name, int((gpu != ref).any(axis=-1).sum()))
+        wp = chans["WorldPosition"].cpu().numpy()
+        assert np.array_equal(wp.view(np.uint32), orc.chan["worldPosition"].reshape(H, W, 4).view(np.uint32)), name
+        if name == "all_fail_card_only":
+            assert (wp[..., 3] == 0).all() and np.allclose(gpu[..., :3], [0.5, 0.5, 0.8], atol=1e-3)
+        else:
+            assert (wp[..., 3] != 0).mean() > 0.5
+        orc.close()
+        ctx.close()

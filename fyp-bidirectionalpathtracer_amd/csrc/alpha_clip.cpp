@@ -140,8 +140,12 @@ bool AlphaClipper::cellRect(uint32_t tri, const double (*poly)[2], int n, const 
     big = std::max(big, std::max(std::fabs(uv[k][0]), std::fabs(uv[k][1])));
   }
   if (big > 4096.0) return false;
-  // what separates the device's fp32 texel coordinate from the exact one: a few ulps of the coordinate's magnitude
-  margin = 0.05 + 1e-5 * (big + 1.0) * (double)std::max(m->w, m->h);
+  // What separates the texel the device's alpha test samples from the one under the exact hit point: the fp32
+  // rounding of the coordinate itself (a few ulps of its magnitude) and, for rays that graze the triangle, the error of
+  // the Moeller-Trumbore barycentrics (eps * distance / (extent * sin of the incidence angle)).  Half a texel covers
+  // the second down to a fraction of a degree for a card a few hundred texels across — the same order of world-space
+  // slack as the pad every box of the tree gets (bvh_build.cpp: 2e-5 of the scene diagonal).
+  margin = 0.5 + 1e-5 * (big + 1.0) * (double)std::max(m->w, m->h);
   double xa = 1e300, xb = -1e300, ya = 1e300, yb = -1e300;
   for (int k = 0; k < n; k++) {
     const double b0 = 1.0 - poly[k][0] - poly[k][1];

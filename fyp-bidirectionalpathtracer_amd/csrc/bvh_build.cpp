@@ -1122,7 +1122,7 @@ bool packBvh(Bvh& bvh, int threads) {
           for (uint32_t k = 0; k < cnt; k++) {
             BvhTri t = bvh.tris[first + k];
             if (k + 1 == cnt) t.flags |= kTriLastOfLeaf;
-            std::memcpy(&bvh.recs[(size_t)base[i] + off + k], &t, sizeof(BvhRec));
+            std::memcpy(&bvh.recs[(size_t)base[i] + off + k], &t, sizeof(BvhTri));
           }
           off += cnt;
         }

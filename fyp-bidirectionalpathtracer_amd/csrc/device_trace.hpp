@@ -8,6 +8,7 @@
 // Hit iff tmin < t < tmax; closest-hit ties resolve to the lowest primitive index so the result
 // does not depend on traversal order (and equals a brute-force scan).
 #pragma once
+#include "bvh.h"  // record slot size (kRecF4)
 #include "device_scene.hpp"
 
 namespace bdpt {
@@ -89,7 +90,7 @@ BD float ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  /
 // entered, the rest stacked in slot order; ORDER 0 (any hit): slot order.
 template <int ORDER, int KL = kStackEntries>
 BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
-  const uint4* np = S.recs + (size_t)T.cur * 3;
+  const uint4* np = S.recs + (size_t)T.cur * kRecF4;
   // origin.xyz, exponents + leaf bits | lo.x lo.y lo.z hi.x | hi.y hi.z childBase childOffsets   (bvh.h BvhRec)
   const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
   const float sx = __uint_as_float((q0.w << 23) & 0x7f800000u), sy = __uint_as_float((q0.w << 15) & 0x7f800000u),
@@ -282,9 +283,9 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   // for nothing (the array ends with a pad record).  Likewise the alpha tests of the two: both records, then both texel
   // quads, fetched side by side (the test has no side effect, so running the second one although the first triangle may
   // end an any-hit query changes nothing but a little traffic).
-  const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(uint32_t)~T.cur * 3;
-  const float4 a0 = ldMaybeNt4<2>(tp), b0 = ldMaybeNt4<2>(tp + 1), c0 = ldMaybeNt4<2>(tp + 2), a1 = ldMaybeNt4<2>(tp + 3), b1 = ldMaybeNt4<2>(tp + 4),
-               c1 = ldMaybeNt4<2>(tp + 5);
+  const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(uint32_t)~T.cur * kRecF4;
+  const float4 a0 = ldMaybeNt4<2>(tp), b0 = ldMaybeNt4<2>(tp + 1), c0 = ldMaybeNt4<2>(tp + 2), a1 = ldMaybeNt4<2>(tp + kRecF4),
+               b1 = ldMaybeNt4<2>(tp + kRecF4 + 1), c1 = ldMaybeNt4<2>(tp + kRecF4 + 2);
   if (COUNT) nTris++;
   TriCand k0 = triGeom<MODE>(T, a0, b0, c0), k1;
   k1.ok = false;
@@ -307,12 +308,12 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   if (k0.ok && triCommit<MODE>(T, k0)) return true;
   if (k1.ok && triCommit<MODE>(T, k1)) return true;
   bool last = k1.last;
-  tp += 6;
+  tp += 2 * kRecF4;
   while (!last) {  // leaves of more than two triangles (builder knob BDPT_LEAF_MAX)
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) nTris++;
     if (triStep<MODE>(S, T, a, b, c, last)) return true;
-    tp += 3;
+    tp += kRecF4;
   }
   return false;
 }
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_quad_kernel(SceneDev S, Ra
       int ref = kDone;
       if (at) {
         if (COUNT && sub == 0) nNodes++;
-        const uint4* np = S.recs + (size_t)cur * 3;
+        const uint4* np = S.recs + (size_t)cur * kRecF4;
         const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
         const uint32_t sh = 8u * (uint32_t)sub;
         const float sx = __uint_as_float((q0.w << 23) & 0x7f800000u), sy = __uint_as_float((q0.w << 15) & 0x7f800000u),
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_quad_kernel(SceneDev S, Ra
         bool lastHere = false, hitHere = false;
         float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
         if (more) {
-          const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(base + (uint32_t)sub) * 3;
+          const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(base + (uint32_t)sub) * kRecF4;
           a = tp[0];
           b = tp[1];
           c = tp[2];

@@ -214,40 +214,42 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, frames=3):
     """One more BASELINE shape on this GPU, one frame in flight: ms per frame, Mrays/s, visits per ray, stage times."""
     t0 = time.time()
     pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, accum_limit=1 << 30)
-    torch.cuda.synchronize()
-    setup = time.time() - t0
-    pipe.render_frame(accumulate=True)
-    torch.cuda.synchronize()
-    pipe.ctx.enable_stage_timing(True)
-    agg = {}
-    pipe.render_frame(accumulate=True)
-    for k, v in pipe.ctx.stage_times():
-        agg[k] = v
-    pipe.ctx.enable_stage_timing(False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(frames):
-        pipe.render_frame(accumulate=True, extra_flags=pkg.abi.PARAM_KEEP_COUNTERS if k else 0)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / frames
-    c = pipe.ctx.counters().as_dict()
-    rays = (sum(c[k] for k in RAY_KEYS) + frames * W * H) / frames
-    pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
-    torch.cuda.synchronize()
-    s = pipe.ctx.counters().as_dict()
-    shadow = max(1, s["raysNee"] + s["raysSplat"] + s["raysConnect"])
-    closest = max(1, s["raysEyeExtend"] + s["raysLightExtend"])
-    info = pipe.ctx.bvh_info()
-    free, total = torch.cuda.mem_get_info()
-    out = {"workload": name, "resolution": [W, H], "max_depth": D, "mat_index": mat, "frames_timed": frames, "frames_in_flight": 1,
-           "ms_per_frame": round(dt * 1e3, 3), "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
-           "visits_per_ray": {"closest_nodes": round(s["nodeVisitsClosest"] / closest, 2), "closest_tris": round(s["triTestsClosest"] / closest, 2),
-                              "shadow_nodes": round(s["nodeVisitsShadow"] / shadow, 2), "shadow_tris": round(s["triTestsShadow"] / shadow, 2)},
-           "stage_ms": {k: round(v, 2) for k, v in agg.items() if v >= 0.05},
-           "bvh": {"nodes": info.numNodes, "references": info.numReferences, "triangles": info.numTriangles,
-                   "alpha_mode_triangles": info.numAlphaMode, "always_pass": info.numAlwaysPass, "dropped": info.numDropped},
-           "setup_s": round(setup, 2), "device_memory_gb": round((total - free) / 2 ** 30, 1)}
-    pipe.close()
+    try:
+        torch.cuda.synchronize()
+        setup = time.time() - t0
+        pipe.render_frame(accumulate=True)
+        torch.cuda.synchronize()
+        pipe.ctx.enable_stage_timing(True)
+        agg = {}
+        pipe.render_frame(accumulate=True)
+        for k, v in pipe.ctx.stage_times():
+            agg[k] = v
+        pipe.ctx.enable_stage_timing(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            pipe.render_frame(accumulate=True, extra_flags=pkg.abi.PARAM_KEEP_COUNTERS if k else 0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+        c = pipe.ctx.counters().as_dict()
+        rays = (sum(c[k] for k in RAY_KEYS) + frames * W * H) / frames
+        pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
+        torch.cuda.synchronize()
+        s = pipe.ctx.counters().as_dict()
+        shadow = max(1, s["raysNee"] + s["raysSplat"] + s["raysConnect"])
+        closest = max(1, s["raysEyeExtend"] + s["raysLightExtend"])
+        info = pipe.ctx.bvh_info()
+        free, total = torch.cuda.mem_get_info()
+        out = {"workload": name, "resolution": [W, H], "max_depth": D, "mat_index": mat, "frames_timed": frames, "frames_in_flight": 1,
+               "ms_per_frame": round(dt * 1e3, 3), "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
+               "visits_per_ray": {"closest_nodes": round(s["nodeVisitsClosest"] / closest, 2), "closest_tris": round(s["triTestsClosest"] / closest, 2),
+                                  "shadow_nodes": round(s["nodeVisitsShadow"] / shadow, 2), "shadow_tris": round(s["triTestsShadow"] / shadow, 2)},
+               "stage_ms": {k: round(v, 2) for k, v in agg.items() if v >= 0.05},
+               "bvh": {"nodes": info.numNodes, "references": info.numReferences, "triangles": info.numTriangles,
+                       "alpha_mode_triangles": info.numAlphaMode, "always_pass": info.numAlwaysPass, "dropped": info.numDropped},
+               "setup_s": round(setup, 2), "device_memory_gb": round((total - free) / 2 ** 30, 1)}
+    finally:
+        pipe.close()
     return out
 
 
@@ -572,37 +574,54 @@ def main():
             },
         }
 
-    # ---- informational passes at N = 1 (rank 0 only; the headline above is already final)
+    # ---- informational passes at N = 1 (rank 0 only; the headline above is already final: whatever goes wrong below is
+    # recorded in the line instead of losing it)
+    def guarded(key, fn):
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001 — the driver needs the JSON line whatever an informational leg does
+            out["config"].setdefault("informational_errors", {})[key] = "%s: %s" % (type(e).__name__, str(e)[:300])
+
     if rank == 0 and world == 1 and dist is None:
         if args.single_pass:
-            R1 = TileRenderer(pkg, scene, W, H, D, mat, local_rank, 1, 0, None, 1)
-            for _ in range(2):
-                R1.step()
-            R1.barrier()
-            R1.rewind(*mark)
-            dt1, rays1 = timed_frames(R1, pkg, args.steps)
-            out["config"]["single_frame_in_flight"] = {
-                "frames_in_flight": 1, "value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 3),
-                "note": "same frames, one context, no host synchronisation either; informational (the kernels' solo durations of the roofline block add up to this loop)"}
-            R1.close()
+            def single():
+                R1 = TileRenderer(pkg, scene, W, H, D, mat, local_rank, 1, 0, None, 1)
+                try:
+                    for _ in range(2):
+                        R1.step()
+                    R1.barrier()
+                    R1.rewind(*mark)
+                    dt1, rays1 = timed_frames(R1, pkg, args.steps)
+                    out["config"]["single_frame_in_flight"] = {
+                        "frames_in_flight": 1, "value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 3),
+                        "note": "same frames, one context, no host synchronisation either; informational (the kernels' solo durations of the roofline block add up to this loop)"}
+                finally:
+                    R1.close()
+            guarded("single_frame_in_flight", single)
         if not args.no_cpu_baseline:  # rank 0 at N=1 only
-            base, parity = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds, mark[0])
-            out["cpu_baseline"] = base
-            out.update(parity)
+            def cpu():
+                base, parity = cpu_baseline(pkg, scene, pipe, W, H, D, mat, args.cpu_seconds, mark[0])
+                out["cpu_baseline"] = base
+                out.update(parity)
+            guarded("cpu_baseline", cpu)
     R.close()
     if rank == 0 and world == 1 and dist is None and args.other_configs and args.scene == "atrium" and (W, H, D) == (1920, 1080, 8):
         others = []
-        s2 = pkg.Scene.cornell()
-        others.append(other_config(pkg, torch, "BASELINE configs[1]: Cornell box 1920x1080 depth 8, Lambertian", s2, 1920, 1080, 8, 1))
-        s2.close()
-        s4 = pkg.Scene.atrium(1, 2800000)
-        others.append(other_config(pkg, torch, "BASELINE configs[3] shape on ONE GPU: 2.8 M triangles (atrium generator, Bistro stand-in) 3840x2160 depth 12",
-                                   s4, 3840, 2160, 12, 0))
-        s4.close()
-        s5 = pkg.Scene.courtyard(2, 10000000, 0.5)
-        others.append(other_config(pkg, torch, "BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "
-                                   "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", s5, 3840, 2160, 16, 0))
-        s5.close()
+
+        def other(name, make, w, h, d, m):
+            def run():
+                sc = make()
+                try:
+                    others.append(other_config(pkg, torch, name, sc, w, h, d, m))
+                finally:
+                    sc.close()
+            guarded(name.split(":")[0], run)
+
+        other("BASELINE configs[1]: Cornell box 1920x1080 depth 8, Lambertian", pkg.Scene.cornell, 1920, 1080, 8, 1)
+        other("BASELINE configs[3] shape on ONE GPU: 2.8 M triangles (atrium generator, Bistro stand-in) 3840x2160 depth 12",
+              lambda: pkg.Scene.atrium(1, 2800000), 3840, 2160, 12, 0)
+        other("BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "
+              "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", lambda: pkg.Scene.courtyard(2, 10000000, 0.5), 3840, 2160, 16, 0)
         out["config"]["other_configs"] = others
     if rank == 0:
         print(json.dumps(out), flush=True)

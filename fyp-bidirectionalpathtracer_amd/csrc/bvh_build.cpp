@@ -115,6 +115,30 @@ void parallelFor(size_t n, int threads, const F& f) {
   for (std::thread& th : pool) th.join();
 }
 
+// [0, n) in chunks of `chunk` items handed out through an atomic counter (work per item may differ by orders of
+// magnitude: a split triangle against an untouched one); f(chunkIndex, first, last).  What a chunk produces must only
+// depend on its index, so that results assembled in chunk order do not depend on the thread count.
+template <class F>
+void parallelChunks(size_t n, int threads, size_t chunk, const F& f) {
+  const size_t numChunks = (n + chunk - 1) / chunk;
+  if (threads <= 1 || numChunks <= 1) {
+    for (size_t c = 0; c < numChunks; c++) f(c, c * chunk, std::min(n, (c + 1) * chunk));
+    return;
+  }
+  std::atomic<size_t> next{0};
+  auto worker = [&] {
+    for (;;) {
+      const size_t c = next.fetch_add(1);
+      if (c >= numChunks) return;
+      f(c, c * chunk, std::min(n, (c + 1) * chunk));
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  worker();
+  for (std::thread& th : pool) th.join();
+}
+
 struct BuildData {
   const std::vector<Box>& boxes;
   const std::vector<float>& cent;
@@ -664,62 +688,51 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       outlierArea = (float)BDPT_SPLIT_OUTLIER * areas[areas.size() / 2];
     }
   }
-  std::vector<Piece> whole;  // only kept for triangles that are clipped or split
   std::vector<double> prio(nTris, 0.0);
   std::vector<float> capOf(nTris, (float)BDPT_SPLIT_MAX_PER_TRI);  // splits a triangle may get at most
-  std::vector<uint8_t> state(nTris, 0);  // 0 = plain reference (triBox), 1 = has a Piece, 2 = dropped
-  std::vector<uint32_t> pieceOf(nTris, 0);
+  std::vector<uint8_t> state(nTris, 0);  // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
   const bool anySplit = budgetOpaque > 0.0f || budgetAlpha > 0.0f;
-  {
-    // pass 1: initial polygons of the non-opaque triangles (clipper) and every triangle's priority
-    std::vector<std::vector<Piece>> partPieces((size_t)threads);
-    std::vector<std::vector<uint32_t>> partIds((size_t)threads);
-    parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
-      for (size_t t = t0; t < t1; t++) {
-        const BvhTri& r = recs[t];
-        const bool alpha = (r.flags & kTriNonOpaque) != 0 && opt.clipper != nullptr;
-        Box bx = triBox[t];
-        double share = 1.0;
-        if (alpha) {
-          Piece pc;
-          pc.n = 3;
-          pc.b[0][0] = 0.0;
-          pc.b[0][1] = 0.0;
-          pc.b[1][0] = 1.0;
-          pc.b[1][1] = 0.0;
-          pc.b[2][0] = 0.0;
-          pc.b[2][1] = 1.0;
-          pc.splits = 0;
-          if (!opt.clipper->clip((uint32_t)t, pc.b, pc.n) || pc.n < 3) {
-            state[t] = 2;
-            continue;
-          }
-          const bool shrunk = !(pc.n == 3 && pc.b[0][0] == 0.0 && pc.b[0][1] == 0.0 && pc.b[1][0] == 1.0 && pc.b[1][1] == 0.0 &&
-                                pc.b[2][0] == 0.0 && pc.b[2][1] == 1.0);
-          if (shrunk) {
-            pc.box = intersectBox(polyBox(r, pc.b, pc.n), bx);
-            bx = pc.box;
-            share = polyArea2(pc.b, pc.n);
-            state[t] = 1;
-            partPieces[(size_t)th].push_back(pc);
-            partIds[(size_t)th].push_back((uint32_t)t);
-          }
-        }
-        const float budget = (r.flags & kTriNonOpaque) ? budgetAlpha : budgetOpaque;
-        if (budget > 0.0f && ((r.flags & kTriNonOpaque) || bx.area() >= outlierArea)) {
-          prio[t] = splitPriority(G, r, bx, share);
-          // an opaque outlier is cut down to about the size of its neighbours, not further
-          if (!(r.flags & kTriNonOpaque) && outlierArea > 0.0f)
-            capOf[t] = std::min((float)BDPT_SPLIT_MAX_PER_TRI, std::floor((float)BDPT_SPLIT_OUTLIER * bx.area() / outlierArea));
-        }
+  // the whole triangle as a piece, shrunk by the clipper where it is non-opaque; false: nothing of it can be hit.
+  // (Recomputed where it is needed again instead of kept: a piece is ~400 bytes and a scene may hold millions.)
+  auto wholePiece = [&](size_t t, Piece& pc, bool& shrunk) {
+    const BvhTri& r = recs[t];
+    pc.n = 3;
+    pc.b[0][0] = 0.0;
+    pc.b[0][1] = 0.0;
+    pc.b[1][0] = 1.0;
+    pc.b[1][1] = 0.0;
+    pc.b[2][0] = 0.0;
+    pc.b[2][1] = 1.0;
+    pc.splits = 0;
+    pc.box = triBox[t];
+    shrunk = false;
+    if (!((r.flags & kTriNonOpaque) != 0 && opt.clipper != nullptr)) return true;
+    if (!opt.clipper->clip((uint32_t)t, pc.b, pc.n) || pc.n < 3) return false;
+    shrunk = !(pc.n == 3 && pc.b[0][0] == 0.0 && pc.b[0][1] == 0.0 && pc.b[1][0] == 1.0 && pc.b[1][1] == 0.0 && pc.b[2][0] == 0.0 && pc.b[2][1] == 1.0);
+    if (shrunk) pc.box = intersectBox(polyBox(r, pc.b, pc.n), triBox[t]);
+    return true;
+  };
+  // pass 1: what the clipper leaves of every non-opaque triangle, and every triangle's priority
+  constexpr size_t kRefChunk = 8192;
+  parallelChunks(nTris, threads, kRefChunk, [&](size_t, size_t t0, size_t t1) {
+    for (size_t t = t0; t < t1; t++) {
+      const BvhTri& r = recs[t];
+      Piece pc;
+      bool shrunk = false;
+      if (!wholePiece(t, pc, shrunk)) {
+        state[t] = 2;
+        continue;
       }
-    });
-    for (int th = 0; th < threads; th++)
-      for (size_t k = 0; k < partIds[(size_t)th].size(); k++) {
-        pieceOf[partIds[(size_t)th][k]] = (uint32_t)whole.size();
-        whole.push_back(partPieces[(size_t)th][k]);
+      state[t] = shrunk ? 1 : 0;
+      const float budget = (r.flags & kTriNonOpaque) ? budgetAlpha : budgetOpaque;
+      if (budget > 0.0f && ((r.flags & kTriNonOpaque) || pc.box.area() >= outlierArea)) {
+        prio[t] = splitPriority(G, r, pc.box, shrunk ? polyArea2(pc.b, pc.n) : 1.0);
+        // an opaque outlier is cut down to about the size of its neighbours, not further
+        if (!(r.flags & kTriNonOpaque) && outlierArea > 0.0f)
+          capOf[t] = std::min((float)BDPT_SPLIT_MAX_PER_TRI, std::floor((float)BDPT_SPLIT_OUTLIER * pc.box.area() / outlierArea));
       }
-  }
+    }
+  });
   // split counts per class: the largest D with sum floor(D p_t) <= budget (integer sums: thread-count independent)
   std::vector<uint32_t> splits(nTris, 0);
   if (anySplit && nTris) {
@@ -768,32 +781,27 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     }
   }
   lap("priorities");
-  // pass 2: the references, triangle order (thread chunks are contiguous triangle ranges, appended in order)
+  // pass 2: the references, triangle order (chunks are contiguous triangle ranges, appended in order)
   std::vector<Box> boxes;
   std::vector<uint32_t> refTri;
   {
-    std::vector<RefOut> part((size_t)threads);
-    parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
-      RefOut& o = part[(size_t)th];
+    std::vector<RefOut> part((nTris + kRefChunk - 1) / kRefChunk);  // one per chunk, appended in chunk order below
+    parallelChunks(nTris, threads, kRefChunk, [&](size_t ci, size_t t0, size_t t1) {
+      RefOut& o = part[ci];
       for (size_t t = t0; t < t1; t++) {
         if (state[t] == 2) continue;
-        if (splits[t] == 0) {
-          o.boxes.push_back(state[t] == 1 ? whole[pieceOf[t]].box : triBox[t]);
+        if (splits[t] == 0 && state[t] == 0) {
+          o.boxes.push_back(triBox[t]);
           o.tri.push_back((uint32_t)t);
           continue;
         }
         Piece pc;
-        if (state[t] == 1) {
-          pc = whole[pieceOf[t]];
-        } else {
-          pc.n = 3;
-          pc.b[0][0] = 0.0;
-          pc.b[0][1] = 0.0;
-          pc.b[1][0] = 1.0;
-          pc.b[1][1] = 0.0;
-          pc.b[2][0] = 0.0;
-          pc.b[2][1] = 1.0;
-          pc.box = triBox[t];
+        bool shrunk = false;
+        if (!wholePiece(t, pc, shrunk)) continue;  // (cannot happen: pass 1 kept it)
+        if (splits[t] == 0) {
+          o.boxes.push_back(pc.box);
+          o.tri.push_back((uint32_t)t);
+          continue;
         }
         pc.splits = splits[t];
         const bool alpha = (recs[t].flags & kTriNonOpaque) != 0 && opt.clipper != nullptr;
@@ -814,8 +822,6 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     for (uint32_t t = 0; t < nTris; t++) dropped += state[t] == 2 ? 1u : 0u;
     out.numDropped = dropped;
   }
-  whole.clear();
-  whole.shrink_to_fit();
   const uint32_t n = (uint32_t)boxes.size();  // references from here on
   std::vector<float> cent((size_t)n * 3);
   parallelFor(n, threads, [&](size_t r0, size_t r1, int) {
@@ -868,9 +874,15 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     worker();
     for (std::thread& th : pool) th.join();
     lap("subtrees");
-    for (size_t j = 0; j < deferred.size(); j++) {
+    // the lists are appended in the order of `deferred` (children stay after parents); every list knows where it
+    // lands, so the copies run side by side
+    std::vector<size_t> at(deferred.size() + 1);
+    at[0] = tmp.size();
+    for (size_t j = 0; j < deferred.size(); j++) at[j + 1] = at[j] + local[j].size() - 1;
+    tmp.resize(at.back());
+    parallelChunks(deferred.size(), threads, 1, [&](size_t j, size_t, size_t) {
       const std::vector<TmpNode>& L = local[j];
-      const int32_t off = (int32_t)tmp.size() - 1;  // local index i >= 1 -> off + i
+      const int32_t off = (int32_t)at[j] - 1;  // local index i >= 1 -> off + i
       TmpNode rootNode = L[0];
       if (rootNode.left >= 0) {
         rootNode.left += off;
@@ -883,9 +895,9 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
           nd.left += off;
           nd.right += off;
         }
-        tmp.push_back(nd);
+        tmp[at[j] + i - 1] = nd;
       }
-    }
+    });
   }
 
   lap("append");

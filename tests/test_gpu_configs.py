@@ -257,20 +257,22 @@ def test_rccl_exchange_path_single_rank_reproduces_plain_run(pkg, tmp_path):
     assert np.isfinite(a).all() and a[..., :3].mean() > 0.01
 
 
-def _stripes_equal_full(pkg, scene, W, H, depth, mat, world):
+def _stripes_equal_full(pkg, scene, W, H, depth, mat, world, flags=0):
     """`world` contexts rendering interleaved stripes (bdpt_resize_stripes) with owner-major splat buffers; the
     integer sum of the buffers (what the reduce-scatter computes), each owner's chunk resolved with
     bdpt_resolve_tile, reproduces the single-context frame bit for bit."""
     import torch
-    full = pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat)
+    full = pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat, flags=flags)
+    full.ctx.set_environment(None, 0, 0, (0.6, 0.5, 0.4, 1.0))
     full.render_frame()
     torch.cuda.synchronize()
     ref = full.output.cpu().numpy()
     full.close()
     R = pkg.tiling.stripe_rows(H, world)
-    pipes = [pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat, stripes=(R, world, r)) for r in range(world)]
+    pipes = [pkg.FramePipeline(scene, W, H, max_depth=depth, mat_index=mat, stripes=(R, world, r), flags=flags) for r in range(world)]
     total = None
     for r, pp in enumerate(pipes):
+        pp.ctx.set_environment(None, 0, 0, (0.6, 0.5, 0.4, 1.0))
         assert pp.rows == pkg.tiling.stripes_of(H, world, r)
         info = pp.ctx.tile_info()
         assert info.chunkRows == pkg.tiling.chunk_rows(H, world) and info.splatU64 == world * info.chunkU64
@@ -303,6 +305,10 @@ def test_striped_tiles_equal_full_frame(pkg):
     the 8-owner split of a 1080p-shaped frame."""
     cornell, atrium = pkg.Scene.cornell(), pkg.Scene.atrium(2, 20000)
     _stripes_equal_full(pkg, cornell, 40, 37, 4, 0, 3)
+    # the environment / emissive terms of the eye walk (BDPT_PARAM_ENV_ON_MISS | _EMISSIVE_HITS) go to the tile's own pixels
+    a = _stripes_equal_full(pkg, atrium, 64, 45, 5, 0, 3, flags=pkg.abi.PARAM_ENV_ON_MISS | pkg.abi.PARAM_EMISSIVE_HITS)
+    b = _stripes_equal_full(pkg, atrium, 64, 45, 5, 0, 3)
+    assert not np.array_equal(a, b)
     _stripes_equal_full(pkg, cornell, 24, 3, 3, 1, 4)       # 3 rows, 4 owners: owner 3 renders nothing
     _stripes_equal_full(pkg, atrium, 192, 108, 5, 0, 8)
     cornell.close()

@@ -386,3 +386,30 @@ def test_decoders_refuse_oversized_headers_without_allocating(pkg, tmp_path):
     open(tmp_path / "big.jpg", "wb").write(jpg)
     assert lib.bdpt_image_load(str(tmp_path / "big.jpg").encode(), C.byref(w), C.byref(h), None, None, 0, msg, 256) != 0
     assert b"limit" in msg.value, msg.value
+
+
+def test_reference_scene_texture_files_decode_to_their_pillow_digests(pkg):
+    """The reference's OWN data for this path: the 28 texture files of its pink_room scene.  Each must decode through
+    the loader (host/ImageDecode.cpp) to exactly the texels an independent decoder (Pillow) produces — committed as
+    SHA-256 digests by tests/golden/make_pink_room_texture_digests.py — with the size and the 32-bit-image verdict
+    (Utils/Bitmap.cpp:104-126: what makes a material's alpha mode Mask) the fixture records.  Needs the reference
+    checkout (present where the CPU suite runs; the GPU box has neither the files nor this test's marker)."""
+    import hashlib
+    import json
+    import os
+    src = "/root/reference/src/CommonPasses/Data/pink_room/textures"
+    if not os.path.isdir(src):
+        pytest.skip("reference checkout not present")
+    fixture = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pink_room_texture_digests.json")))
+    lib = pkg.load_library()
+    assert len(fixture) == 28
+    for name, want in sorted(fixture.items()):
+        path = os.path.join(src, name).encode()
+        w, h, a = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        msg = C.create_string_buffer(256)
+        assert lib.bdpt_image_load(path, C.byref(w), C.byref(h), C.byref(a), None, 0, msg, 256) == 0, (name, msg.value)
+        assert (w.value, h.value, bool(a.value)) == (want["width"], want["height"], want["alpha"]), name
+        px = np.zeros((h.value, w.value, 4), np.uint8)
+        assert lib.bdpt_image_load(path, C.byref(w), C.byref(h), C.byref(a), px.ctypes.data, px.size, msg, 256) == 0
+        texels = px if want["alpha"] else px[..., :3]
+        assert hashlib.sha256(np.ascontiguousarray(texels).tobytes()).hexdigest() == want["sha256"], name

@@ -265,3 +265,57 @@ def test_textured_alpha_masked_spot_lit_frame_matches_float64_reading(pkg, ob):
         n_pix, n_hit, n_alpha_pixels, n_gb_ok, n_nee_ok, worst_gb, worst_nee))
     orc.close()
     scene.close()
+
+
+def test_textured_light_walk_and_connections_match_float64_reading(pkg, ob):
+    """The same second reading (tests/hlsl_textured_numpy.py) for the stages whose vertices come from the LIGHT walk —
+    light-tracing splats and vertex connections — on the textured, alpha-masked, spot-lit courtyard: the light
+    sub-path's hits go through vertex fetch, material decode and texture sampling too, and its rays through the
+    any-hit alpha test.  Connections with ORACLE_CONNECT_ALL_VISIBLE (their rays end exactly on the far surface)."""
+    import hlsl_integrator_numpy as hi
+    import hlsl_textured_numpy as ht
+    A = pkg.abi
+    W, H, depth = 26, 16, 3
+    scene = pkg.Scene.courtyard(5, 7000, 0.35)
+    desc, keep = _relit_desc(pkg, scene)
+    cam = scene.camera(W / H)
+    sc = ht.TexturedScene(desc)
+    stages = (("splat", A.PARAM_NO_NEE | A.PARAM_NO_CONNECT, dict(nee=False, connect=False), 0),
+              ("connect", A.PARAM_NO_NEE | A.PARAM_NO_SPLAT, dict(nee=False, splat=False, connect_all_visible=True), ob.ORACLE_CONNECT_ALL_VISIBLE))
+    for name, flags, kw, oflags in stages:
+        gp, p = _frame_params(pkg, depth, 0, flags, 2e-3)
+        orc = ob.OracleRender(A, desc, W, H)
+        orc.gbuffer(cam, gp)
+        orc.bdpt(cam, p, flags=oflags)
+        own = orc.image().astype(np.float64)
+        splat = orc.splat.astype(np.float64)
+        splat[:, :3] /= 2.0 ** 32
+        R = hi.Renderer(sc, cam, p, W, H)
+        img = np.zeros((H, W, 4))
+        spl = np.zeros((W * H, 4))
+        for y in range(H):
+            for x in range(W):
+                i = y * W + x
+                with np.errstate(all="ignore"):
+                    o, ss = R.pixel(x, y, orc.chan["worldPosition"][i], orc.chan["worldNormal"][i], orc.chan["materialDiffuse"][i],
+                                    orc.chan["materialSpecRough"][i], orc.chan["emissive"][i], **kw)
+                img[y, x] = o
+                for tx, ty, c in ss:
+                    spl[ty * W + tx, :3] += c
+                    spl[ty * W + tx, 3] += 1
+        n = W * H
+        if name == "splat":
+            # a light path is per PIXEL (its seed), its splat lands anywhere: compare per source pixel via the totals and
+            # per target pixel where the same number of splats landed
+            same_count = spl[:, 3] == splat[:, 3]
+            assert same_count.mean() > 0.97, same_count.mean()
+            err = np.abs(spl[same_count, :3] - splat[same_count, :3]) / (1e-3 + np.abs(splat[same_count, :3]))
+            assert (err.max(axis=1) < 1e-3).mean() > 0.99 and splat[:, 3].sum() > n / 4
+            assert abs(spl[:, 3].sum() - splat[:, 3].sum()) <= 0.03 * splat[:, 3].sum()
+        else:
+            err = np.abs(img[..., :3] - own[..., :3]).max(axis=-1) / (1e-3 + np.abs(own[..., :3]).max(axis=-1))
+            ok = (err < 1e-3) & (img[..., 3] == own[..., 3])
+            assert ok.mean() > 0.97, ok.mean()
+            assert (own[..., :3].sum(axis=-1) > 1e-5).mean() > 0.2
+        orc.close()
+    scene.close()

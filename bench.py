@@ -552,6 +552,7 @@ def main():
             "roofline": {
                 "kernel": dominant, "bound": dom.get("bound", "hbm"), "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac"], "traffic": dom.get("traffic"),
+                "frac_note": dom.get("frac_note", "algorithmic bytes over HBM peak; see `fractions` for the ceilings that can bind"),
                 "fractions": dom.get("fractions"),
                 "peak_achievable_copy": 6290.0,  # float4 copy rate MI355X_MICROARCH.md reports (79 % of spec)
                 "bytes_per_frame": dom["bytes_per_frame"], "ms_per_frame": dom["ms_per_frame"],

@@ -599,8 +599,7 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightLast, np))) return rc;
   if ((rc = devAlloc(c, c->frameAllocs, &P.lightReal, np))) return rc;
   // a path queue = kNumSubQueues lists; workgroup b appends to list b % kNumSubQueues
-  // (+ one workgroup's worth: a list may also be fed by image region, kernels.hip BDPT_REGION_LISTS, whose share of the
-  // workgroups rounds up once more)
+  // (+ one workgroup's worth of slack)
   P.pathSubCap = (uint32_t)((((np + kWave - 1) / kWave + kNumSubQueues - 1) / kNumSubQueues + 1) * kWave);
   const size_t qcap = (size_t)P.pathSubCap * kNumSubQueues;
   for (int q = 0; q < 3; q++)

@@ -64,16 +64,11 @@ constexpr uint32_t kTriNonOpaque = 1u, kTriDoubleSided = 2u;
 //   word 11   record offset of child c from childBase in byte c (child 0: 0)
 // Device references: ref >= 0 interior record index; ref < 0 leaf, ~ref = record index of its first triangle; the last
 // triangle of a leaf carries kTriLastOfLeaf in its flags.  The root is record 0; kBvhPadRecs zero pad records end the array.
-// EXPERIMENT knob (profiles/README.md r3): BDPT_REC_F4 = 4 gives every record a 64-byte slot (48 bytes used), so that a
-// node never straddles two 128-byte lines; the default packs them at 48 bytes.
-#ifndef BDPT_REC_F4
-#define BDPT_REC_F4 3
-#endif
-constexpr int kRecF4 = BDPT_REC_F4;  // 16-byte words per record slot
+constexpr int kRecF4 = 3;  // 16-byte words per record
 struct alignas(16) BvhRec {
   uint32_t w[4 * kRecF4];
 };
-static_assert(sizeof(BvhRec) == 16 * kRecF4 && kRecF4 >= 3, "record slot");
+static_assert(sizeof(BvhRec) == 48, "record size");
 constexpr uint32_t kTriLastOfLeaf = 4u;  // BvhTri::flags bit set by packBvh (device-side records only)
 constexpr uint32_t kBvhPadRecs = 4;      // zero records behind the array (a leaf fetch reads past a leaf's last triangle)
 

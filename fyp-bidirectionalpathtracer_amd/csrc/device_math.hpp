@@ -21,29 +21,6 @@ struct f3 {
 BD f3 mk(float x, float y, float z) { return f3{x, y, z}; }
 BD f3 mk(float s) { return f3{s, s, s}; }
 BD f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
-// EXPERIMENT knob (profiles/README.md r3): mark data that is read or written once per ray — ray-queue planes and
-// visibility bytes (bit 0), leaf triangle records (bit 1), path-vertex stores and per-primitive shading records
-// (bit 2) — as non-temporal, so that the caches keep the BVH's interior nodes instead.
-#ifndef BDPT_NT
-#define BDPT_NT 0
-#endif
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-BD float4 ldNt4(const float4* p) {
-  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-BD void stNt4(float4* p, float4 v) {
-  nt_f4 t;
-  t.x = v.x;
-  t.y = v.y;
-  t.z = v.z;
-  t.w = v.w;
-  __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
-}
-template <int BIT>
-BD float4 ldMaybeNt4(const float4* p) { return (BDPT_NT & BIT) ? ldNt4(p) : *p; }
-template <int BIT>
-BD float ldMaybeNt(const float* p) { return (BDPT_NT & BIT) ? __builtin_nontemporal_load(p) : *p; }
 BD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 BD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 BD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }

@@ -196,8 +196,7 @@ struct Shading {
 template <bool NMAP>
 BD Shading shadeHit(const SceneDev& S, uint32_t prim, float bu, float bv, f3 camPosW) {
   const float4* r = S.shade + (size_t)prim * kShadeRecF4;
-  const float4 r0 = ldMaybeNt4<4>(r), r1 = ldMaybeNt4<4>(r + 1), r2 = ldMaybeNt4<4>(r + 2), r3 = ldMaybeNt4<4>(r + 3), r4 = ldMaybeNt4<4>(r + 4),
-               r5 = ldMaybeNt4<4>(r + 5), r6 = ldMaybeNt4<4>(r + 6);
+  const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
   const float b0 = 1.0f - bu - bv;
   float u = 0, v = 0;
   f3 normalW = mk(0), posW = mk(0);

@@ -19,9 +19,6 @@ struct Hit {
   float t, u, v;
 };
 
-#ifndef BDPT_ORDERED_ANYHIT
-#define BDPT_ORDERED_ANYHIT 0
-#endif
 constexpr int kDone = (int)0x80000000;  // traversal cursor value: stack exhausted
 
 struct TravState {
@@ -284,8 +281,7 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   // quads, fetched side by side (the test has no side effect, so running the second one although the first triangle may
   // end an any-hit query changes nothing but a little traffic).
   const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(uint32_t)~T.cur * kRecF4;
-  const float4 a0 = ldMaybeNt4<2>(tp), b0 = ldMaybeNt4<2>(tp + 1), c0 = ldMaybeNt4<2>(tp + 2), a1 = ldMaybeNt4<2>(tp + kRecF4),
-               b1 = ldMaybeNt4<2>(tp + kRecF4 + 1), c1 = ldMaybeNt4<2>(tp + kRecF4 + 2);
+  const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2], a1 = tp[kRecF4], b1 = tp[kRecF4 + 1], c1 = tp[kRecF4 + 2];
   if (COUNT) nTris++;
   TriCand k0 = triGeom<MODE>(T, a0, b0, c0), k1;
   k1.ok = false;
@@ -326,7 +322,7 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
   while (T.cur != kDone) {
     while (T.cur >= 0) {
       if (COUNT) nNodes++;
-      nodeStep<((MODE != 2) || BDPT_ORDERED_ANYHIT) ? 1 : 0>(S, T, stk);
+      nodeStep<(MODE != 2) ? 1 : 0>(S, T, stk);
     }
     if (T.cur == kDone) break;
     if (leafStep<MODE, COUNT>(S, T, nTris)) break;
@@ -428,8 +424,8 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
           rid = idx;
           const float* r = Q.rays + idx;
           const size_t c = Q.cap;
-          travInit(T, mk(ldMaybeNt<1>(r), ldMaybeNt<1>(r + c), ldMaybeNt<1>(r + 2 * c)),
-                   mk(ldMaybeNt<1>(r + 3 * c), ldMaybeNt<1>(r + 4 * c), ldMaybeNt<1>(r + 5 * c)), shadowTmin, ldMaybeNt<1>(r + 6 * c));
+          travInit(T, mk(r[0], r[c], r[2 * c]),
+                   mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
           has = true;
         }
         chunkPos += take;
@@ -452,7 +448,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
 #pragma unroll 1
       for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0, kStackLds>(S, T, stk);
+        nodeStep<0, kStackLds>(S, T, stk);
         if (COUNT) maxSp = T.sp > maxSp ? T.sp : maxSp;
       }
     }
@@ -480,7 +476,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
     if (has) {
       while (T.cur >= 0) {
         if (COUNT) nNodes++;
-        nodeStep<BDPT_ORDERED_ANYHIT ? 1 : 0, kStackLds>(S, T, stk);
+        nodeStep<0, kStackLds>(S, T, stk);
       }
       bool finished = (T.cur == kDone);
       if (!finished) {
@@ -505,364 +501,6 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
   }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 3, profiles/README.md): four lanes per ray.  A wave holds 16 any-hit rays; lane c of a ray's quad
-// decodes and slab-tests child c of the four-wide node, the quad's hit bits combine through __ballot, one stack per
-// quad (2 KiB of LDS per wave for all 32 rows: no overflow area), a leaf's triangles are tested by the quad's lanes
-// side by side.  Any-hit answers do not depend on the order of traversal, so the visibility bytes are those of
-// trace_shadow_kernel bit for bit.  Built only with -DBDPT_QUAD_ANYHIT=1.
-// ------------------------------------------------------------------------------------------------
-#ifndef BDPT_QUAD_ANYHIT
-#define BDPT_QUAD_ANYHIT 0
-#endif
-#if BDPT_QUAD_ANYHIT
-template <bool COUNT>
-__global__ __launch_bounds__(kWave) void trace_shadow_quad_kernel(SceneDev S, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
-                                                                  float shadowTmin) {
-  constexpr int kQuads = kWave / 4;
-  __shared__ int s_stack[kStackEntries * kQuads];
-  const int lane = (int)(threadIdx.x & 63u), sub = lane & 3, slot = lane >> 2, quadBase = lane & ~3;
-  int* stk = s_stack + slot;  // entry e of this quad's ray at stk[e * kQuads]
-  bool has = false, exhausted = false;
-  uint32_t rid = 0;
-  f3 o = mk(0), idir = mk(0), d = mk(0);
-  float tmin = shadowTmin, tmax = 0.0f;
-  int cur = kDone, sp = 0;
-  uint32_t nNodes = 0, nTris = 0;
-  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
-  const uint32_t wavesPerList = (gridDim.x + Q.numSub - 1) / Q.numSub;
-  const unsigned long long leaders = 0x1111111111111111ull;  // lane 0 of every quad
-  for (;;) {
-    const unsigned long long idleMask = __ballot(!has) & leaders;
-    const int idle = __popcll(idleMask);
-    if (!exhausted && idle >= 4) {
-      while (chunkPos >= chunkEnd && !exhausted) {
-        const uint32_t nq = Q.count[q * kCursorStride];
-        uint32_t base = nq;
-        if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
-          uint32_t share = (nq / wavesPerList + kQuads - 1) & ~(uint32_t)(kQuads - 1);
-          chunk = share < (uint32_t)kQuads ? (uint32_t)kQuads : (share > kFetchChunk ? kFetchChunk : share);
-          if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], chunk);
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        }
-        if (base < nq) {
-          chunkPos = base;
-          chunkEnd = (base + chunk < nq) ? base + chunk : nq;
-          tried = 0;
-        } else {
-          q = (q + 1 == Q.numSub) ? 0u : q + 1;
-          if (++tried >= Q.numSub) exhausted = true;
-        }
-      }
-      if (!exhausted) {
-        const uint32_t avail = chunkEnd - chunkPos;
-        const uint32_t take = ((uint32_t)idle < avail) ? (uint32_t)idle : avail;
-        const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << quadBase) - 1ull));  // idle quads below this one
-        if (!has && rank < take) {
-          const uint32_t idx = q * Q.subCap + chunkPos + rank;
-          rid = idx;
-          const float* r = Q.rays + idx;
-          const size_t c = Q.cap;
-          o = mk(r[0], r[c], r[2 * c]);
-          d = mk(r[3 * c], r[4 * c], r[5 * c]);
-          tmax = r[6 * c];
-          idir = mk(clampedRcp(d.x), clampedRcp(d.y), clampedRcp(d.z));
-          const bool finite = (o.x == o.x) && (o.y == o.y) && (o.z == o.z) && (d.x == d.x) && (d.y == d.y) && (d.z == d.z);
-          cur = (finite && (tmax > shadowTmin)) ? 0 : kDone;
-          sp = 0;
-          has = true;
-        }
-        chunkPos += take;
-      }
-    }
-    if (__ballot(has) == 0ull) break;
-    // ---- node visits: every quad whose ray stands on an interior node, up to BDPT_NODE_BURST times
-#pragma unroll 1
-    for (int k = 0; k < BDPT_NODE_BURST; k++) {
-      const bool at = has && cur >= 0;
-      if (__ballot(at) == 0ull) break;
-      bool hit = false;
-      int ref = kDone;
-      if (at) {
-        if (COUNT && sub == 0) nNodes++;
-        const uint4* np = S.recs + (size_t)cur * kRecF4;
-        const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-        const uint32_t sh = 8u * (uint32_t)sub;
-        const float sx = __uint_as_float((q0.w << 23) & 0x7f800000u), sy = __uint_as_float((q0.w << 15) & 0x7f800000u),
-                    sz = __uint_as_float((q0.w << 7) & 0x7f800000u);
-        const float ax = sx * idir.x, ay = sy * idir.y, az = sz * idir.z;
-        const float bx = (__uint_as_float(q0.x) - o.x) * idir.x, by = (__uint_as_float(q0.y) - o.y) * idir.y,
-                    bz = (__uint_as_float(q0.z) - o.z) * idir.z;
-        const uint32_t lx = (q1.x >> sh) & 0xffu, ly = (q1.y >> sh) & 0xffu, lz = (q1.z >> sh) & 0xffu;
-        const uint32_t hx = (q1.w >> sh) & 0xffu, hy = (q2.x >> sh) & 0xffu, hz = (q2.y >> sh) & 0xffu;
-        const float t0x = fmaf((float)lx, ax, bx), t1x = fmaf((float)hx, ax, bx);
-        const float t0y = fmaf((float)ly, ay, by), t1y = fmaf((float)hy, ay, by);
-        const float t0z = fmaf((float)lz, az, bz), t1z = fmaf((float)hz, az, bz);
-        const float n = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-        const float f = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-        hit = (n <= f) && (lx <= hx);  // an unused slot has lo = 255, hi = 0 on every axis
-        const int idx = (int)(q2.z + ((q2.w >> sh) & 0xffu));
-        ref = idx ^ ((int)(q0.w << (7 - sub)) >> 31);
-      }
-      const unsigned long long hm = __ballot(hit);
-      if (at) {
-        const uint32_t m = (uint32_t)(hm >> quadBase) & 15u;
-        const int pos = __popc(m & ((1u << sub) - 1u)), nh = __popc(m);
-        if (hit) stk[(sp + pos) * kQuads] = ref;
-        sp += nh;
-        if (sp == 0) {
-          cur = kDone;
-        } else {
-          sp--;
-          cur = stk[sp * kQuads];
-        }
-      }
-    }
-    // ---- leaves (and retirement) once half of the rays wait there or none can take a node visit
-    const unsigned long long waitMask = __ballot(has && cur < 0) & leaders, nodeMask = __ballot(has && cur >= 0) & leaders;
-    const int waitNeed = (__popcll(waitMask | nodeMask) * BDPT_LEAF_WAIT_FRAC8 + 7) >> 3;
-    if ((int)__popcll(waitMask) >= waitNeed || nodeMask == 0ull) {
-      const bool atLeaf = has && cur < 0 && cur != kDone;
-      bool found = false;
-      // a leaf's triangles, four at a time: lane `sub` takes triangle `sub` unless an earlier one ends the leaf
-      uint32_t base = atLeaf ? (uint32_t)~cur : 0u;
-      bool more = atLeaf;
-      while (__ballot(more) != 0ull) {
-        // fetch four records; those behind the leaf's last triangle are not triangles of this leaf (another leaf's, a
-        // node's, or the zero pad): their flags are read to find the end, nothing else of them is used
-        bool lastHere = false, hitHere = false;
-        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-        if (more) {
-          const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)(base + (uint32_t)sub) * kRecF4;
-          a = tp[0];
-          b = tp[1];
-          c = tp[2];
-          lastHere = (__float_as_uint(b.w) & 4u) != 0u;
-        }
-        const unsigned long long lm = __ballot(lastHere);
-        const uint32_t lq = (uint32_t)(lm >> quadBase) & 15u;
-        // triangles up to and including the first "last of leaf" belong to the leaf
-        const uint32_t validBits = lq ? ((2u << (uint32_t)(__ffs((int)lq) - 1)) - 1u) : 15u;
-        if (more && ((validBits >> sub) & 1u)) {
-          TravState T;
-          T.o = o;
-          T.d = d;
-          T.tmin = tmin;
-          T.tmax = tmax;
-          const TriCand kc = triGeom<2>(T, a, b, c);
-          hitHere = kc.ok;
-          if (hitHere && (kc.flags & 1u)) hitHere = !alphaTestFails(S, kc.aux, kc.u, kc.v);
-        }
-        const unsigned long long hmask = __ballot(hitHere);
-        if (more) {
-          const uint32_t hq = (uint32_t)(hmask >> quadBase) & 15u;
-          if (COUNT && sub == 0) nTris += (uint32_t)__popc(validBits);
-          if (hq) found = true;
-          more = !found && lq == 0u;
-          base += 4u;
-        }
-      }
-      if (has && cur < 0) {
-        bool finished = (cur == kDone) || found;
-        if (!finished) {
-          if (sp == 0) {
-            finished = true;
-          } else {
-            sp--;
-            cur = stk[sp * kQuads];
-          }
-        }
-        if (finished) {
-          if (sub == 0) vis[rid] = found ? (uint8_t)0 : (uint8_t)1;
-          has = false;
-          cur = kDone;
-        }
-      }
-    }
-  }
-  if (COUNT) {
-    waveAddCount(counters, C_NODE_SHADOW, nNodes);
-    waveAddCount(counters, C_TRI_SHADOW, nTris);
-  }
-}
-#endif  // BDPT_QUAD_ANYHIT
-
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 3, profiles/README.md): two rays per lane.  Every lane owns a LIVE ray (registers) and a PARKED
-// one (14 dwords in LDS); when the live ray reaches a leaf and the parked one can take node visits the two swap, so
-// the node bursts — nine tenths of the work — run with the lanes the deferred-leaf loop leaves idle.  Each ray keeps
-// only KL rows of its stack in LDS (the rest in the context's overflow area), so that the wave holds twice the rays
-// in about the LDS the one-ray kernel uses.  Any-hit answers are independent of the order of traversal: visibility
-// bytes identical to trace_shadow_kernel.  Built only with -DBDPT_TWO_RAYS=1.
-// ------------------------------------------------------------------------------------------------
-#if BDPT_TWO_RAYS
-constexpr int kParkFields = 14;  // o d idir (9) neg tmax cur sp rid
-template <bool COUNT, int KL>
-__global__ __launch_bounds__(kWave) void trace_shadow2_kernel(SceneDev S0, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
-                                                              float shadowTmin) {
-  __shared__ int s_stack[2 * KL * kWave];
-  __shared__ uint32_t s_park[kParkFields * kWave];
-  const int lane = (int)(threadIdx.x & 63u);
-  uint32_t* park = s_park + lane;  // field f at park[f * 64]
-  bool has = false, hasParked = false, exhausted = false;
-  uint32_t rid = 0, which = 0;  // which half of the stack (and of the overflow rows) the live ray uses
-  TravState T;
-  T.cur = kDone;
-  T.tmin = shadowTmin;
-  uint32_t nNodes = 0, nTris = 0;
-  int maxSp = 0;
-  SceneDev S = S0;  // stackOvf is offset per lane by the live ray's half
-  auto bindStack = [&]() { S.stackOvf = S0.stackOvf + (size_t)which * (size_t)(kStackEntries - KL) * S0.stackOvfStride; };
-  bindStack();
-  auto initRay = [&](TravState& R, uint32_t idx) {
-    const float* r = Q.rays + idx;
-    const size_t c = Q.cap;
-    travInit(R, mk(r[0], r[c], r[2 * c]), mk(r[3 * c], r[4 * c], r[5 * c]), shadowTmin, r[6 * c]);
-  };
-  auto storeParked = [&](const TravState& R, uint32_t id) {
-    park[0 * 64] = __float_as_uint(R.o.x);
-    park[1 * 64] = __float_as_uint(R.o.y);
-    park[2 * 64] = __float_as_uint(R.o.z);
-    park[3 * 64] = __float_as_uint(R.d.x);
-    park[4 * 64] = __float_as_uint(R.d.y);
-    park[5 * 64] = __float_as_uint(R.d.z);
-    park[6 * 64] = __float_as_uint(R.idir.x);
-    park[7 * 64] = __float_as_uint(R.idir.y);
-    park[8 * 64] = __float_as_uint(R.idir.z);
-    park[9 * 64] = R.neg;
-    park[10 * 64] = __float_as_uint(R.tmax);
-    park[11 * 64] = (uint32_t)R.cur;
-    park[12 * 64] = (uint32_t)R.sp;
-    park[13 * 64] = id;
-  };
-  auto loadParked = [&](TravState& R, uint32_t& id) {
-    R.o = mk(__uint_as_float(park[0 * 64]), __uint_as_float(park[1 * 64]), __uint_as_float(park[2 * 64]));
-    R.d = mk(__uint_as_float(park[3 * 64]), __uint_as_float(park[4 * 64]), __uint_as_float(park[5 * 64]));
-    R.idir = mk(__uint_as_float(park[6 * 64]), __uint_as_float(park[7 * 64]), __uint_as_float(park[8 * 64]));
-    R.neg = park[9 * 64];
-    R.tmin = shadowTmin;
-    R.tmax = __uint_as_float(park[10 * 64]);
-    R.cur = (int)park[11 * 64];
-    R.sp = (int)park[12 * 64];
-    R.best.prim = -1;
-    R.best.t = R.tmax;
-    R.best.u = R.best.v = 0.0f;
-    id = park[13 * 64];
-  };
-  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
-  const uint32_t wavesPerList = (gridDim.x + Q.numSub - 1) / Q.numSub;
-  for (;;) {
-    // ---- refill: empty live slots first, then empty parked slots
-    const unsigned long long liveEmpty = __ballot(!has), parkEmpty = __ballot(!hasParked);
-    const int nLE = __popcll(liveEmpty), nPE = __popcll(parkEmpty);
-    if (!exhausted && (nLE >= kRefillIdle || nLE + nPE >= 2 * kRefillIdle)) {
-      uint32_t want = (uint32_t)(nLE + nPE), taken = 0;
-      const uint32_t rankL = (uint32_t)__popcll(liveEmpty & ((1ull << lane) - 1ull));
-      const uint32_t rankP = (uint32_t)nLE + (uint32_t)__popcll(parkEmpty & ((1ull << lane) - 1ull));
-      bool gotL = false, gotP = false;
-      uint32_t idL = 0, idP = 0;
-      while (want > 0 && !exhausted) {
-        while (chunkPos >= chunkEnd && !exhausted) {
-          const uint32_t nq = Q.count[q * kCursorStride];
-          uint32_t base = nq;
-          if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
-            uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
-            chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
-            if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], chunk);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          }
-          if (base < nq) {
-            chunkPos = base;
-            chunkEnd = (base + chunk < nq) ? base + chunk : nq;
-            tried = 0;
-          } else {
-            q = (q + 1 == Q.numSub) ? 0u : q + 1;
-            if (++tried >= Q.numSub) exhausted = true;
-          }
-        }
-        if (exhausted) break;
-        const uint32_t avail = chunkEnd - chunkPos;
-        const uint32_t take = (want < avail) ? want : avail;
-        if (!has && !gotL && rankL >= taken && rankL < taken + take) {
-          idL = q * Q.subCap + chunkPos + (rankL - taken);
-          gotL = true;
-        }
-        if (!hasParked && !gotP && rankP >= taken && rankP < taken + take) {
-          idP = q * Q.subCap + chunkPos + (rankP - taken);
-          gotP = true;
-        }
-        chunkPos += take;
-        taken += take;
-        want -= take;
-      }
-      if (gotL) {
-        rid = idL;
-        initRay(T, idL);
-        has = true;
-      }
-      if (gotP) {
-        TravState R;
-        initRay(R, idP);
-        storeParked(R, idP);
-        hasParked = true;
-      }
-    }
-    if (__ballot(has || hasParked) == 0ull) break;
-    // ---- a lane whose live slot is empty, or whose live ray waits at a leaf while the parked one can take node visits, swaps
-    {
-      const int parkedCur = hasParked ? (int)park[11 * 64] : kDone;
-      const bool swapIn = hasParked && (!has || (T.cur < 0 && parkedCur >= 0));
-      if (swapIn) {
-        TravState R;
-        uint32_t id2;
-        loadParked(R, id2);
-        if (has) storeParked(T, rid);
-        hasParked = has;
-        T = R;
-        rid = id2;
-        has = true;
-        which ^= 1u;
-        bindStack();
-      }
-    }
-    int* stk = s_stack + (int)which * KL * kWave + lane;
-    // ---- node visits in bursts; leaves once half of the live rays wait at one (device_trace.hpp trace_shadow_kernel)
-    if (has) {
-#pragma unroll 1
-      for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
-        if (COUNT) nNodes++;
-        nodeStep<0, KL>(S, T, stk);
-        if (COUNT) maxSp = T.sp > maxSp ? T.sp : maxSp;
-      }
-    }
-    const unsigned long long waitMask = __ballot(has && T.cur < 0), nodeMask = __ballot(has && T.cur >= 0);
-    const int waitNeed = (__popcll(waitMask | nodeMask) * BDPT_LEAF_WAIT_FRAC8 + 7) >> 3;
-    if ((int)__popcll(waitMask) >= waitNeed || nodeMask == 0ull) {
-      if (has && T.cur < 0) {
-        bool finished = (T.cur == kDone);
-        if (!finished) {
-          finished = leafStep<2, COUNT>(S, T, nTris);
-          if (!finished) {
-            T.cur = travPop<KL>(S, T, stk);
-            finished = (T.cur == kDone);
-          }
-        }
-        if (finished) {
-          vis[rid] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
-          has = false;
-          T.cur = kDone;
-        }
-      }
-    }
-  }
-  if (COUNT) {
-    waveAddCount(counters, C_NODE_SHADOW, nNodes);
-    waveAddCount(counters, C_TRI_SHADOW, nTris);
-    if (maxSp > 0) atomicMax(&counters->v[blockIdx.x % kCounterShards][C_STACK_MAX], (unsigned long long)maxSp);
-  }
-}
-#endif  // BDPT_TWO_RAYS
 
 #undef BD
 }  // namespace bdpt

@@ -21,23 +21,12 @@ constexpr int kStackEntries = KSTACK;  // per-lane traversal stack capacity (the
 #endif
 constexpr int kStackLds = BDPT_STACK_LDS < KSTACK ? BDPT_STACK_LDS : KSTACK;
 constexpr int kMaxPersistentPerCU = 32;  // resident one-wave workgroups per CU a persistent grid may use (8 per SIMD)
-// EXPERIMENT knob (profiles/README.md r3): the any-hit kernel with TWO rays per lane — a live one in registers, a parked
-// one in LDS, swapped whenever the live ray waits at a leaf — and only BDPT_TWO_RAYS_KL stack rows per ray in LDS.
-#ifndef BDPT_TWO_RAYS
-#define BDPT_TWO_RAYS 0
-#endif
-#ifndef BDPT_TWO_RAYS_KL
-#define BDPT_TWO_RAYS_KL 8
-#endif
 // Rows of the per-context stack overflow area (SceneDev::stackOvf).  INVARIANT the area relies on: it is indexed by
 // workgroup and lane only, so no two persistent traversal launches of one context may be resident at once — every
 // launchWalk / launchTraceShadow of a context goes to the caller's stream, the context's second stream only runs
 // generators (api.cpp bdpt_execute, evFork / evJoin), and the test hooks synchronise the device first.
-constexpr int kStackOvfRows = BDPT_TWO_RAYS ? 2 * (KSTACK - BDPT_TWO_RAYS_KL) : (KSTACK - (BDPT_STACK_LDS < KSTACK ? BDPT_STACK_LDS : KSTACK));
-#ifndef BDPT_SHADE_REC_F4
-#define BDPT_SHADE_REC_F4 7
-#endif
-constexpr int kShadeRecF4 = BDPT_SHADE_REC_F4;  // float4s per triangle shading record (7 used = 112 B)
+constexpr int kStackOvfRows = KSTACK - kStackLds;
+constexpr int kShadeRecF4 = 7;  // float4s per triangle shading record (7 used = 112 B)
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // Hot single-word atomics top out near 90 M/s on this chip (MI355X_MICROARCH.md "dequeue"), so
 // producer and consumer cursors of every queue are sharded over sub-queues, the any-hit trace kernel

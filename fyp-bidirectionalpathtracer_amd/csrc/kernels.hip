@@ -28,10 +28,6 @@
 #include "device_scene.hpp"
 #include "device_trace.hpp"
 
-#ifndef BDPT_REGION_LISTS
-#define BDPT_REGION_LISTS 0
-#endif
-
 namespace bdpt {
 
 #define BD __device__ __forceinline__
@@ -108,21 +104,12 @@ BD void storeVtx(const PathBuf& P, int path, int k, uint32_t p, const Vtx& v) {
   const float4 q0 = make_float4(v.pos.x, v.pos.y, v.pos.z, v.rough), q1 = make_float4(v.N.x, v.N.y, v.N.z, v.isSpec ? 1.0f : 0.0f),
                q2 = make_float4(v.dif.x, v.dif.y, v.dif.z, v.pdf), q3 = make_float4(v.spec.x, v.spec.y, v.spec.z, 0.0f),
                q4 = make_float4(v.color.x, v.color.y, v.color.z, 0.0f), q5 = make_float4(v.V.x, v.V.y, v.V.z, 0.0f);
-  if (BDPT_NT & 4) {
-    stNt4(r, q0);
-    stNt4(r + 1, q1);
-    stNt4(r + 2, q2);
-    stNt4(r + 3, q3);
-    stNt4(r + 4, q4);
-    stNt4(r + 5, q5);
-  } else {
-    r[0] = q0;
-    r[1] = q1;
-    r[2] = q2;
-    r[3] = q3;
-    r[4] = q4;
-    r[5] = q5;
-  }
+  r[0] = q0;
+  r[1] = q1;
+  r[2] = q2;
+  r[3] = q3;
+  r[4] = q4;
+  r[5] = q5;
 }
 // geometry + material of a stored vertex (no colour, no V); GGX = false skips the fields Lambert never reads
 template <bool GGX = true>
@@ -323,14 +310,7 @@ __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev 
       out4[pix] = em ? make_float4(0.0f + er, 0.0f + eg, 0.0f + eb, 0.0f + ea) : make_float4(0, 0, 0, 0);
     }
   }
-#if BDPT_REGION_LISTS
-  // Experiment (profiles/README.md r3): valid-pixel list q holds pixels of image region q % 8 (eighths of the tile in row
-  // order), so that the walk waves of XCD x (workgroup b -> XCD b % 8, first list b % 64) start on eye sub-paths of ONE
-  // region and their first hits share that XCD's L2.
-  wavePush(geom, p, P.queue[0], P.qcount, P.pathSubCap, (uint32_t)(((uint64_t)blockIdx.x * 8u) / gridDim.x) + 8u * (blockIdx.x % 4u));
-#else
   wavePush(geom, p, P.queue[0], P.qcount, P.pathSubCap);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -998,9 +978,7 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
       }
     }
     const uint32_t id = emitRay(P, RAY_PAIRS, emit, ce.pos, dirAB, lengthAB, shade);
-#ifndef BDPT_EXP_NO_SLOT
     if (pairAct) P.slotRay[(size_t)slot * P.Np + p] = id;
-#endif
     nConn += emit ? 1u : 0u;
   }
   waveAddCount(F.counters, C_RAYS_CONNECT, nConn);
@@ -1432,23 +1410,6 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
              P.rayHead + (size_t)cls * kRayCursorBlock};
   uint8_t* vis = P.rayVis + P.rayBase[cls];
   uint32_t& g = G.shadow[cnt ? 1 : 0];
-#if BDPT_TWO_RAYS
-  if (cnt) {
-    if (!g) g = persistentGrid(trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>, numCUs);
-    hipLaunchKernelGGL((trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>), dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
-  } else {
-    if (!g) g = persistentGrid(trace_shadow2_kernel<false, BDPT_TWO_RAYS_KL>, numCUs);
-    hipLaunchKernelGGL((trace_shadow2_kernel<false, BDPT_TWO_RAYS_KL>), dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
-  }
-#elif BDPT_QUAD_ANYHIT
-  if (cnt) {
-    if (!g) g = persistentGrid(trace_shadow_quad_kernel<true>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_quad_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
-  } else {
-    if (!g) g = persistentGrid(trace_shadow_quad_kernel<false>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_quad_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
-  }
-#else
   if (cnt) {
     if (!g) g = persistentGrid(trace_shadow_kernel<true>, numCUs);
     hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
@@ -1456,7 +1417,6 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
     if (!g) g = persistentGrid(trace_shadow_kernel<false>, numCUs);
     hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
   }
-#endif
 }
 
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st) {
@@ -1512,16 +1472,8 @@ void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode,
 void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap, const uint32_t* count, uint32_t* head, uint8_t* vis,
                            DevCounters* counters, float tmin, int numCUs, hipStream_t st) {
   RayQueue Q{planes, cap, cap, 1u, count, head};
-#if BDPT_TWO_RAYS
-  const uint32_t g = persistentGrid(trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>, numCUs);
-  hipLaunchKernelGGL((trace_shadow2_kernel<true, BDPT_TWO_RAYS_KL>), dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
-#elif BDPT_QUAD_ANYHIT
-  const uint32_t g = persistentGrid(trace_shadow_quad_kernel<true>, numCUs);
-  hipLaunchKernelGGL(trace_shadow_quad_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
-#else
   const uint32_t g = persistentGrid(trace_shadow_kernel<true>, numCUs);
   hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
-#endif
 }
 void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st) {
   if (!n) return;

@@ -5,10 +5,8 @@
 # kernels.h that both sides use — the stack overflow area — depend on them.)
 cd fyp-bidirectionalpathtracer_amd/csrc
 for v in "$@"; do
-  rm -f kernels.o api.o bvh_build.o scene_bvh.o alpha_clip.o libbdpt_amd.so
-  hostflags=$(for w in $v; do case $w in -D*) echo -n "$w ";; esac; done)
-  make EXTRA="$v" HOSTEXTRA="$hostflags" > /tmp/variant_build.log 2>&1 || { echo "== $v : build failed"; tail -5 /tmp/variant_build.log; continue; }
+  make EXTRA="$v" > /tmp/variant_build.log 2>&1 || { echo "== $v : build failed"; tail -5 /tmp/variant_build.log; continue; }
   echo "== [$v]"
   (cd ../.. && timeout -k 10 180 python tools/stages.py 2>&1 | grep -v amdgpu.ids | tail -1)
 done
-rm -f kernels.o api.o bvh_build.o scene_bvh.o alpha_clip.o libbdpt_amd.so; make > /dev/null 2>&1
+make > /dev/null 2>&1   # the flag stamp (.flags) rebuilds what the last variant left behind

@@ -16,7 +16,9 @@ ray tallies add up on the device.  Stage times, visit counts and the roofline bl
 untimed frames run ALONE before the timed region (their HIP events see one frame's kernels only).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--scene atrium|cornell] ...
-For N > 1 launch with torch.distributed.run (one rank per GPU).
+`python bench.py --gpus N` with N > 1 starts its own ranks (one process per GPU, a torch.distributed.run child started
+before anything in this process touches a GPU); launched under torch.distributed.run it is one of the ranks.
+The per-rank frame loop is the package's (fyp-bidirectionalpathtracer_amd/tiling.py TileRenderer).
 """
 import argparse
 import ctypes as C
@@ -85,92 +87,6 @@ def load_pmc(scene, W, H, D, world):
             out[name] = v  # the timed variant (no visit counters) has more launches than the one statistics frame
     out["_meta"] = {k: v for k, v in raw.items() if k != "kernels"}
     return out
-
-
-class TileRenderer:
-    """This rank's share of the frame loop: `inflight` contexts over the same tile (interleaved stripes of rows; with
-    one rank the whole frame), each with one frame in flight on its own stream."""
-
-    def __init__(self, pkg, scene, W, H, D, mat, local_rank, world, rank, dist, inflight=3):
-        import torch
-        self.torch, self.pkg, self.dist = torch, pkg, dist
-        self.W, self.H, self.world, self.rank = W, H, world, rank
-        self.dev = torch.device("cuda", local_rank)
-        # Frames in flight: the persistent launches of one frame ramp up and drain (a sub-path is up to D rays in
-        # series), and a tile leaves the chip underfilled (DESIGN.md section 5), so several frames are kept going on
-        # separate streams/contexts; frames stay independent until the running mean, which is applied in frame order.
-        self.inflight = max(1, int(inflight))
-        stripes = (pkg.tiling.stripe_rows(H, world), world, rank)
-        self.pipes = [pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, device=local_rank, stripes=stripes,
-                                        accum_limit=1 << 30) for _ in range(self.inflight)]
-        self.pipe = self.pipes[0]
-        self.ctx = self.pipe.ctx
-        self.rows = self.pipe.rows
-        self.num_pixels = sum(b - a for a, b in self.rows) * W
-        self.state = {"frame": 0, "accum": 0, "accum_event": None}
-        info = self.ctx.tile_info()
-        self.exchange_bytes = int(info.splatU64) * 8  # what one rank hands to the reduce-scatter per frame
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.inflight)]
-        self.splat_full = [torch.zeros(info.splatU64, dtype=torch.int64, device=self.dev) for _ in range(self.inflight)]
-        # without a process group nothing is exchanged: this rank's own chunk is resolved where it is (one rank: the frame)
-        self.splat_mine = [self.splat_full[i][rank * info.chunkU64:(rank + 1) * info.chunkU64] if dist is None else
-                           torch.zeros(info.chunkU64, dtype=torch.int64, device=self.dev) for i in range(self.inflight)]
-        for pp, sf in zip(self.pipes, self.splat_full):
-            pp.ctx.set_splat_buffer(C.c_void_p(sf.data_ptr()), sf.numel())
-        self.last_frame = self.pipe.last_frame  # the running mean is shared by all frames in flight
-        self.exchange_events = None               # set by time_exchange(): [(tail0, tail1, ex0, ex1)] of solo frames
-
-    def step(self, flags=0):
-        """One pipeline frame on this rank's tile; returns the context that took it."""
-        torch, pkg, state = self.torch, self.pkg, self.state
-        f = state["frame"]
-        state["frame"] += 1
-        i = f % self.inflight
-        pp, s = self.pipes[i], self.streams[i]
-        pp.gbuffer_frame, pp.bdpt_frame = 0xdeadbeef + f, 0x1337 + f
-        timing = self.exchange_events is not None
-        with torch.cuda.stream(s):
-            # phase 1: everything that writes the splat buffer; then the exchange starts on RCCL's stream while
-            # phase 2 (zero-valued connection rounds) runs on ours
-            _, p = pp.render_frame(accumulate=False, extra_flags=flags | pkg.abi.PARAM_DEFER_RESOLVE | pkg.abi.PARAM_DEFER_TAIL)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timing else None
-            if timing:
-                ev[2].record(s)
-            work = pkg.tiling.exchange_splats_async(self.dist, self.splat_full[i], self.splat_mine[i]) if self.dist is not None else None
-            st = C.c_void_p(s.cuda_stream)
-            if timing:
-                ev[0].record(s)
-            pp.ctx.execute_tail(p, pp.gb, C.c_void_p(pp.output.data_ptr()), st)
-            if timing:
-                ev[1].record(s)
-            if work is not None:
-                work.wait()
-            if timing:
-                ev[3].record(s)
-                self.exchange_events.append(ev)
-            pp.ctx.resolve_tile(C.c_void_p(self.splat_mine[i].data_ptr()), C.c_void_p(pp.output.data_ptr()), st)
-            if state["accum_event"] is not None:
-                s.wait_event(state["accum_event"])  # running mean in frame order
-            n = state["accum"]
-            state["accum"] += 1
-            pp.ctx.accumulate_tile(C.c_void_p(self.last_frame.data_ptr()), C.c_void_p(pp.output.data_ptr()), n, pp.accum_limit, st)
-            done = torch.cuda.Event()
-            done.record(s)
-            state["accum_event"] = done
-        return pp.ctx
-
-    def barrier(self):
-        self.torch.cuda.synchronize(self.dev)
-        if self.dist is not None:
-            self.dist.barrier()
-            self.torch.cuda.synchronize(self.dev)
-
-    def rewind(self, frame, accum):
-        self.state["frame"], self.state["accum"] = frame, accum
-
-    def close(self):
-        for pp in self.pipes:
-            pp.close()
 
 
 def solo_frames(R, pkg, torch, n, flags=0):
@@ -278,6 +194,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
@@ -286,8 +205,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch N > 1 with torch.distributed.run, one rank per GPU "
-                         "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launched under torch.distributed.run with another rank count?)"
+                         % (args.gpus, world))
     dist = None
     # BDPT_BENCH_TILED_AT_1=1 under torch.distributed.run makes a single rank go through the RCCL exchange too, so the
     # N>1 code can be exercised on a one-GPU box; otherwise N=1 runs without any collective.
@@ -345,7 +264,7 @@ def main():
         pp.close()
         return
 
-    R = TileRenderer(pkg, scene, W, H, D, mat, local_rank, world, rank, dist, args.inflight)
+    R = pkg.tiling.TileRenderer(scene, W, H, D, mat, local_rank, world, rank, dist, args.inflight)
     pipe, ctx, inflight = R.pipe, R.ctx, R.inflight
     n_pix_tile = R.num_pixels
     info = ctx.bvh_info()
@@ -353,8 +272,7 @@ def main():
     if args.dump_frames > 0:
         for _ in range(args.dump_frames):
             R.step()
-        R.barrier()
-        full = pkg.tiling.gather_frame(dist, torch, R.last_frame, H, world, rank) if dist is not None else R.last_frame
+        full = R.gather()
         if rank == 0:
             import numpy as np
             np.save(args.dump_path, full.cpu().numpy())
@@ -586,7 +504,7 @@ def main():
     if rank == 0 and world == 1 and dist is None:
         if args.single_pass:
             def single():
-                R1 = TileRenderer(pkg, scene, W, H, D, mat, local_rank, 1, 0, None, 1)
+                R1 = pkg.tiling.TileRenderer(scene, W, H, D, mat, local_rank, 1, 0, None, 1)
                 try:
                     for _ in range(2):
                         R1.step()
@@ -629,6 +547,23 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (never an exec: a
+    process that has initialised the GPU must not be replaced, and nothing here has touched one yet — torch is not even
+    imported), stream its output through and return its exit code.  Rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loop-back interface (the hostname may not resolve)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def effective_cpus():

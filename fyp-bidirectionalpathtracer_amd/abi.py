@@ -147,6 +147,7 @@ PROTOTYPES = {
     "bdpt_execute_tail": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bdpt_resize_stripes": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, Stripes, C.c_uint32]),
+    "bdpt_stripe_rows": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "bdpt_get_tile_info": (C.c_int, [C.c_void_p, C.POINTER(TileInfo)]),
     "bdpt_tile_row_ranges": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
     "bdpt_resolve_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

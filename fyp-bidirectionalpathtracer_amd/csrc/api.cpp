@@ -530,6 +530,10 @@ int bdpt_resize_stripes(bdpt_ctx* c, uint32_t width, uint32_t height, bdpt_strip
   return resizeRows(c, width, height, maxDepth);
 }
 
+uint32_t bdpt_stripe_rows(uint32_t height, uint32_t numOwners) {
+  const uint32_t per = height / std::max(1u, numOwners * 4u);
+  return std::max(1u, std::min(8u, per));
+}
 int bdpt_get_tile_info(const bdpt_ctx* c, bdpt_tile_info* out) {
   if (!c || !out) return BDPT_E_INVALID;
   if (!c->haveSize) return BDPT_E_STATE;

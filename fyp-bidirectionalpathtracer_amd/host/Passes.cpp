@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 namespace bdpt {
 
@@ -306,6 +307,8 @@ void RenderPass::onShutdown() {
 // ------------------------------------------------------------------------------------------------
 RayLaunch::SharedPtr RayLaunch::create(RenderContext* ctx) {
   static std::map<int, std::weak_ptr<RayLaunch>> perDevice;
+  static std::mutex perDeviceLock;  // a multi-GPU host runs one pipeline per device, each on a thread of its own
+  std::lock_guard<std::mutex> guard(perDeviceLock);
   const int dev = ctx ? ctx->getDevice() : 0;
   if (auto sp = perDevice[dev].lock()) return sp;
   SharedPtr r(new RayLaunch());
@@ -317,7 +320,17 @@ RayLaunch::SharedPtr RayLaunch::create(RenderContext* ctx) {
   perDevice[dev] = r;
   return r;
 }
+void RayLaunch::freeTileSplat() {
+  for (uint64_t* p : mTileSplat)
+    if (p) (void)hipFree(p);
+  mTileSplat.clear();
+}
+void RayLaunch::setTiling(TileExchange::SharedPtr x) {
+  mExchange = x;
+  mW = mH = 0;  // the next ensureSize re-sizes every context as stripes
+}
 RayLaunch::~RayLaunch() {
+  freeTileSplat();
   for (bdpt_ctx* c : mMore)
     if (c) bdpt_destroy(c);
   if (mCtx) bdpt_destroy(mCtx);
@@ -364,6 +377,24 @@ bool RayLaunch::ensureSize(uint32_t w, uint32_t h) {
   bdpt_tile tile{0, h};
   std::vector<bdpt_ctx*> all{mCtx};
   all.insert(all.end(), mMore.begin(), mMore.end());
+  if (mExchange) {
+    // this rank's interleaved stripes; the reduced chunk of every frame slot lands in a buffer of its own
+    mStripeRows = bdpt_stripe_rows(h, mExchange->world());
+    const bdpt_stripes st{mStripeRows, mExchange->world(), mExchange->rank()};
+    for (bdpt_ctx* c : all)
+      if (bdpt_resize_stripes(c, w, h, st, mMaxDepth) != BDPT_OK) {
+        std::fprintf(stderr, "[RayLaunch] bdpt_resize_stripes failed: %s\n", bdpt_last_error(c));
+        return false;
+      }
+    if (bdpt_get_tile_info(mCtx, &mTileInfo) != BDPT_OK) return false;
+    freeTileSplat();
+    (void)hipSetDevice(mDevice);
+    for (size_t i = 0; i < all.size(); i++) {
+      uint64_t* p = nullptr;
+      if (hipMalloc(&p, std::max<size_t>((size_t)mTileInfo.chunkU64 * 8, 16)) != hipSuccess) return false;
+      mTileSplat.push_back(p);
+    }
+  } else
   for (bdpt_ctx* c : all)
     if (bdpt_resize(c, w, h, tile, mMaxDepth) != BDPT_OK) {
       std::fprintf(stderr, "[RayLaunch] bdpt_resize failed: %s\n", bdpt_last_error(c));
@@ -525,8 +556,32 @@ void BDPTPass::execute(RenderContext* pRenderContext) {
     }
     bdpt_set_environment(mpRays->ctx(), &e);
   }
-  if (bdpt_execute(mpRays->ctx(), &p, &gb, (float*)pDstTex->getDevicePointer(), pRenderContext->getStream()) != BDPT_OK)
-    std::fprintf(stderr, "[BDPTPass] %s\n", mpRays->lastError());
+  float* out = (float*)pDstTex->getDevicePointer();
+  hipStream_t stream = pRenderContext->getStream();
+  if (!mpRays->tiled()) {
+    if (bdpt_execute(mpRays->ctx(), &p, &gb, out, stream) != BDPT_OK) std::fprintf(stderr, "[BDPTPass] %s\n", mpRays->lastError());
+    return;
+  }
+  // Tiled over several GPUs (RenderingPipeline::setTiling): this rank's stripes.  Phase 1 enqueues everything that
+  // writes the splat accumulators; the reduce-scatter then runs on the exchange stream beside phase 2 (the zero-valued
+  // connection rounds, which never touch them); the rank's own chunk, summed over all ranks, is folded into its rows.
+  TileExchange::SharedPtr x = mpRays->exchange();
+  const uint32_t slot = mpRays->currentSlot();
+  uint64_t* full = nullptr;
+  uint64_t fullWords = 0;
+  p.flags |= BDPT_PARAM_DEFER_RESOLVE | BDPT_PARAM_DEFER_TAIL;
+  bool ok = bdpt_execute(mpRays->ctx(), &p, &gb, out, stream) == BDPT_OK;
+  ok = ok && bdpt_splat_buffer(mpRays->ctx(), &full, &fullWords) == BDPT_OK && fullWords == mpRays->tileInfo().splatU64;
+  if (ok && !x->reduceScatter(full, mpRays->tileSplat(), mpRays->tileInfo().chunkU64, stream, slot)) {
+    std::fprintf(stderr, "[BDPTPass] splat exchange failed: %s\n", x->lastError().c_str());
+    ok = false;
+  }
+  ok = ok && bdpt_execute_tail(mpRays->ctx(), &p, &gb, out, stream) == BDPT_OK;
+  if (ok) {
+    x->waitFor(stream, slot);
+    ok = bdpt_resolve_tile(mpRays->ctx(), mpRays->tileSplat(), out, stream) == BDPT_OK;
+  }
+  if (!ok) std::fprintf(stderr, "[BDPTPass] %s\n", mpRays->lastError());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -575,6 +630,12 @@ void SimpleAccumulationPass::execute(RenderContext* pRenderContext) {
   }
   mResumed = false;
   const uint32_t gAccumCount = (int32_t)mAccumCount < mCountLimit ? mAccumCount++ : (uint32_t)mCountLimit;
+  if (mpRays->tiled()) {  // the running mean over this rank's rows only (the other rows belong to other GPUs)
+    if (!mpRays->ensureSize(inputTexture->getWidth(), inputTexture->getHeight())) return;
+    bdpt_accumulate_tile(mpRays->ctx(), (float*)mpLastFrame->getDevicePointer(), (float*)inputTexture->getDevicePointer(), gAccumCount,
+                         (uint32_t)mCountLimit, pRenderContext->getStream());
+    return;
+  }
   bdpt_accumulate(mpRays->ctx(), (float*)mpLastFrame->getDevicePointer(), (float*)inputTexture->getDevicePointer(), gAccumCount,
                   (uint32_t)mCountLimit, (uint64_t)inputTexture->getWidth() * inputTexture->getHeight(), pRenderContext->getStream());
 }
@@ -614,6 +675,12 @@ void BlockwiseMultiOrderFeatureRegression::execute(RenderContext* pRenderContext
   if (!mpResManager || !mpRays) return;
   Texture::SharedPtr inputTexture = mpResManager->getTexture(mDenoiseChannel);
   if (!inputTexture || !mDoDenoise) return;
+  if (mpRays->tiled()) {  // the filter's blocks need their neighbours: it works on the whole frame, a rank holds its stripes
+    static bool told = false;
+    if (!told) std::fprintf(stderr, "[BMFR] skipped: a tiled pipeline holds only its own rows; denoise the gathered frame\n");
+    told = true;
+    return;
+  }
   Texture::SharedPtr pos = mpResManager->getTexture("WorldPosition"), nrm = mpResManager->getTexture("WorldNormal"),
                      alb = mpResManager->getTexture("MaterialDiffuse");
   if (!pos || !nrm || !alb || !mpScene || !mpScene->getActiveCamera()) return;
@@ -684,6 +751,16 @@ RenderingPipeline::~RenderingPipeline() {
     if (p) p->onShutdown();
   mActivePasses.clear();
 }
+bool RenderingPipeline::setTiling(uint32_t rank, uint32_t world, ncclComm_t comm) {
+  if (world == 0 || rank >= world || (world > 1 && !comm)) return false;
+  mTileRank = rank;
+  mTileWorld = world;
+  mTileComm = comm;
+  return true;
+}
+std::string RenderingPipeline::rankPath(const std::string& path) const {
+  return mTileWorld > 0 ? path + ".rank" + std::to_string(mTileRank) + "of" + std::to_string(mTileWorld) : path;
+}
 bool RenderingPipeline::inFlightActive() {
   if (mFramesInFlight <= 1 || mSlotStreams.empty()) return false;
   for (auto& p : mActivePasses)
@@ -704,6 +781,12 @@ bool RenderingPipeline::initialize(Scene::SharedPtr pScene) {
     if (!p->onInitialize(&mContext, mpResourceManager)) p = nullptr;  // a failing pass is dropped (RenderingPipeline.cpp:58-59)
   }
   mpResourceManager->initializeResources();
+  if (mTileWorld > 0) {  // multi-GPU: the launcher's contexts render this rank's stripes
+    mpRays = RayLaunch::create(&mContext);
+    TileExchange::SharedPtr x = TileExchange::create(mContext.getDevice(), mTileRank, mTileWorld, mTileComm);
+    if (!mpRays || !x) return false;
+    mpRays->setTiling(x);
+  }
   if (mFramesInFlight > 1) {  // frame slots: channels, launcher contexts and streams, one set per frame in flight
     mpRays = RayLaunch::create(&mContext);
     if (!mpRays || !mpRays->setSlotCount(mFramesInFlight)) return false;
@@ -872,7 +955,7 @@ bool RenderingPipeline::saveCheckpoint(const std::string& path) {
     put64(out, st.size());
     out.insert(out.end(), st.begin(), st.end());
   }
-  FILE* f = std::fopen(path.c_str(), "wb");
+  FILE* f = std::fopen(rankPath(path).c_str(), "wb");
   if (!f) return false;
   const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
   return std::fclose(f) == 0 && ok;
@@ -884,7 +967,7 @@ bool RenderingPipeline::loadCheckpoint(const std::string& path) {
       std::fprintf(stderr, "[RenderingPipeline] pass '%s' holds cross-frame state no checkpoint carries: not resuming\n", pass->getName().c_str());
       return false;
     }
-  FILE* f = std::fopen(path.c_str(), "rb");
+  FILE* f = std::fopen(rankPath(path).c_str(), "rb");
   if (!f) return false;
   std::vector<uint8_t> d;
   uint8_t buf[65536];
@@ -931,7 +1014,50 @@ bool RenderingPipeline::loadCheckpoint(const std::string& path) {
 std::vector<float> RenderingPipeline::readOutput() {
   for (hipStream_t st : mSlotStreams) (void)hipStreamSynchronize(st);
   Texture::SharedPtr t = mpResourceManager->getTexture(ResourceManager::kOutputChannel);  // the latest frame's slot
-  return t ? t->download(mContext.getStream()) : std::vector<float>();
+  if (!t) return std::vector<float>();
+  if (mTileWorld == 0 || !mpRays || !mpRays->tiled()) return t->download(mContext.getStream());
+  // Tiled: "tile framebuffers gathered".  Every rank packs its rows (its stripes in order, zero-padded to the chunk
+  // size all ranks share), one ncclAllGather hands every rank all of them, and the rows go back to their places.
+  // Collective: every rank of the group must call readOutput() at the same point of its frame sequence.
+  hipStream_t stream = mContext.getStream();
+  (void)hipStreamSynchronize(stream);
+  const uint32_t W = t->getWidth(), H = t->getHeight(), world = mTileWorld, R = mpRays->stripeRows();
+  const bdpt_tile_info& ti = mpRays->tileInfo();
+  const size_t perRank = (size_t)ti.chunkRows * W * 4;
+  float *mine = nullptr, *all = nullptr;
+  std::vector<float> out;
+  if (hipMalloc(&mine, std::max<size_t>(perRank * 4, 16)) != hipSuccess || hipMalloc(&all, std::max<size_t>(perRank * 4 * world, 16)) != hipSuccess) {
+    if (mine) (void)hipFree(mine);
+    return out;
+  }
+  (void)hipMemsetAsync(mine, 0, perRank * 4, stream);
+  const uint32_t numStripes = (H + R - 1) / R;
+  const float* src = (const float*)t->getDevicePointer();
+  size_t at = 0;
+  for (uint32_t s = mTileRank; s < numStripes; s += world) {
+    const uint32_t a = s * R, b = std::min(H, a + R);
+    (void)hipMemcpyAsync(mine + at, src + (size_t)a * W * 4, (size_t)(b - a) * W * 16, hipMemcpyDeviceToDevice, stream);
+    at += (size_t)(b - a) * W * 4;
+  }
+  const bool ok = mpRays->exchange()->allGather(mine, all, perRank, stream);
+  std::vector<float> packed(perRank * world);
+  if (ok && hipStreamSynchronize(stream) == hipSuccess &&
+      hipMemcpy(packed.data(), all, packed.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+    out.assign((size_t)W * H * 4, 0.0f);
+    for (uint32_t r = 0; r < world; r++) {
+      size_t from = (size_t)r * perRank;
+      for (uint32_t s = r; s < numStripes; s += world) {
+        const uint32_t a = s * R, b = std::min(H, a + R);
+        std::memcpy(&out[(size_t)a * W * 4], &packed[from], (size_t)(b - a) * W * 16);
+        from += (size_t)(b - a) * W * 4;
+      }
+    }
+  } else if (!ok) {
+    std::fprintf(stderr, "[RenderingPipeline] gather failed: %s\n", mpRays->exchange()->lastError().c_str());
+  }
+  (void)hipFree(mine);
+  (void)hipFree(all);
+  return out;
 }
 
 }  // namespace bdpt

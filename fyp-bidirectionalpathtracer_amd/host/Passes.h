@@ -8,6 +8,7 @@
 #pragma once
 #include "../../include/bdpt.h"
 #include "RenderPass.h"
+#include "Tiling.h"
 
 namespace bdpt {
 
@@ -29,9 +30,24 @@ class RayLaunch {
   // Frames in flight: one bdpt_ctx per frame slot (each owns its path state and traverses its own copy of the BVH)
   bool setSlotCount(uint32_t n);
   void setCurrentSlot(uint32_t s) { mSlot = s <= mMore.size() ? s : 0; }
+  uint32_t currentSlot() const { return mSlot; }
+  // Multi-GPU tiling (Tiling.h): every context of this launcher renders the stripes of rank
+  // x->rank() of x->world() (bdpt_resize_stripes) and keeps its splat accumulators owner-major; the passes then run the
+  // two-phase execute with the exchange in between.  Call before the first frame (RenderingPipeline::setTiling does).
+  void setTiling(TileExchange::SharedPtr x);
+  bool tiled() const { return mExchange != nullptr; }
+  TileExchange::SharedPtr exchange() const { return mExchange; }
+  const bdpt_tile_info& tileInfo() const { return mTileInfo; }
+  uint32_t stripeRows() const { return mStripeRows; }
+  uint64_t* tileSplat() const { return mTileSplat.empty() ? nullptr : mTileSplat[mSlot]; }  // the current slot's reduced chunk
 
  private:
   RayLaunch() = default;
+  void freeTileSplat();
+  TileExchange::SharedPtr mExchange;
+  bdpt_tile_info mTileInfo{};
+  uint32_t mStripeRows = 0;
+  std::vector<uint64_t*> mTileSplat;  // per slot: chunkU64 words, receives this rank's chunk of the reduce-scatter
   bdpt_ctx* mCtx = nullptr;
   std::vector<bdpt_ctx*> mMore;  // slots 1..
   uint32_t mSlot = 0;
@@ -183,6 +199,15 @@ class RenderingPipeline {
   // Call before initialize(); ignored (n = 1) while a pass holds temporal state of its own (the denoiser switched on).
   void setFramesInFlight(uint32_t n) { mFramesInFlight = n < 1 ? 1 : (n > 8 ? 8 : n); }
   uint32_t getFramesInFlight() const { return mFramesInFlight; }
+  // Multi-GPU: this pipeline is rank `rank` of `world` pipelines (one per GPU, in threads of one process or in
+  // processes of their own) that render ONE frame together — interleaved stripes of rows, scene replicated, splat
+  // accumulators summed with one ncclReduceScatter per frame, the frame assembled by ncclAllGather when it is read
+  // back (readOutput).  `comm` is this rank's RCCL communicator, created and destroyed by the host program; nullptr is
+  // allowed for world == 1 (the tiled code path without a collective).  Call before initialize().  The passes and
+  // their per-frame order (SharedUtils/RenderingPipeline.cpp:611-695) are unchanged; what is replaced is the single
+  // DispatchRays of the reference (Falcor API/D3D12/D3D12RenderContext.cpp:350-384).  Same image as one GPU, bit for bit.
+  bool setTiling(uint32_t rank, uint32_t world, ncclComm_t comm);
+  bool isTiled() const { return mTileWorld > 0; }
   // RenderingPipeline::run (RenderingPipeline.cpp:697-712) without a window: size the channels from the config,
   // load the scene named by BDPT_SCENE (a .fscene / .obj path, "atrium", default the Cornell box), render BDPT_FRAMES
   // frames (default 1), and delete the pipeline.
@@ -217,6 +242,9 @@ class RenderingPipeline {
   std::vector<hipEvent_t> mOrderEvents;    // per ordered pass: recorded after it ran for the latest frame
   RayLaunch::SharedPtr mpRays;             // kept to switch the launcher's slot
   bool inFlightActive();
+  uint32_t mTileRank = 0, mTileWorld = 0;  // world 0: not tiled
+  ncclComm_t mTileComm = nullptr;
+  std::string rankPath(const std::string& path) const;  // checkpoints of a tiled pipeline are per rank
 };
 
 }  // namespace bdpt

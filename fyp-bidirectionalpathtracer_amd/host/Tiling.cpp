@@ -1,0 +1,96 @@
+// Tiling.cpp — RCCL side of the tiled frame loop (Tiling.h).
+#include "Tiling.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "../../include/bdpt.h"
+
+namespace bdpt {
+
+uint32_t stripeRows(uint32_t height, uint32_t world) { return bdpt_stripe_rows(height, world); }
+
+TileExchange::SharedPtr TileExchange::create(int device, uint32_t rank, uint32_t world, ncclComm_t comm) {
+  if (world == 0 || rank >= world || (world > 1 && !comm)) return nullptr;
+  SharedPtr x(new TileExchange());
+  x->mDevice = device;
+  x->mRank = rank;
+  x->mWorld = world;
+  x->mComm = comm;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  if (hipStreamCreateWithFlags(&x->mStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  for (uint32_t i = 0; i < kMaxSlots; i++)
+    if (hipEventCreateWithFlags(&x->mReady[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->mDone[i], hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+  return x;
+}
+
+TileExchange::~TileExchange() {
+  if (mStream) {
+    (void)hipStreamSynchronize(mStream);
+    (void)hipStreamDestroy(mStream);
+  }
+  for (uint32_t i = 0; i < kMaxSlots; i++) {
+    if (mReady[i]) (void)hipEventDestroy(mReady[i]);
+    if (mDone[i]) (void)hipEventDestroy(mDone[i]);
+  }
+}
+
+bool TileExchange::reduceScatter(const uint64_t* full, uint64_t* mine, uint64_t chunkU64, hipStream_t renderStream, uint32_t slot) {
+  if (slot >= kMaxSlots || !full || !mine) return false;
+  if (hipEventRecord(mReady[slot], renderStream) != hipSuccess) return false;
+  if (hipStreamWaitEvent(mStream, mReady[slot], 0) != hipSuccess) return false;
+  if (mComm) {
+    const ncclResult_t r = ncclReduceScatter(full, mine, (size_t)chunkU64, ncclUint64, ncclSum, mComm, mStream);
+    if (r != ncclSuccess) {
+      mError = std::string("ncclReduceScatter: ") + ncclGetErrorString(r);
+      return false;
+    }
+  } else if (mine != full + (size_t)mRank * chunkU64) {  // one rank, no communicator: its chunk is the buffer
+    if (hipMemcpyAsync(mine, full + (size_t)mRank * chunkU64, (size_t)chunkU64 * 8, hipMemcpyDeviceToDevice, mStream) != hipSuccess) return false;
+  }
+  return hipEventRecord(mDone[slot], mStream) == hipSuccess;
+}
+
+void TileExchange::waitFor(hipStream_t renderStream, uint32_t slot) {
+  if (slot < kMaxSlots) (void)hipStreamWaitEvent(renderStream, mDone[slot], 0);
+}
+
+bool TileExchange::allGather(const float* mine, float* all, size_t count, hipStream_t stream) {
+  if (mComm) {
+    const ncclResult_t r = ncclAllGather(mine, all, count, ncclFloat32, mComm, stream);
+    if (r != ncclSuccess) {
+      mError = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+      return false;
+    }
+    return true;
+  }
+  return hipMemcpyAsync(all + (size_t)mRank * count, mine, count * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess;
+}
+
+bool exchangeUniqueIdThroughFile(const std::string& path, uint32_t rank, ncclUniqueId* id, double timeoutSeconds) {
+  if (rank == 0) {
+    if (ncclGetUniqueId(id) != ncclSuccess) return false;
+    const std::string tmp = path + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(id, sizeof(*id), 1, f) == 1;
+    if (std::fclose(f) != 0 || !ok) return false;
+    return std::rename(tmp.c_str(), path.c_str()) == 0;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    if (FILE* f = std::fopen(path.c_str(), "rb")) {
+      const bool ok = std::fread(id, sizeof(*id), 1, f) == 1;
+      std::fclose(f);
+      if (ok) return true;
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) return false;
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+}
+
+}  // namespace bdpt

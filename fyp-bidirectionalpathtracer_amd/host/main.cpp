@@ -1,11 +1,21 @@
 // main.cpp — headless counterpart of BidirectionalPathtracing/Main.cpp:9-29: the same pipeline
 // (G-buffer pass -> BDPT pass -> accumulation pass -> BMFR denoiser, which is off unless --denoise /
 // --denoise-regression tick its boxes), run for a number of frames, output written as a PFM image.
+//
+// Multi-GPU: `--gpus N` runs N such pipelines, one per GPU, each on a host thread of its own
+// with its own RCCL communicator (ncclCommInitAll); `--rank R --world N --id-file F` is the same for one PROCESS per
+// GPU (ncclCommInitRank; rank 0 hands the ncclUniqueId to the others through file F).  Every rank renders its
+// interleaved stripes of the ONE frame (RenderingPipeline::setTiling), the splat accumulators are summed with one
+// ncclReduceScatter per frame, the frame is assembled with ncclAllGather when it is written.  `--gpus 1` takes the
+// same code path through a one-rank communicator.
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "ReferenceNames.h"  // the mirror's classes under the reference's global names: no `using namespace`
 
@@ -18,53 +28,61 @@ static void writePfm(const char* path, const std::vector<float>& rgba, uint32_t 
   std::fclose(f);
 }
 
-int main(int argc, char** argv) {
-  std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume, envFile;
+
+namespace {
+struct Options {
+  std::string scene = "cornell", out = "bdpt_out.pfm", raw, checkpoint, resume, envFile, idFile;
   uint32_t W = 1280, H = 720;  // the reference's window, Main.cpp:23-24
   int frames = 8, depth = 3, mat = 0, device = 0, accumLimit = 100, inflight = 1, warmup = 0;
+  int gpus = 0, rank = -1, world = 0;  // gpus: ranks as threads of this process; rank / world: this process is one rank
   bool denoise = false, denoiseRegression = false;
-  for (int i = 1; i < argc; i++) {
-    auto next = [&](const char* name) -> const char* {
-      if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
-      return nullptr;
-    };
-    if (std::strcmp(argv[i], "--denoise") == 0) denoise = true;
-    else if (std::strcmp(argv[i], "--denoise-regression") == 0) denoise = denoiseRegression = true;
-    else if (const char* v = next("--scene")) scene = v;
-    else if (const char* v = next("--width")) W = (uint32_t)std::atoi(v);
-    else if (const char* v = next("--height")) H = (uint32_t)std::atoi(v);
-    else if (const char* v = next("--frames")) frames = std::atoi(v);
-    else if (const char* v = next("--depth")) depth = std::atoi(v);
-    else if (const char* v = next("--mat")) mat = std::atoi(v);
-    else if (const char* v = next("--device")) device = std::atoi(v);
-    else if (const char* v = next("--accum-limit")) accumLimit = std::atoi(v);
-    else if (const char* v = next("--out")) out = v;
-    else if (const char* v = next("--raw")) raw = v;
-    else if (const char* v = next("--checkpoint")) checkpoint = v;
-    else if (const char* v = next("--resume")) resume = v;
-    else if (const char* v = next("--env")) envFile = v;
-    else if (const char* v = next("--inflight")) inflight = std::atoi(v);
-    else if (const char* v = next("--warmup")) warmup = std::atoi(v);  // of --frames: rendered before the clock starts (first-use allocations)
-    else {
-      std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
-                           "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32] "
-                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black] [--inflight N] [--warmup N]\n");
-      return 2;
+};
+
+// all ranks of one process meet here (timing brackets); a multi-process run brackets with a collective instead
+class Barrier {
+ public:
+  explicit Barrier(int n) : mN(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mM);
+    const uint64_t gen = mGen;
+    if (++mCount == mN) {
+      mCount = 0;
+      mGen++;
+      mCv.notify_all();
+    } else {
+      mCv.wait(lk, [&] { return gen != mGen; });
     }
-  }
-  // a path (.fscene / .obj) goes through the loader, as SceneLoaderWrapper::loadScene does for the file dialog's pick
-  Scene::SharedPtr pScene;
-  if (scene.find('.') != std::string::npos) {
-    std::string err;
-    pScene = Scene::loadFromFile(scene, &err);
-    if (!pScene) {
-      std::fprintf(stderr, "bdpt_render: %s\n", err.c_str());
-      return 1;
-    }
-  } else {
-    pScene = scene == "atrium" ? Scene::createAtrium(1, 262144) : Scene::createCornellBox();
   }
 
+ private:
+  std::mutex mM;
+  std::condition_variable mCv;
+  int mN, mCount = 0;
+  uint64_t mGen = 0;
+};
+
+struct RankResult {
+  int rc = 1;
+  double ms = 0;
+};
+
+Scene::SharedPtr makeScene(const Options& o, std::string* err) {
+  // a path (.fscene / .obj) goes through the loader, as SceneLoaderWrapper::loadScene does for the file dialog's pick
+  if (o.scene.find('.') != std::string::npos) return Scene::loadFromFile(o.scene, err);
+  return o.scene == "atrium" ? Scene::createAtrium(1, 262144) : Scene::createCornellBox();
+}
+
+// One pipeline on one GPU.  world == 0: the plain single-GPU run.  Otherwise rank `rank` of `world` (comm may be null
+// for world == 1).  `barrier` (threads of one process) may be null.
+RankResult runRank(const Options& o, int device, uint32_t rank, uint32_t world, ncclComm_t comm, Barrier* barrier) {
+  RankResult res;
+  const bool tiled = world > 0, writer = !tiled || rank == 0;
+  std::string err;
+  Scene::SharedPtr pScene = makeScene(o, &err);  // every rank holds the scene (and builds its BVH): replicated
+  if (!pScene) {
+    std::fprintf(stderr, "bdpt_render: %s\n", err.c_str());
+    return res;
+  }
   // Create our rendering pipeline and add the passes, as Main.cpp:12-18 does
   RenderingPipeline* pipeline = new RenderingPipeline();
   pipeline->setPass(0, LightProbeGBufferPass::create());
@@ -74,56 +92,172 @@ int main(int argc, char** argv) {
   // the window parameters of Main.cpp:20-25 size the channels (there is no window)
   SampleConfig config;
   config.windowDesc.resizableWindow = true;
-  config.windowDesc.width = W;
-  config.windowDesc.height = H;
+  config.windowDesc.width = o.W;
+  config.windowDesc.height = o.H;
   config.windowDesc.title = "Bidirectional Path Tracing (headless)";
   pipeline->setSize(config.windowDesc.width, config.windowDesc.height, device);
-  pipeline->setFramesInFlight((uint32_t)(inflight < 1 ? 1 : inflight));  // offline accumulation: frames overlap, same image
+  pipeline->setFramesInFlight((uint32_t)(o.inflight < 1 ? 1 : o.inflight));  // offline accumulation: frames overlap, same image
+  if (tiled && !pipeline->setTiling(rank, world, comm)) {
+    std::fprintf(stderr, "bdpt_render: bad tiling (rank %u of %u)\n", rank, world);
+    return res;
+  }
   if (!pipeline->initialize(pScene) || pipeline->getPassCount() != 4) {
     std::fprintf(stderr, "pipeline initialisation failed (no GPU?)\n");
-    return 1;
+    return res;
   }
   // the light probe a user would pick in the file dialog (RenderingPipeline.cpp:229-243 -> ResourceManager::updateEnvironmentMap)
-  if (!envFile.empty() && !pipeline->getResourceManager()->updateEnvironmentMap(envFile)) {
-    std::fprintf(stderr, "bdpt_render: cannot load the environment map %s\n", envFile.c_str());
-    return 1;
+  if (!o.envFile.empty() && !pipeline->getResourceManager()->updateEnvironmentMap(o.envFile)) {
+    std::fprintf(stderr, "bdpt_render: cannot load the environment map %s\n", o.envFile.c_str());
+    return res;
   }
   Gui gui;  // what a user would have set in the GUI windows
-  gui.overrides["Max Ray Depth"] = depth;
-  gui.overrides["Material"] = mat;
-  gui.overrides["Max frames to accumulate"] = accumLimit;
-  if (denoise) gui.overrides["Ignore the denoise stage"] = 1;  // the check box's label while it is off (DenoisePass.cpp:139)
-  if (denoiseRegression) gui.overrides["Skip Regression"] = 1;
+  gui.overrides["Max Ray Depth"] = o.depth;
+  gui.overrides["Material"] = o.mat;
+  gui.overrides["Max frames to accumulate"] = o.accumLimit;
+  if (o.denoise) gui.overrides["Ignore the denoise stage"] = 1;  // the check box's label while it is off (DenoisePass.cpp:139)
+  if (o.denoiseRegression) gui.overrides["Skip Regression"] = 1;
   pipeline->applyGui(&gui);
-  if (!resume.empty() && !pipeline->loadCheckpoint(resume)) {  // continue an earlier run's frame sequence
-    std::fprintf(stderr, "bdpt_render: cannot resume from %s (missing, or written for other passes / another frame size)\n", resume.c_str());
-    return 1;
+  if (!o.resume.empty() && !pipeline->loadCheckpoint(o.resume)) {  // continue an earlier run's frame sequence
+    std::fprintf(stderr, "bdpt_render: cannot resume from %s (missing, or written for other passes / another frame size)\n", o.resume.c_str());
+    return res;
   }
 
-  if (warmup < 0 || warmup >= frames) warmup = 0;
+  int warmup = o.warmup;
+  if (warmup < 0 || warmup >= o.frames) warmup = 0;
   for (int f = 0; f < warmup; f++) pipeline->renderFrame();
   (void)hipDeviceSynchronize();
+  if (barrier) barrier->wait();
   auto t0 = std::chrono::steady_clock::now();
-  for (int f = warmup; f < frames; f++) pipeline->renderFrame();
+  for (int f = warmup; f < o.frames; f++) pipeline->renderFrame();
   (void)hipDeviceSynchronize();
-  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  std::vector<float> img = pipeline->readOutput();
-  double mean = 0;
-  for (size_t i = 0; i < img.size(); i += 4) mean += img[i] + img[i + 1] + img[i + 2];
-  std::printf("%s %ux%u depth %d mat %d: %d frames in %.2f ms (%.2f ms/frame), mean radiance %.6f\n", scene.c_str(), W, H, depth, mat,
-              frames - warmup, ms, ms / (frames - warmup), mean / (3.0 * (double)(img.size() / 4)));
-  writePfm(out.c_str(), img, W, H);
-  if (!checkpoint.empty() && !pipeline->saveCheckpoint(checkpoint)) {
-    std::fprintf(stderr, "bdpt_render: cannot write %s\n", checkpoint.c_str());
-    return 1;
+  if (barrier) barrier->wait();  // the job is done when its slowest rank is
+  res.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<float> img = pipeline->readOutput();  // tiled: a collective — every rank calls it, every rank gets the frame
+  if (img.size() != (size_t)o.W * o.H * 4) {
+    std::fprintf(stderr, "bdpt_render: reading the output back failed\n");
+    return res;
   }
-  if (!raw.empty()) {
-    FILE* f = std::fopen(raw.c_str(), "wb");
+  if (writer) {
+    double mean = 0;
+    for (size_t i = 0; i < img.size(); i += 4) mean += img[i] + img[i + 1] + img[i + 2];
+    std::printf("%s %ux%u depth %d mat %d: %d frames in %.2f ms (%.2f ms/frame), mean radiance %.6f", o.scene.c_str(), o.W, o.H, o.depth, o.mat,
+                o.frames - warmup, res.ms, res.ms / (o.frames - warmup), mean / (3.0 * (double)(img.size() / 4)));
+    if (tiled) std::printf(", %u GPU%s (interleaved stripes of %u rows, RCCL reduce-scatter + all-gather)", world, world == 1 ? "" : "s",
+                           bdpt_stripe_rows(o.H, world));
+    std::printf("\n");
+    writePfm(o.out.c_str(), img, o.W, o.H);
+  }
+  if (!o.checkpoint.empty() && !pipeline->saveCheckpoint(o.checkpoint)) {  // tiled: one file per rank (its rows)
+    std::fprintf(stderr, "bdpt_render: cannot write %s\n", o.checkpoint.c_str());
+    return res;
+  }
+  if (writer && !o.raw.empty()) {
+    FILE* f = std::fopen(o.raw.c_str(), "wb");
     if (f) {
       std::fwrite(img.data(), 4, img.size(), f);
       std::fclose(f);
     }
   }
   delete pipeline;
-  return 0;
+  res.rc = 0;
+  return res;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  Options o;
+  for (int i = 1; i < argc; i++) {
+    auto next = [&](const char* name) -> const char* {
+      if (std::strcmp(argv[i], name) == 0 && i + 1 < argc) return argv[++i];
+      return nullptr;
+    };
+    if (std::strcmp(argv[i], "--denoise") == 0) o.denoise = true;
+    else if (std::strcmp(argv[i], "--denoise-regression") == 0) o.denoise = o.denoiseRegression = true;
+    else if (const char* v = next("--scene")) o.scene = v;
+    else if (const char* v = next("--width")) o.W = (uint32_t)std::atoi(v);
+    else if (const char* v = next("--height")) o.H = (uint32_t)std::atoi(v);
+    else if (const char* v = next("--frames")) o.frames = std::atoi(v);
+    else if (const char* v = next("--depth")) o.depth = std::atoi(v);
+    else if (const char* v = next("--mat")) o.mat = std::atoi(v);
+    else if (const char* v = next("--device")) o.device = std::atoi(v);
+    else if (const char* v = next("--accum-limit")) o.accumLimit = std::atoi(v);
+    else if (const char* v = next("--out")) o.out = v;
+    else if (const char* v = next("--raw")) o.raw = v;
+    else if (const char* v = next("--checkpoint")) o.checkpoint = v;
+    else if (const char* v = next("--resume")) o.resume = v;
+    else if (const char* v = next("--env")) o.envFile = v;
+    else if (const char* v = next("--inflight")) o.inflight = std::atoi(v);
+    else if (const char* v = next("--warmup")) o.warmup = std::atoi(v);  // of --frames: rendered before the clock starts (first-use allocations)
+    else if (const char* v = next("--gpus")) o.gpus = std::atoi(v);
+    else if (const char* v = next("--rank")) o.rank = std::atoi(v);
+    else if (const char* v = next("--world")) o.world = std::atoi(v);
+    else if (const char* v = next("--id-file")) o.idFile = v;
+    else {
+      std::fprintf(stderr, "usage: bdpt_render [--scene cornell|atrium|FILE.fscene|FILE.obj] [--width W] [--height H] [--frames N] [--depth D] "
+                           "[--mat 0|1] [--accum-limit N] [--denoise | --denoise-regression] [--out file.pfm] [--raw file.f32] "
+                           "[--resume file.ckpt] [--checkpoint file.ckpt] [--env probe.hdr|image|Black] [--inflight N] [--warmup N] "
+                           "[--gpus N | --rank R --world N --id-file F [--device D]]\n");
+      return 2;
+    }
+  }
+  if (o.gpus < 0 || o.gpus > 64 || (o.gpus > 0 && o.world > 0)) {
+    std::fprintf(stderr, "bdpt_render: --gpus N (ranks as threads) or --rank R --world N --id-file F (one process per rank), not both\n");
+    return 2;
+  }
+  if ((o.denoise) && (o.gpus > 0 || o.world > 0)) {
+    std::fprintf(stderr, "bdpt_render: the BMFR denoiser filters whole frames; a tiled run holds stripes (denoise the gathered image)\n");
+    return 2;
+  }
+
+  if (o.world > 0) {  // one process per GPU: this is rank --rank of --world
+    if (o.rank < 0 || o.rank >= o.world || o.idFile.empty()) {
+      std::fprintf(stderr, "bdpt_render: --world N needs --rank R in [0, N) and --id-file F\n");
+      return 2;
+    }
+    if (hipSetDevice(o.device) != hipSuccess) {
+      std::fprintf(stderr, "bdpt_render: no HIP device %d\n", o.device);
+      return 1;
+    }
+    ncclUniqueId id;
+    ncclComm_t comm = nullptr;
+    if (!bdpt::exchangeUniqueIdThroughFile(o.idFile, (uint32_t)o.rank, &id) ||
+        ncclCommInitRank(&comm, o.world, id, o.rank) != ncclSuccess) {
+      std::fprintf(stderr, "bdpt_render: rank %d could not join the communicator through %s\n", o.rank, o.idFile.c_str());
+      return 1;
+    }
+    RankResult r = runRank(o, o.device, (uint32_t)o.rank, (uint32_t)o.world, comm, nullptr);
+    ncclCommDestroy(comm);
+    return r.rc;
+  }
+
+  if (o.gpus > 0) {  // N ranks as threads of this process, GPUs device .. device + N - 1
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < o.device + o.gpus) {
+      std::fprintf(stderr, "bdpt_render: --gpus %d from device %d, but %d HIP device(s) are visible\n", o.gpus, o.device, have);
+      return 1;
+    }
+    std::vector<int> devs((size_t)o.gpus);
+    for (int i = 0; i < o.gpus; i++) devs[(size_t)i] = o.device + i;
+    std::vector<ncclComm_t> comms((size_t)o.gpus, nullptr);
+    const ncclResult_t nr = ncclCommInitAll(comms.data(), o.gpus, devs.data());
+    if (nr != ncclSuccess) {
+      std::fprintf(stderr, "bdpt_render: ncclCommInitAll: %s\n", ncclGetErrorString(nr));
+      return 1;
+    }
+    Barrier barrier(o.gpus);
+    std::vector<RankResult> results((size_t)o.gpus);
+    std::vector<std::thread> threads;
+    for (int r = 1; r < o.gpus; r++)
+      threads.emplace_back([&, r] { results[(size_t)r] = runRank(o, devs[(size_t)r], (uint32_t)r, (uint32_t)o.gpus, comms[(size_t)r], &barrier); });
+    results[0] = runRank(o, devs[0], 0u, (uint32_t)o.gpus, comms[0], &barrier);
+    for (std::thread& t : threads) t.join();
+    int rc = 0;
+    for (int r = 0; r < o.gpus; r++) {
+      if (results[(size_t)r].rc != 0) rc = 1;
+      ncclCommDestroy(comms[(size_t)r]);
+    }
+    return rc;
+  }
+
+  return runRank(o, o.device, 0u, 0u, nullptr, nullptr).rc;
 }

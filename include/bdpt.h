@@ -365,6 +365,12 @@ int bdpt_resize(bdpt_ctx* ctx, uint32_t width, uint32_t height, bdpt_tile tile, 
  * the numOwners ranks leaves every rank with the summed accumulators of exactly its own pixels, in tile-local
  * order, ready for bdpt_resolve_tile.  (With bdpt_resize the buffer is in plain frame order.) */
 int bdpt_resize_stripes(bdpt_ctx* ctx, uint32_t width, uint32_t height, bdpt_stripes stripes, uint32_t maxDepth);
+/* The stripe height the tiled hosts of this build use for a frame of `height` rows dealt to `numOwners` ranks (C++
+ * RenderingPipeline::setTiling, Python tiling.stripe_rows): small enough that every rank gets at least four stripes,
+ * at most 8 rows — a stripe is only a run of rows in the tile's pixel list, so its size costs nothing, and small ones
+ * spread the rows that cost most.  Host-only helper; any stripeRows >= 1 is valid for
+ * bdpt_resize_stripes as long as all ranks agree. */
+uint32_t bdpt_stripe_rows(uint32_t height, uint32_t numOwners);
 int bdpt_get_tile_info(const bdpt_ctx* ctx, bdpt_tile_info* out);
 /* The tile's rows as [first, last) pairs in ascending order; writes up to cap pairs, returns how many. */
 int bdpt_tile_row_ranges(const bdpt_ctx* ctx, uint32_t* out_first_last, uint32_t cap);

@@ -346,6 +346,13 @@ def test_tiling_bands(pkg):
             assert 0 <= a <= b <= H and b - a <= rows
             covered += list(range(a, b))
         assert covered == list(range(H))
+    # stripes: the C++ host (bdpt_stripe_rows) and the Python host (tiling.stripe_rows) deal the rows the same way
+    lib = pkg.load_library()
+    for H in (1, 3, 7, 64, 180, 720, 1080, 2160, 4320):
+        for world in (1, 2, 3, 4, 5, 8, 16):
+            assert lib.bdpt_stripe_rows(H, world) == t.stripe_rows(H, world), (H, world)
+            rows = sorted(y for r in range(world) for a, b in t.stripes_of(H, world, r) for y in range(a, b))
+            assert rows == list(range(H))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -398,6 +405,30 @@ def test_error_conventions_without_gpu(pkg):
     assert lib.bdpt_set_scene(None, None) == -1 and lib.bdpt_resize(None, 1, 1, pkg.abi.Tile(0, 1), 3) == -1
 
 
+def test_bench_gpus_n_starts_its_own_ranks_before_touching_a_gpu(tmp_path):
+    """`python bench.py --gpus 2` as the driver would type it for N = 1: no launcher, no RANK.  It must start the two
+    ranks itself as a child process (torch.distributed.run over 127.0.0.1) and hand their exit code back.  Here there is
+    no GPU, so each RANK stops with bench.py's own "visible GPUs" message — which shows both were started — and the
+    parent never imported torch (it is gone before `import torch`, so the message cannot come from it)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "BDPT_BENCH_DEVICE")}
+    env["BDPT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("2 ranks but 0 visible GPUs") == 2, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    import ast
+    src = open(os.path.join(root, "bench.py")).read()
+    main = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    launch_line = [n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "launch_ranks"][0]
+    torch_line = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Import) and n.names[0].name == "torch")
+    assert launch_line < torch_line  # the child is started before torch (and with it HIP) is imported
+
+
 def test_product_does_not_reference_the_oracle():
     """The oracle is test infrastructure: nothing under the package may import, link or name it."""
     pk = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd")
@@ -429,6 +460,19 @@ def test_bvh_build_does_not_depend_on_thread_count(pkg, which):
     scene.close()
 
 
+def _build_tiled_host_program(exe):
+    import subprocess
+    host = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd", "host")
+    csrc = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd", "csrc")
+    src = os.path.join(ROOT, "tests", "host_compile", "tiled_host_main.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + host, "-o", exe, src,
+                        os.path.join(host, "Passes.cpp"), os.path.join(host, "Tiling.cpp"), "-L" + csrc, "-lbdpt_amd", "-L/opt/rocm/lib",
+                        "-lamdhip64", "-lrccl", "-lpthread", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
 def test_reference_style_program_compiles_against_the_host_mirror():
     """host/ReferenceNames.h exports the mirror's classes at global scope: a program written like the reference's
     Main.cpp (global ::RenderingPipeline, ::BDPTPass ..., SampleConfig, RenderingPipeline::run, a user pass derived from
@@ -443,3 +487,28 @@ def test_reference_style_program_compiles_against_the_host_mirror():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "using namespace" not in open(src).read().split("int main")[1]
+
+
+def test_tiled_multi_gpu_host_program_compiles_links_and_runs(tmp_path):
+    """The multi-GPU host surface — host/Tiling.h (TileExchange over RCCL), RenderingPipeline::setTiling — as a
+    maintainer's program would use it (tests/host_compile/tiled_host_main.cpp: one pipeline per GPU on its own thread,
+    ncclCommInitAll): compiles, links against libbdpt_amd.so and librccl, and runs.  Without a GPU the program says so
+    and exits 0; on the GPU box the same source renders (tests/test_gpu_parity.py runs it there)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = _build_tiled_host_program(str(tmp_path / "tiled_host"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "tiled host:" in r.stdout
+    # bdpt_render is that program with options: the same link line, --gpus / --rank / --world on the usage
+    render = os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd", "host", "bdpt_render")
+    u = subprocess.run([render, "--help"], capture_output=True, text=True, timeout=60)
+    assert u.returncode == 2 and "--gpus N" in u.stderr and "--id-file" in u.stderr
+    sym = subprocess.run(["nm", "-D", "--undefined-only", render], capture_output=True, text=True).stdout
+    assert "ncclReduceScatter" in sym and "ncclAllGather" in sym and "bdpt_resize_stripes" in sym and "bdpt_execute_tail" in sym
+    # the C ABI library itself stays free of RCCL: the host owns the collectives
+    lib = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd", "csrc", "libbdpt_amd.so")],
+                         capture_output=True, text=True).stdout
+    assert "nccl" not in lib

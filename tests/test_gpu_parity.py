@@ -313,10 +313,9 @@ def test_full_size_config_bands_equal_full_frame(pkg, ob):
 
 
 def test_frames_in_flight_tiled_loop_equals_plain_loop(pkg):
-    """bench.py's tiled frame loop (two-phase execute, splat exchange, three frames in flight on three streams,
-    running mean applied in frame order) accumulates exactly the image of the plain one-context loop."""
+    """The package's tiled frame loop (tiling.TileRenderer: two-phase execute, splat exchange, three frames in flight on
+    three streams, running mean applied in frame order) accumulates exactly the image of the plain one-context loop."""
     import torch
-    import bench
     scene = pkg.Scene.atrium(2, 20000)
     W, H, D, frames = 128, 72, 5, 7
     plain = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=0, accum_limit=1 << 30)  # the reference's sequence, one frame at a time
@@ -325,7 +324,7 @@ def test_frames_in_flight_tiled_loop_equals_plain_loop(pkg):
     torch.cuda.synchronize()
     ref = plain.last_frame.cpu().numpy().copy()
     plain.close()
-    tiled = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, 1, 0, None, 3)  # what bench.py times at N = 1
+    tiled = pkg.tiling.TileRenderer(scene, W, H, D, 0, 0, 1, 0, None, 3)  # what bench.py times at N = 1
     assert tiled.inflight == 3
     for _ in range(frames):
         tiled.step()
@@ -635,6 +634,32 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(pkg, tmp_path):
     assert np.isfinite(a).all() and a[..., :3].mean() > 0.01
 
 
+def test_bench_gpus_2_starts_its_own_ranks(pkg):
+    """`python bench.py --gpus 2` with no launcher on the command line and no RANK in the environment: bench.py starts the
+    two ranks itself (a torch.distributed.run child, before it touches a GPU), both ranks share this box's one GPU, the
+    exchange goes through gloo; exit code 0 and exactly ONE JSON line, rank 0's, carrying the whole-job figures."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BDPT_BENCH_BACKEND="gloo", BDPT_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--width", "320",
+                        "--height", "180", "--depth", "5", "--triangles", "30000"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+    t = d["config"]["tiling"]
+    assert t["backend"] == "gloo" and len(t["per_rank"]["ms_per_step"]) == 2 and sum(t["per_rank"]["rows"]) == 180
+    # a wrong rank count under a launcher is still refused, before any GPU work
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, cwd=root, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
 def test_cpp_host_checkpoint_resume_continues_bit_for_bit(pkg, tmp_path):
     """host/bdpt_render --checkpoint / --resume: 7 accumulated frames in one run == 3 frames, checkpoint, a new process
     resuming for 4 more (frame counters, jitter sequence and the running mean carry over); a checkpoint written for
@@ -753,6 +778,49 @@ def test_cpp_host_frames_in_flight_accumulate_the_same_image(pkg, tmp_path):
     d = run(["--frames", "4", "--denoise"], "dn1.f32")
     e = run(["--frames", "4", "--denoise", "--inflight", "3"], "dn3.f32")
     assert np.array_equal(d.view(np.uint32), e.view(np.uint32))
+
+
+def test_cpp_host_tiled_over_rccl_reproduces_the_plain_run(pkg, tmp_path):
+    """host/bdpt_render --gpus 1: the C++ host's multi-GPU frame loop (RenderingPipeline::setTiling -> interleaved stripes via
+    bdpt_resize_stripes, two-phase bdpt_execute with ncclReduceScatter(ncclUint64, ncclSum) on the exchange stream in
+    between, bdpt_resolve_tile, bdpt_accumulate_tile, ncclAllGather of the tiles when the image is written) through a
+    real one-rank RCCL communicator (ncclCommInitAll) must accumulate the image of the plain run bit for bit — also with
+    three frames in flight, and also as one PROCESS per rank (ncclCommInitRank, id through a file).  More ranks need more
+    GPUs: the same binary with --gpus 8 is what an 8-GPU node runs."""
+    import os
+    import subprocess
+    import __graft_entry__ as ge
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe)
+    common = ["--scene", "atrium", "--width", "160", "--height", "90", "--depth", "5", "--frames", "6", "--out", str(tmp_path / "o.pfm")]
+
+    def run(extra, raw):
+        r = subprocess.run([exe] + common + extra + ["--raw", str(tmp_path / raw)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        return np.fromfile(tmp_path / raw, np.float32), r.stdout
+
+    a, _ = run([], "plain.f32")
+    assert a.size == 160 * 90 * 4 and np.isfinite(a).all() and a.reshape(-1, 4)[:, :3].mean() > 0.01
+    b, out = run(["--gpus", "1"], "tiled.f32")
+    assert "1 GPU" in out and "RCCL" in out
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), int((a != b).sum())
+    c, _ = run(["--gpus", "1", "--inflight", "3"], "tiled3.f32")
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), int((a != c).sum())
+    d, _ = run(["--rank", "0", "--world", "1", "--id-file", str(tmp_path / "nccl.id"), "--inflight", "2"], "proc.f32")
+    assert np.array_equal(a.view(np.uint32), d.view(np.uint32)), int((a != d).sum())
+    # a tiled run checkpoints per rank and resumes bit for bit
+    run(["--gpus", "1", "--frames", "2", "--checkpoint", str(tmp_path / "t.ckpt")], "part.f32")
+    assert os.path.exists(str(tmp_path / "t.ckpt") + ".rank0of1")
+    e, _ = run(["--gpus", "1", "--frames", "4", "--resume", str(tmp_path / "t.ckpt")], "res.f32")
+    assert np.array_equal(a.view(np.uint32), e.view(np.uint32))
+    # two ranks on one GPU is refused by the host before RCCL sees it
+    r = subprocess.run([exe] + common + ["--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "HIP device" in r.stderr
+    # the maintainer-style program of tests/host_compile (one pipeline + communicator per visible GPU, frames in flight)
+    import test_cpu_oracle_and_host as th
+    prog = th._build_tiled_host_program(str(tmp_path / "tiled_host"))
+    r = subprocess.run([prog], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "frame gathered on every rank" in r.stdout, r.stderr + r.stdout
 
 
 def test_per_piece_alpha_classification_on_the_device(pkg, ob):

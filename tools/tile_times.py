@@ -19,7 +19,7 @@ for inflight in (1, 3):
     for world in (1, 2, 4, 8):
         worst = 0.0
         for rank in ((0,) if world == 1 else (0, world - 1)):
-            R = bench.TileRenderer(pkg, scene, W, H, D, 0, 0, world, rank, None, inflight)
+            R = pkg.tiling.TileRenderer(scene, W, H, D, 0, 0, world, rank, None, inflight)
             for _ in range(4):
                 R.step()
             R.barrier()

@@ -43,7 +43,7 @@ LANE_LOADS_PER_CLK_PER_CU = 1.03
 VALU_CLK_FAST, VALU_CLK_SLOW = 2.4, 4.3
 SHADER_CLK_HZ = 2.4e9
 NUM_CUS, NUM_SIMDS = 256, 1024
-PROFILE_ROUND = "r3"   # profiles/<round>/roofline_pmc.json holds the PMC counts the roofline block quotes
+PROFILE_ROUND = "r4"   # profiles/<round>/roofline_pmc.json holds the PMC counts the roofline block quotes
 
 
 SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 48  # algorithmic bytes per interior-node / triangle visit
@@ -54,32 +54,43 @@ def num_connect_pairs(D):
     return sum(min(t, D - 1) for t in range(2, D + 1))
 
 
-def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b):
+def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b, D):
     """SURVEY.md §8(d), per frame and per kernel: B_ray = 32 + nodeBytes*n_int + triBytes*n_tri + O (O = 4 shadow /
-    20 closest); 388 B per closest-hit shade; 200 B per connection pair; 116 B per NEE/splat term; 120 B per
-    pixel-frame (56 G-buffer + 16 output + 48 accumulate)."""
+    20 closest); 388 B per closest-hit shade; 168 B per connection pair and 84 B per NEE/splat term for the generators.
+    The gather side of every term (SURVEY: "+ 32 B pixel RMW" per term) is costed where it happens, in the per-pixel
+    kernels, at what one term really needs there: 4 B slot id per slot, 1 B visibility per ray,
+    12 B contribution per ray, ONE 32 B read-modify-write of the pixel (the sums run in registers), 4 B target index per
+    splat slot and 32 B of atomics per landed splat; init_paths: 56 B G-buffer + 16 B output per pixel and, per valid
+    pixel, two 96-B vertices, 24 B ray directions, 8 B seeds, 3 flag bytes, 4 B queue entry; clear + resolve: 32 B of
+    splat accumulator written and read per pixel, 32 B pixel RMW per pixel a splat landed on (<= splats)."""
     closest = cnt["raysEyeExtend"] + cnt["raysLightExtend"]
     shadow = cnt["raysNee"] + cnt["raysSplat"] + cnt["raysConnect"]
+    valid = cnt["pixelsValid"]
+    pairs = num_connect_pairs(D)
     b = {}
     # walk_kernel: every extension ray of both walks and the hit/miss shader that follows it
     b["walk_kernel"] = 52 * closest + node_b * cnt["nodeVisitsClosest"] + tri_b * cnt["triTestsClosest"] + 388 * closest
     # trace_shadow_kernel: main launch + lazy rounds
     b["trace_shadow_kernel"] = 36 * shadow + node_b * cnt["nodeVisitsShadow"] + tri_b * cnt["triTestsShadow"]
-    # gen_nee + gen_splat + gen_connect (+ lazy_gen): D NEE and D splat terms and every defined pair per valid pixel
-    b["gen_kernels"] = 116 * cnt["raysNee"] + 116 * cnt["raysSplat"] + 200 * n_pairs_eval
-    # gbuffer (primary ray costed with the closest-hit means) + init_paths + gather + resolve + accumulate
-    b["per_pixel_kernels"] = 120 * n_pix_tile + 32 * n_pix_tile
+    # gen_nee + gen_splat + gen_connect (+ lazy_gen): the vertex reads of every term and pair, the ray they append (28 B + 12 B)
+    b["gen_kernels"] = 84 * cnt["raysNee"] + 84 * cnt["raysSplat"] + 168 * n_pairs_eval + 40 * shadow
+    # clear + init_paths + gather + lazy_check + resolve
+    b["per_pixel_kernels"] = (n_pix_tile * (56 + 16 + 32 + 32) + valid * (2 * 96 + 24 + 8 + 3 + 4) +
+                              valid * (4 * (2 * D + pairs) + 32 + 4 * D) + shadow * (1 + 12) + cnt["splatsLanded"] * (32 + 32))
     return b
 
 
-def load_pmc(scene, W, H, D, world):
+def load_pmc(pkg, scene, W, H, D, world):
     """Per-kernel, per-frame hardware counts of the committed rocprofv3 --pmc passes of this command
-    (tools/collect_profiles.sh -> tools/roofline_pmc.py): {kernel base name: {counter: value per frame}}."""
+    (tools/collect_profiles.sh -> tools/roofline_pmc.py): {kernel base name: {counter: value per frame}}.  The file names
+    the sources it was measured on (source_hash); counts of another build are not quoted (pmc_build_match false)."""
     pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "roofline_pmc.json")
     if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(pj)):
         return {}
     with open(pj) as f:
         raw = json.load(f)
+    if raw.get("source_hash") != pkg.source_hash():
+        return {"_mismatch": True}
     out = {}
     for k, v in raw["kernels"].items():
         name = k.split("<")[0]
@@ -159,7 +170,9 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, frames=3):
         out = {"workload": name, "resolution": [W, H], "max_depth": D, "mat_index": mat, "frames_timed": frames, "frames_in_flight": 1,
                "ms_per_frame": round(dt * 1e3, 3), "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
                "visits_per_ray": {"closest_nodes": round(s["nodeVisitsClosest"] / closest, 2), "closest_tris": round(s["triTestsClosest"] / closest, 2),
-                                  "shadow_nodes": round(s["nodeVisitsShadow"] / shadow, 2), "shadow_tris": round(s["triTestsShadow"] / shadow, 2)},
+                                  "shadow_nodes": round(s["nodeVisitsShadow"] / shadow, 2), "shadow_tris": round(s["triTestsShadow"] / shadow, 2),
+                                  # any-hit shader invocations (alpha tests) per ray: the "any-hit rate" of BASELINE.md section 3 row 5
+                                  "closest_alpha_tests": round(s["alphaTestsClosest"] / closest, 3), "shadow_alpha_tests": round(s["alphaTestsShadow"] / shadow, 3)},
                "stage_ms": {k: round(v, 2) for k, v in agg.items() if v >= 0.05},
                "bvh": {"nodes": info.numNodes, "references": info.numReferences, "triangles": info.numTriangles,
                        "alpha_mode_triangles": info.numAlphaMode, "always_pass": info.numAlwaysPass, "dropped": info.numDropped},
@@ -174,7 +187,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell"])
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "atrium_uneven", "cornell"],
+                    help="built-in scene: the Sponza stand-in (default), the same hall with heavy-tailed triangle areas, the Cornell box")
+    ap.add_argument("--scene-file", default=None, help="a supplied asset instead: .fscene or .obj, read through bdpt_scene_load "
+                    "(the reference's import rules); config.workload names the file and data says \"file\"")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
@@ -247,8 +263,27 @@ def main():
             raise SystemExit("bench.py: two ranks share a device (%s)" % idents)
 
     W, H, D = args.width, args.height, args.depth
-    mat = args.mat if args.mat is not None else (0 if args.scene == "atrium" else 1)
-    scene = pkg.Scene.atrium(1, args.triangles) if args.scene == "atrium" else pkg.Scene.cornell()
+    scene_load_s = None
+    if args.scene_file:  # a supplied asset (e.g. the real Sponza OBJ, were it dropped on the box)
+        t0 = time.time()
+        scene = pkg.Scene.load(args.scene_file)
+        scene_load_s = time.time() - t0
+        scene_name = "file"
+        workload = "%s (%d triangles, %d materials, %d textures, %d lights; read by bdpt_scene_load in %.2f s)" % (
+            os.path.basename(args.scene_file), scene.desc.numTriangles, scene.desc.numMaterials, scene.desc.numTextures, scene.desc.numLights, scene_load_s)
+        metric_scene = "scene file %s" % os.path.basename(args.scene_file)
+    elif args.scene == "cornell":
+        scene, scene_name = pkg.Scene.cornell(), "cornell"
+        workload, metric_scene = "Cornell box, 32 triangles, Lambertian", "Cornell box"
+    elif args.scene == "atrium_uneven":
+        scene, scene_name = pkg.Scene.atrium_uneven(1, args.triangles), "atrium_uneven"
+        workload = "procedural atrium with heavy-tailed triangle areas (two-triangle walls and floors), %d triangles, textured GGX" % scene.desc.numTriangles
+        metric_scene = "Sponza-class scene"
+    else:
+        scene, scene_name = pkg.Scene.atrium(1, args.triangles), "atrium"
+        workload = "procedural atrium (Sponza stand-in), %d triangles, textured GGX" % scene.desc.numTriangles
+        metric_scene = "Sponza-class scene"
+    mat = args.mat if args.mat is not None else (1 if scene_name == "cornell" else 0)
 
     if args.dump_frames > 0 and args.plain_loop:
         if world != 1 or dist is not None:
@@ -334,7 +369,7 @@ def main():
         # ---- roofline per kernel and for the whole frame.  Algorithmic bytes from the device tallies
         # of one frame of the same sequence; durations = HIP events on the launch stream around each kernel's launches
         # (bdpt_get_stage_times), summed over the frame, averaged over the frames named in stage_timing.
-        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, SURVEY_NODE_BYTES, SURVEY_TRI_BYTES)
+        alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, SURVEY_NODE_BYTES, SURVEY_TRI_BYTES, D)
         ms = {k: v / stage_frames for k, v in stage_ms.items()}
         kernel_ms = {
             "walk_kernel": ms.get("walk", 0.0),
@@ -344,7 +379,10 @@ def main():
             "per_pixel_kernels": ms.get("clear", 0.0) + ms.get("init_paths", 0.0) + ms.get("gather", 0.0) +
                                  ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0),
         }
-        pmc = load_pmc(args.scene, W, H, D, world)
+        pmc = load_pmc(pkg, scene_name, W, H, D, world)
+        pmc_match = None if not pmc else not pmc.get("_mismatch", False)
+        if pmc_match is False:
+            pmc = {}
         members = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
                    "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
                    "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
@@ -420,8 +458,7 @@ def main():
         shadow_per_frame = (per_stage_rays.get("raysNee", 0) + per_stage_rays.get("raysSplat", 0) +
                             per_stage_rays.get("raysConnect", 0)) / stage_frames
         out = {
-            "metric": "Mrays/s + RMSE vs the scalar oracle, BDPT pass, %s %dx%d depth %d" % (
-                "Sponza-class scene" if args.scene == "atrium" else "Cornell box", W, H, D),
+            "metric": "Mrays/s + RMSE vs the scalar oracle, BDPT pass, %s %dx%d depth %d" % (metric_scene, W, H, D),
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -432,10 +469,9 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "file" if args.scene_file else "synthetic",
             "config": {
-                "workload": ("procedural atrium (Sponza stand-in), %d triangles, textured GGX" % scene.desc.numTriangles)
-                if args.scene == "atrium" else "Cornell box, 32 triangles, Lambertian",
+                "workload": workload,
                 "resolution": [W, H], "max_depth": D, "spp_per_step": 1, "mat_index": mat,
                 "parallelism": "tile%d" % world,
                 "tiling": {"stripe_rows": pkg.tiling.stripe_rows(H, world), "rows_this_rank": n_pix_tile // W,
@@ -454,7 +490,9 @@ def main():
                 "bvh": {"nodes": info.numNodes, "node_bytes": info.nodeBytes, "tri_bytes": info.triBytes,
                         "references": info.numReferences, "max_depth": info.maxDepth, "sah_cost": round(info.sahCost, 2)},
                 "visits_per_ray": {"shadow_nodes": round(n_int_s, 2), "shadow_tris": round(n_tri_s, 2),
-                                   "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2)},
+                                   "closest_nodes": round(n_int_c, 2), "closest_tris": round(n_tri_c, 2),
+                                   "closest_alpha_tests": round(stat["alphaTestsClosest"] / n_closest, 3),
+                                   "shadow_alpha_tests": round(stat["alphaTestsShadow"] / n_shadow, 3)},
                 "frames_in_flight": inflight,
                 "stage_timing": "HIP events over %d untimed frames run alone on rank 0's tile before the timed region "
                                 "(timed frames overlap each other)" % stage_frames,
@@ -479,6 +517,9 @@ def main():
                           "achieved": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 1) if frame_ms > 0 else 0.0,
                           "frac": round(frame_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms > 0 else 0.0,
                           "traffic": sum(k["traffic"] for k in kernels.values() if k.get("traffic")) or None},
+                # True: the PMC counts behind traffic / fractions were collected on exactly these sources; False: the
+                # committed counts belong to another build and are not quoted; None: no counts for this workload
+                "pmc_build_match": pmc_match,
                 "node_bytes_costed": SURVEY_NODE_BYTES, "node_bytes_fetched": info.nodeBytes,
                 "note": "achieved / frac = ALGORITHMIC bytes (SURVEY.md §8d: no cache credit, an interior-node visit costed at 64 B) / "
                         "measured time against HBM peak: the contract's figure; it exceeds the HBM-side traffic (PMC) because the BVH "
@@ -524,7 +565,7 @@ def main():
                 out.update(parity)
             guarded("cpu_baseline", cpu)
     R.close()
-    if rank == 0 and world == 1 and dist is None and args.other_configs and args.scene == "atrium" and (W, H, D) == (1920, 1080, 8):
+    if rank == 0 and world == 1 and dist is None and args.other_configs and scene_name == "atrium" and (W, H, D) == (1920, 1080, 8):
         others = []
 
         def other(name, make, w, h, d, m):
@@ -537,6 +578,19 @@ def main():
             guarded(name.split(":")[0], run)
 
         other("BASELINE configs[1]: Cornell box 1920x1080 depth 8, Lambertian", pkg.Scene.cornell, 1920, 1080, 8, 1)
+        # what even tessellation hides: the same hall and triangle count with areas spread over six decades,
+        # as built by default and with opaque pre-splitting switched on (the builder's BDPT_SPLIT_BUDGET environment knob)
+        other("stress: atrium with heavy-tailed triangle areas (two-triangle walls and floors), 262144 triangles, 1920x1080 depth 8",
+              lambda: pkg.Scene.atrium_uneven(1, 262144), 1920, 1080, 8, 0)
+
+        def split_on():
+            os.environ["BDPT_SPLIT_BUDGET"] = "1"
+            return pkg.Scene.atrium_uneven(1, 262144)
+        try:
+            other("stress+split: the same scene built with BDPT_SPLIT_BUDGET=1 (one extra reference per opaque triangle on average)",
+                  split_on, 1920, 1080, 8, 0)
+        finally:
+            os.environ.pop("BDPT_SPLIT_BUDGET", None)
         other("BASELINE configs[3] shape on ONE GPU: 2.8 M triangles (atrium generator, Bistro stand-in) 3840x2160 depth 12",
               lambda: pkg.Scene.atrium(1, 2800000), 3840, 2160, 12, 0)
         other("BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "

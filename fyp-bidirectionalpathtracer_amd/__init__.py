@@ -12,7 +12,7 @@ import ctypes as C
 from . import abi, tiling
 from .abi import (Camera, Counters, GBuffer, GBufferParams, Params, SceneDesc, Stripes, Tile, TileInfo, load_library)
 
-__all__ = ["abi", "tiling", "Scene", "Context", "FramePipeline", "load_library"]
+__all__ = ["abi", "tiling", "Scene", "Context", "FramePipeline", "load_library", "source_hash"]
 
 # Channel names of the reference's ResourceManager (BDPTPass.cpp:27-29, LightProbeGBufferPass.cpp:46-51)
 GBUFFER_CHANNELS = ("WorldPosition", "WorldNormal", "MaterialDiffuse", "MaterialSpecRough", "MaterialExtraParams",
@@ -22,6 +22,23 @@ OUTPUT_CHANNEL = "PipelineOutput"  # ResourceManager::kOutputChannel, SharedUtil
 
 class BdptError(RuntimeError):
     pass
+
+
+def source_hash():
+    """SHA-256 over the sources libbdpt_amd.so is built from (csrc/*.{hip,hpp,h,cpp}, the host files linked into it and
+    the Makefile): ties hardware-counter files (profiles/<round>/roofline_pmc.json) to the build they were measured on."""
+    import glob
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(here, "csrc", "*.h")) + glob.glob(os.path.join(here, "csrc", "*.cpp")) +
+                   [os.path.join(here, "csrc", "Makefile")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 class Scene:
@@ -43,6 +60,11 @@ class Scene:
     @classmethod
     def atrium(cls, seed=1, target_triangles=262144):
         return cls(load_library().bdpt_scene_create_atrium(seed, target_triangles))
+
+    @classmethod
+    def atrium_uneven(cls, seed=1, target_triangles=262144):
+        """The atrium with heavy-tailed triangle areas (two-triangle walls and floors beside finely tessellated ornaments)."""
+        return cls(load_library().bdpt_scene_create_atrium_uneven(seed, target_triangles))
 
     @classmethod
     def courtyard(cls, seed=1, target_triangles=262144, foliage_fraction=0.5):

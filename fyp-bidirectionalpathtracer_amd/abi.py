@@ -103,7 +103,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect",
         "nodeVisitsClosest", "triTestsClosest", "nodeVisitsShadow", "triTestsShadow", "pixelsValid",
-        "splatsLanded", "raysConnectLazy")]
+        "splatsLanded", "raysConnectLazy", "alphaTestsClosest", "alphaTestsShadow")]
 
     def total_rays(self):
         return (self.raysPrimary + self.raysEyeExtend + self.raysLightExtend + self.raysNee + self.raysSplat +
@@ -172,6 +172,7 @@ PROTOTYPES = {
     "bdpt_test_bsdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "bdpt_scene_create_cornell": (C.c_void_p, []),
     "bdpt_scene_create_atrium": (C.c_void_p, [C.c_uint32, C.c_uint32]),
+    "bdpt_scene_create_atrium_uneven": (C.c_void_p, [C.c_uint32, C.c_uint32]),
     "bdpt_scene_create_courtyard": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
     "bdpt_scene_create_soup": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
     "bdpt_scene_load": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_uint32]),

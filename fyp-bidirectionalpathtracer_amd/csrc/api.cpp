@@ -1041,11 +1041,16 @@ int bdpt_get_counters(bdpt_ctx* c, bdpt_counters* out) {
   HIPCHK(c, hipStreamSynchronize(c->lastStream));
   DevCounters h;
   HIPCHK(c, hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-  static_assert(sizeof(bdpt_counters) == 13 * sizeof(uint64_t), "counter fields");
+  static_assert(sizeof(bdpt_counters) == 15 * sizeof(uint64_t), "counter fields");
   uint64_t* o = reinterpret_cast<uint64_t*>(out);
   for (int f = 0; f < 13; f++) {
     o[f] = 0;
     for (uint32_t sh = 0; sh < kCounterShards; sh++) o[f] += h.v[sh][f];
+  }
+  out->alphaTestsClosest = out->alphaTestsShadow = 0;
+  for (uint32_t sh = 0; sh < kCounterShards; sh++) {
+    out->alphaTestsClosest += h.v[sh][C_ALPHA_CLOSEST];
+    out->alphaTestsShadow += h.v[sh][C_ALPHA_SHADOW];
   }
   out->raysPrimary = (uint64_t)c->P.Np;  // GBufferRayGen traces exactly one ray per tile pixel
   return BDPT_OK;

@@ -261,11 +261,12 @@ BD bool triCommit(TravState& T, const TriCand& k) {
   }
   return false;
 }
-template <int MODE>
-BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, bool& last) {
+template <int MODE, bool COUNT>
+BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, bool& last, uint32_t& nAlpha) {
   const TriCand k = triGeom<MODE>(T, a, b, c);
   last = k.last;
   if (!k.ok) return false;
+  if (COUNT && (k.flags & 1u) && (MODE == 2 || k.t <= T.best.t)) nAlpha++;
   // any-hit shader: IgnoreHit().  A closest-hit candidate beyond the hit already held cannot be committed whatever the
   // test says (DXR does not report such candidates either), so the test and its fetches are skipped for it.
   if ((k.flags & 1u) && (MODE == 2 || k.t <= T.best.t) && alphaTestFails(S, k.aux, k.u, k.v)) return false;
@@ -273,8 +274,9 @@ BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b,
 }
 
 // All triangles of the leaf in T.cur; returns true when an any-hit query is finished.
+// (COUNT: nTris / nAlpha tally triangle tests and any-hit alpha tests: the "any-hit rate" of BASELINE.md section 3 row 5)
 template <int MODE, bool COUNT>
-BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
+BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris, uint32_t& nAlpha) {
   // The first TWO records are fetched together (six loads in flight): half of the leaves hold two triangles and their
   // second test would otherwise wait for a second, dependent fetch; a one-triangle leaf fetches the record behind it
   // for nothing (the array ends with a pad record).  Likewise the alpha tests of the two: both records, then both texel
@@ -295,6 +297,7 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   // (closest hit: a candidate beyond the hit already held cannot be committed whatever its alpha test says: not run)
   const bool n0 = k0.ok && (k0.flags & 1u) && (MODE == 2 || k0.t <= T.best.t);
   const bool n1 = k1.ok && (k1.flags & 1u) && (MODE == 2 || k1.t <= T.best.t);
+  if (COUNT) nAlpha += (n0 ? 1u : 0u) + (n1 ? 1u : 0u);
   if (n0 || n1) {
     bool f0 = false, f1 = false;
     alphaTestFails2(S, n0, k0.aux, k0.u, k0.v, n1, k1.aux, k1.u, k1.v, f0, f1);
@@ -308,7 +311,7 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
   while (!last) {  // leaves of more than two triangles (builder knob BDPT_LEAF_MAX)
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) nTris++;
-    if (triStep<MODE>(S, T, a, b, c, last)) return true;
+    if (triStep<MODE, COUNT>(S, T, a, b, c, last, nAlpha)) return true;
     tp += kRecF4;
   }
   return false;
@@ -317,6 +320,7 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris) {
 // Whole query by one lane (coherent primary rays, test hooks, the few lazy rays of the gather stage).
 template <int MODE, bool COUNT>
 BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk, uint32_t& nNodes, uint32_t& nTris) {
+  uint32_t nAlpha = 0;  // (primary rays and test hooks: not tallied)
   TravState T;
   travInit(T, o, d, tmin, tmax);
   while (T.cur != kDone) {
@@ -325,7 +329,7 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
       nodeStep<(MODE != 2) ? 1 : 0>(S, T, stk);
     }
     if (T.cur == kDone) break;
-    if (leafStep<MODE, COUNT>(S, T, nTris)) break;
+    if (leafStep<MODE, COUNT>(S, T, nTris, nAlpha)) break;
     T.cur = travPop<kStackEntries>(S, T, stk);
   }
   return T.best;
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
   uint32_t rid = 0;
   TravState T;
   T.cur = kDone;
-  uint32_t nNodes = 0, nTris = 0;
+  uint32_t nNodes = 0, nTris = 0, nAlpha = 0;
   int maxSp = 0;
   // wave-uniform fetch state: current sub-queue and the chunk [chunkPos, chunkEnd) taken from it
   uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
       if (has && T.cur < 0) {
         bool finished = (T.cur == kDone);
         if (!finished) {
-          finished = leafStep<2, COUNT>(S, T, nTris);
+          finished = leafStep<2, COUNT>(S, T, nTris, nAlpha);
           if (!finished) {
             T.cur = travPop<kStackLds>(S, T, stk);
             finished = (T.cur == kDone);
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
       }
       bool finished = (T.cur == kDone);
       if (!finished) {
-        finished = leafStep<2, COUNT>(S, T, nTris);
+        finished = leafStep<2, COUNT>(S, T, nTris, nAlpha);
         if (!finished) {
           T.cur = travPop<kStackLds>(S, T, stk);
           finished = (T.cur == kDone);
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
   if (COUNT) {
     waveAddCount(counters, C_NODE_SHADOW, nNodes);
     waveAddCount(counters, C_TRI_SHADOW, nTris);
+    waveAddCount(counters, C_ALPHA_SHADOW, nAlpha);
     if (maxSp > 0) atomicMax(&counters->v[blockIdx.x % kCounterShards][C_STACK_MAX], (unsigned long long)maxSp);
   }
 }

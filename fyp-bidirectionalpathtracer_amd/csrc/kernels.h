@@ -87,7 +87,8 @@ struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; one 128-by
 enum : int {
   C_RAYS_PRIMARY = 0, C_RAYS_EYE, C_RAYS_LIGHT, C_RAYS_NEE, C_RAYS_SPLAT, C_RAYS_CONNECT,
   C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS, C_RAYS_LAZY,
-  C_STACK_MAX  // deepest any-hit traversal stack seen (a maximum, not a sum; with BDPT_PARAM_COUNTERS)
+  C_STACK_MAX,  // deepest any-hit traversal stack seen (a maximum, not a sum; with BDPT_PARAM_COUNTERS)
+  C_ALPHA_CLOSEST, C_ALPHA_SHADOW  // any-hit alpha tests run by closest-hit / any-hit queries (with BDPT_PARAM_COUNTERS)
 };
 
 // Number of connection pairs the reference defines for depth D (cameraLength <= totalLength,

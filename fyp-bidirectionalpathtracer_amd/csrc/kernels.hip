@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
   TravState T;
   travInit(T, mk(0), mk(0), F.p.minT, 1.0e38f);
   T.cur = kDone;
-  uint32_t nNodes = 0, nTris = 0;
+  uint32_t nNodes = 0, nTris = 0, nAlpha = 0;
   uint32_t nEye = 0, nLight = 0, nParked = 0, nReady = 0;  // wave-uniform
   uint32_t vq = firstV + blockIdx.x % numV, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = BDPT_WALK_CHUNK;
   bool exhausted = false;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
         if (trav && T.cur < 0) {
           finished = (T.cur == kDone);
           if (!finished) {
-            finished = leafStep<0, COUNT>(S, T, nTris);
+            finished = leafStep<0, COUNT>(S, T, nTris, nAlpha);
             if (!finished) {
               T.cur = travPop<kWalkStackLds>(S, T, stk);
               finished = (T.cur == kDone);
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
       }
       finished = (T.cur == kDone);
       if (!finished) {
-        finished = leafStep<0, COUNT>(S, T, nTris);
+        finished = leafStep<0, COUNT>(S, T, nTris, nAlpha);
         if (!finished) {
           T.cur = travPop<kWalkStackLds>(S, T, stk);
           finished = (T.cur == kDone);
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK
   if (COUNT) {
     waveAddCount(F.counters, C_NODE_CLOSEST, nNodes);
     waveAddCount(F.counters, C_TRI_CLOSEST, nTris);
+    waveAddCount(F.counters, C_ALPHA_CLOSEST, nAlpha);
   }
 }
 

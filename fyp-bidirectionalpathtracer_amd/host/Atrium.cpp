@@ -133,10 +133,14 @@ struct Builder {
   Scene& s;
   float q;  // tessellation scale
   uint32_t seed;
+  bool uneven = false;  // heavy-tailed variant: the large flat surfaces are two triangles each, the budget goes to the ornaments
   int seg(float n) const {
     int v = (int)(n * q + 0.5f);
     return v < 2 ? 2 : v;
   }
+  // segments of a LARGE surface (floors, slabs, walls): one in the uneven variant — a real asset's walls are not
+  // tessellated to the density of its drapes, and triangle areas spanning decades are what strains a SAH tree
+  int big(float n) const { return uneven ? 1 : seg(n); }
 };
 
 enum Mat : uint32_t { M_FLOOR = 0, M_BRICK, M_STONE, M_DRAPE, M_GOLD, M_LATTICE, M_RELIEF, M_GLOSS, M_LAMP, M_PEBBLE, M_LEAF };
@@ -145,32 +149,32 @@ void buildGeometry(Builder& b) {
   Scene& s = b.s;
   const float X0 = -15, X1 = 15, Z0 = -6, Z1 = 6, YG = 5.0f, YT = 11.0f, ZG = 3.5f;
   // ground floor (gentle undulation so it is not two triangles)
-  addParametric(s, b.seg(96), b.seg(40),
-                [&](float u, float v) { return float3{X0 + (X1 - X0) * u, 0.02f * fbm(u * 40, v * 16, b.seed + 11), Z1 - (Z1 - Z0) * v}; },
+  addParametric(s, b.big(96), b.big(40),
+                [&](float u, float v) { return float3{X0 + (X1 - X0) * u, b.uneven ? 0.0f : 0.02f * fbm(u * 40, v * 16, b.seed + 11), Z1 - (Z1 - Z0) * v}; },
                 M_FLOOR, 15, 6, false);
   // gallery floors (top faces up, underside faces down) on both sides
   for (int side = 0; side < 2; side++) {
     float za = side ? ZG : Z0, zb = side ? Z1 : -ZG;
-    addParametric(s, b.seg(60), b.seg(6), [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YG, zb - (zb - za) * v}; }, M_FLOOR, 15,
+    addParametric(s, b.big(60), b.big(6), [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YG, zb - (zb - za) * v}; }, M_FLOOR, 15,
                   1.5f, false);
-    addParametric(s, b.seg(60), b.seg(6), [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YG - 0.3f, za + (zb - za) * v}; },
+    addParametric(s, b.big(60), b.big(6), [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YG - 0.3f, za + (zb - za) * v}; },
                   M_STONE, 15, 1.5f, false);
     // gallery edge fascia facing the nave
     float ze = side ? ZG : -ZG;
     float sgn = side ? -1.0f : 1.0f;
-    addParametric(s, b.seg(60), 2, [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YG - 0.3f + 0.3f * v, ze}; }, M_STONE, 15, 0.2f,
+    addParametric(s, b.big(60), b.uneven ? 1 : 2, [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YG - 0.3f + 0.3f * v, ze}; }, M_STONE, 15, 0.2f,
                   sgn < 0);
     // roof slab over the gallery
-    addParametric(s, b.seg(40), b.seg(4), [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YT, za + (zb - za) * v}; }, M_STONE, 15,
+    addParametric(s, b.big(40), b.big(4), [&](float u, float v) { return float3{X0 + (X1 - X0) * u, YT, za + (zb - za) * v}; }, M_STONE, 15,
                   1.5f, false);
   }
   // side walls (relief: displaced bricks, normal mapped), facing inward
   for (int side = 0; side < 2; side++) {
     float z = side ? Z1 : Z0;
     float sgn = side ? -1.0f : 1.0f;
-    addParametric(s, b.seg(150), b.seg(56),
+    addParametric(s, b.big(150), b.big(56),
                   [&](float u, float v) {
-                    float d = 0.06f * fbm(u * 60, v * 22, b.seed + 21 + (uint32_t)side);
+                    float d = b.uneven ? 0.0f : 0.06f * fbm(u * 60, v * 22, b.seed + 21 + (uint32_t)side);
                     return float3{X0 + (X1 - X0) * u, YT * v, z + sgn * d};
                   },
                   M_BRICK, 15, 5.5f, side == 1);
@@ -179,9 +183,9 @@ void buildGeometry(Builder& b) {
   for (int side = 0; side < 2; side++) {
     float x = side ? X1 : X0;
     float sgn = side ? -1.0f : 1.0f;
-    addParametric(s, b.seg(72), b.seg(64),
+    addParametric(s, b.big(72), b.big(64),
                   [&](float u, float v) {
-                    float d = 0.25f * fbm(u * 9, v * 8, b.seed + 31 + (uint32_t)side) + 0.05f * fbm(u * 50, v * 44, b.seed + 33);
+                    float d = b.uneven ? 0.0f : 0.25f * fbm(u * 9, v * 8, b.seed + 31 + (uint32_t)side) + 0.05f * fbm(u * 50, v * 44, b.seed + 33);
                     return float3{x + sgn * d, YT * v, Z0 + (Z1 - Z0) * u};
                   },
                   M_RELIEF, 6, 5.5f, side == 0);
@@ -503,10 +507,16 @@ void addLeafMaterial(Scene& s, uint32_t seed) {
 
 }  // namespace
 
-Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles) { return createAtrium(seed, targetTriangles, 0.0f); }
+Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles) { return createAtrium(seed, targetTriangles, 0.0f, false); }
+Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, float foliageFraction) {
+  return createAtrium(seed, targetTriangles, foliageFraction, false);
+}
 
 // foliageFraction > 0: the courtyard variant — that share of the triangles are alpha-masked leaf cards.
-Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, float foliageFraction) {
+// uneven: the heavy-tailed variant — floors, slabs and walls are two flat triangles each (hundreds of square metres)
+// and the whole triangle budget goes to columns, drapes, urns and ornaments (square millimetres): the same hall, the
+// same count, triangle areas spread over six decades, as in assets modelled by hand.
+Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, float foliageFraction, bool uneven) {
   if (targetTriangles < 4096) targetTriangles = 4096;
   if (!(foliageFraction > 0.0f)) foliageFraction = 0.0f;
   if (foliageFraction > 0.9f) foliageFraction = 0.9f;
@@ -515,10 +525,21 @@ Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, fl
   targetTriangles -= foliage;
   // find the largest tessellation scale whose triangle count stays at or below the target
   float lo = 0.02f, hi = 8.0f;
+  if (uneven) {  // the ornaments take the whole budget: bracket the scale by doubling first (a probe costs scale^2)
+    hi = 1.0f;
+    for (int it = 0; it < 8; it++) {
+      SharedPtr probe = create();
+      Builder b{*probe, hi, seed, true};
+      buildGeometry(b);
+      if (probe->getTriangleCount() > targetTriangles) break;
+      lo = hi;
+      hi *= 2.0f;
+    }
+  }
   for (int it = 0; it < 22; it++) {
     float mid = 0.5f * (lo + hi);
     SharedPtr probe = create();
-    Builder b{*probe, mid, seed};
+    Builder b{*probe, mid, seed, uneven};
     buildGeometry(b);
     if (probe->getTriangleCount() <= targetTriangles)
       lo = mid;
@@ -526,7 +547,7 @@ Scene::SharedPtr Scene::createAtrium(uint32_t seed, uint32_t targetTriangles, fl
       hi = mid;
   }
   SharedPtr s = create();
-  Builder b{*s, lo, seed};
+  Builder b{*s, lo, seed, uneven};
   buildGeometry(b);
   if (s->getTriangleCount() < targetTriangles) addPebbles(*s, targetTriangles - s->getTriangleCount(), seed);
   if (foliage) addFoliage(*s, total > s->getTriangleCount() ? total - s->getTriangleCount() : 0u, seed);  // (never below zero: the base may overshoot a small target)

@@ -311,6 +311,11 @@ bdpt_scene* bdpt_scene_create_courtyard(uint32_t seed, uint32_t targetTriangles,
   h->scene = bdpt::Scene::createAtrium(seed, targetTriangles, foliageFraction);
   return h;
 }
+bdpt_scene* bdpt_scene_create_atrium_uneven(uint32_t seed, uint32_t targetTriangles) {
+  bdpt_scene* h = new bdpt_scene();
+  h->scene = bdpt::Scene::createAtrium(seed, targetTriangles, 0.0f, true);
+  return h;
+}
 bdpt_scene* bdpt_scene_create_soup(uint32_t seed, uint32_t numTriangles, float maxEdge) {
   bdpt_scene* h = new bdpt_scene();
   h->scene = bdpt::Scene::createTriangleSoup(seed, numTriangles, maxEdge);

@@ -65,6 +65,7 @@ class Scene {
   static SharedPtr createCornellBox();
   static SharedPtr createAtrium(uint32_t seed, uint32_t targetTriangles);
   static SharedPtr createAtrium(uint32_t seed, uint32_t targetTriangles, float foliageFraction);
+  static SharedPtr createAtrium(uint32_t seed, uint32_t targetTriangles, float foliageFraction, bool uneven);  // Atrium.cpp: heavy-tailed triangle areas
   static SharedPtr createTriangleSoup(uint32_t seed, uint32_t numTriangles, float maxEdge);
   // `.fscene` (Falcor scene JSON) or `.obj` (+ .mtl, PPM/PGM/TGA textures); the role of
   // RtScene::loadFromFile behind SharedUtils/SceneLoaderWrapper.cpp:56-60.  nullptr + *error on failure.

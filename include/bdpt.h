@@ -284,6 +284,8 @@ typedef struct bdpt_counters {
   uint64_t pixelsValid;       /* G-buffer pixels with geometry */
   uint64_t splatsLanded;
   uint64_t raysConnectLazy;   /* subset of raysConnect traced by the gather stage for zero-valued pairs */
+  uint64_t alphaTestsClosest; /* any-hit alpha tests (alphaTestFails, BDPTUtils.hlsli:115-127) run by closest-hit queries, */
+  uint64_t alphaTestsShadow;  /* ... and by any-hit queries; with BDPT_PARAM_COUNTERS (the G-buffer ray is not tallied) */
 } bdpt_counters;
 
 /* The environment secondary misses see (BDPT_PARAM_ENV_ON_MISS): an RGBA32F lat-long map (device pointer for

@@ -35,6 +35,13 @@ bdpt_scene* bdpt_scene_create_atrium(uint32_t seed, uint32_t targetTriangles);
  * where most rays run the any-hit alpha test (BDPTUtils.hlsli:115-127) several times. */
 bdpt_scene* bdpt_scene_create_courtyard(uint32_t seed, uint32_t targetTriangles, float foliageFraction);
 
+/* The atrium with heavy-tailed triangle areas: floors, slabs and walls are two flat triangles each (up to 165 m^2),
+ * the whole budget of `targetTriangles` goes to columns, drapes, urns and ornaments (down to square millimetres) —
+ * the same hall and the same count as bdpt_scene_create_atrium, areas spread over six decades as in hand-modelled
+ * assets (real Sponza's walls are not tessellated like its drapes).  What an evenly tessellated stand-in hides:
+ * large triangles overlapping many small ones in the SAH tree. */
+bdpt_scene* bdpt_scene_create_atrium_uneven(uint32_t seed, uint32_t targetTriangles);
+
 /* Uniform random triangle soup in the unit cube (intersection KATs). */
 bdpt_scene* bdpt_scene_create_soup(uint32_t seed, uint32_t numTriangles, float maxEdge);
 

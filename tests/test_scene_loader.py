@@ -268,3 +268,114 @@ def test_loaded_scene_frame_matches_oracle(pkg, ob, courtyard):
         assert np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)), f"{(gpu != ref).any(axis=-1).sum()} pixels differ"
         orc.close()
         pipe.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# tools/export_obj.py: a scene of the package written as .fscene + OBJ/MTL + PNG and read back
+# ---------------------------------------------------------------------------------------------
+def _export_tool():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("export_obj", os.path.join(root, "tools", "export_obj.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def exported_atrium(pkg, tmp_path_factory):
+    ex = _export_tool()
+    src = pkg.Scene.atrium(2, 24000)
+    d = tmp_path_factory.mktemp("exported")
+    path = ex.export_scene(pkg, src, str(d))
+    back = pkg.Scene.load(path)
+    yield ex, src, back, str(d)
+    back.close()
+    src.close()
+
+
+def test_exported_scene_loads_back(pkg, exported_atrium):
+    """Export the atrium, load the files through bdpt_scene_load: the geometry comes back bit for bit (positions and
+    triangle order per shading model), normals / texture coordinates to the last place the importer's own rules leave
+    (re-normalisation, the FlipUVs 1 - v), materials as the reference's import rules make them (constants, textures,
+    double-sided, alpha mask; the roughness TEXTURE is dropped as the reference's importer drops map_Ks), lights and
+    camera to float precision — and the loaded scene written out and loaded once more is the same scene (positions, indices, materials and texels bit for bit; normals and v to the last place)."""
+    ex, src, back, outdir = exported_atrium
+    a, b = ex.scene_arrays(src.desc), ex.scene_arrays(back.desc)
+    assert src.desc.numTriangles == back.desc.numTriangles and len(b["lights"]) == len(a["lights"]) == 3
+    sg = np.array([((a["materials"][m].flags & 7) == 2) for m in a["tri_material"]], bool)
+    order = np.concatenate([np.flatnonzero(~sg), np.flatnonzero(sg)])  # the two OBJ models: MetalRough first, then SpecGloss
+    assert sg.any() and (~sg).any()
+    ca, cb = a["positions"][a["indices"][order]], b["positions"][b["indices"]]
+    assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))        # triangle corners: bit for bit, same order
+    na, nb = a["normals"][a["indices"][order]], b["normals"][b["indices"]]
+    assert np.abs(na - nb).max() <= 2.4e-7                               # re-normalised by the importer: 1-2 ulp
+    ua, ub = a["texcoords"][a["indices"][order]][..., :2], b["texcoords"][b["indices"]][..., :2]
+    assert np.array_equal(ua[..., 0].view(np.uint32), ub[..., 0].view(np.uint32)) and np.abs(ua[..., 1] - ub[..., 1]).max() <= 1.2e-7 * 6
+    # materials: each model brings the ones it uses, MetalRough model first
+    used = [i for i in range(len(a["materials"])) if i in set(a["tri_material"].tolist())]
+    new_index = {i: k for k, i in enumerate([i for i in used if (a["materials"][i].flags & 7) != 2] + [i for i in used if (a["materials"][i].flags & 7) == 2])}
+    assert len(b["materials"]) == len(used)
+    assert np.array_equal(np.array([new_index[int(m)] for m in a["tri_material"][order]], np.uint32), b["tri_material"])
+    for i in used:
+        ma, mb = a["materials"][i], b["materials"][new_index[i]]
+        fa, fb = _flags(pkg.abi, ma.flags), _flags(pkg.abi, mb.flags)
+        assert list(ma.baseColor) == list(mb.baseColor) and list(ma.specular) == list(mb.specular) and ma.IoR == mb.IoR, i
+        assert list(ma.emissive) == list(mb.emissive)
+        assert (fa["model"], fa["dbl"], fa["alpha"], fa["nmap"], fa["dif"]) == (fb["model"], fb["dbl"], fb["alpha"], fb["nmap"], fb["dif"]), i
+        assert (ma.texBaseColor >= 0) == (mb.texBaseColor >= 0) and (ma.texNormal >= 0) == (mb.texNormal >= 0)
+        assert mb.texSpecular == -1                                      # what the reference's importer leaves of map_Ks
+        if ma.texBaseColor >= 0:
+            ta, tb = a["textures"][ma.texBaseColor], b["textures"][mb.texBaseColor]
+            keep = 4 if fa["alpha"] == 1 else 3
+            assert np.array_equal(ta["rgba"][..., :keep], tb["rgba"][..., :keep]) and tb["srgb"] == 1
+    for la, lb in zip(a["lights"], b["lights"]):
+        assert la.type == lb.type and list(la.posW) == list(lb.posW) and list(la.intensity) == list(lb.intensity)
+        assert abs(la.openingAngle - lb.openingAngle) < 1e-6 and abs(la.cosOpeningAngle - lb.cosOpeningAngle) < 1e-6
+        assert abs(la.penumbraAngle - lb.penumbraAngle) < 1e-6 and np.allclose(list(la.dirW), list(lb.dirW), atol=1e-7)
+    c0, c1 = src.camera(16 / 9), back.camera(16 / 9)
+    for f in ("posW", "cameraU", "cameraV", "cameraW"):
+        assert np.allclose(list(getattr(c0, f)), list(getattr(c1, f)), rtol=0, atol=2e-6), f
+    # fixed point: the loaded scene written out and loaded again is the same scene, bit for bit
+    again = ex.export_scene(pkg, back, os.path.join(outdir, "again"))
+    back2 = pkg.Scene.load(again)
+    c = ex.scene_arrays(back2.desc)
+    for k in ("positions", "indices", "tri_material"):
+        assert b[k].shape == c[k].shape and np.array_equal(b[k].view(np.uint32), c[k].view(np.uint32)), k
+    for k in ("normals", "texcoords"):  # the importer re-normalises and flips v again: identical to the last place or two
+        assert b[k].shape == c[k].shape and np.abs(b[k] - c[k]).max() <= 2.4e-7 * 3, k
+    assert len(b["materials"]) == len(c["materials"]) and len(b["textures"]) == len(c["textures"])
+    for mb, mc in zip(b["materials"], c["materials"]):
+        assert bytes(mb) == bytes(mc)
+    for tb, tc in zip(b["textures"], c["textures"]):
+        assert tb["srgb"] == tc["srgb"] and np.array_equal(tb["rgba"], tc["rgba"])
+    back2.close()
+
+
+@pytest.mark.gpu
+def test_exported_scene_frame_matches_oracle_and_the_in_memory_scene(pkg, ob, exported_atrium):
+    """The exported-and-loaded atrium through the HIP path: bit-identical to the oracle on the same loaded scene (the
+    parity gate), and — where the file format can carry the scene — close to the in-memory one: the only material
+    difference is the floor's roughness texture (dropped by the reference's import rule), so with the Lambertian model
+    (which reads neither roughness nor the normal map beyond the primary hit) the two frames agree to float rounding."""
+    import torch
+    ex, src, back, _ = exported_atrium
+    W, H, D = 96, 54, 4
+    frames = {}
+    for name, sc in (("memory", src), ("loaded", back)):
+        pipe = pkg.FramePipeline(sc, W, H, max_depth=D, mat_index=1)
+        gp, p = pipe.render_frame()
+        torch.cuda.synchronize()
+        frames[name] = pipe.output.cpu().numpy().copy()
+        if name == "loaded":
+            orc = ob.OracleRender(pkg.abi, sc.desc, W, H)
+            orc.gbuffer(pipe.cam, gp)
+            orc.bdpt(pipe.cam, p)
+            orc.resolve()
+            ref = orc.image()
+            assert np.array_equal(frames[name].view(np.uint32), ref.view(np.uint32)), f"{(frames[name] != ref).any(axis=-1).sum()} pixels differ"
+            orc.close()
+        pipe.close()
+    d = frames["memory"][..., :3].astype(np.float64) - frames["loaded"][..., :3].astype(np.float64)
+    same = (frames["memory"].view(np.uint32) == frames["loaded"].view(np.uint32)).all(axis=-1).mean()
+    assert np.sqrt((d * d).mean()) < 2e-2 and same > 0.5, (float(np.sqrt((d * d).mean())), float(same))

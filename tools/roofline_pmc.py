@@ -11,7 +11,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name):
@@ -48,6 +51,8 @@ def main():
     out = {"command": "rocprofv3 --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-pass --no-other-configs "
                       "(one run per counter set; tools/prof_pmc.sh)",
            "unit": "counts per frame (all dispatches of the kernel in a frame summed); *_bytes = counter x 1024",
+           # the build the counts belong to: bench.py drops them (pmc_build_match false) when its sources differ
+           "source_hash": __import__("__graft_entry__").load_package().source_hash(),
            "fetch_factor": {"walk_kernel": 2.0, "trace_shadow_kernel": 2.0, "gen_kernels": 2.0, "per_pixel_kernels": 2.0},
            "kernels": {}}
     for k in sorted(kernels):

@@ -98,14 +98,14 @@ void hostParallelFor(size_t n, const F& f) {
     f((size_t)0, n);
     return;
   }
-  std::vector<std::thread> pool;
+  WorkerScope pool;
   const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
   for (int t = 1; t < threads; t++) {
     const size_t a = std::min(n, chunk * (size_t)t), b = std::min(n, a + chunk);
-    if (a < b) pool.emplace_back([&f, a, b] { f(a, b); });
+    if (a < b) pool.spawn([&f, a, b] { f(a, b); });
   }
   f((size_t)0, std::min(n, chunk));
-  for (std::thread& th : pool) th.join();
+  pool.join();
 }
 
 bool fail(bdpt_ctx* c, const std::string& m) {
@@ -269,7 +269,7 @@ void bdpt_destroy(bdpt_ctx* c) {
 
 const char* bdpt_last_error(const bdpt_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
+static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   if (!c || !d) return BDPT_E_INVALID;
   if (!d->positions || !d->normals || !d->indices || !d->triMaterial || !d->materials || !d->numMaterials) {
     fail(c, "scene: positions, normals, indices, triMaterial and materials are required");
@@ -465,6 +465,20 @@ int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->haveScene = true;
   return BDPT_OK;
 }
+// Nothing thrown while the scene is copied and its acceleration structure built — on this thread or on a builder
+// worker (bvh.h WorkerScope) — crosses the C boundary: the large allocations of a 10 M-triangle scene fail as BDPT_E_NOMEM.
+int bdpt_set_scene(bdpt_ctx* c, const bdpt_scene_desc* d) {
+  try {
+    return setSceneImpl(c, d);
+  } catch (const std::bad_alloc&) {
+    fail(c, "scene: out of host memory while building the acceleration structure");
+    return BDPT_E_NOMEM;
+  } catch (const std::exception& e) {
+    fail(c, std::string("scene: ") + e.what());
+    return BDPT_E_INVALID;
+  }
+}
+
 
 int bdpt_get_bvh_info(const bdpt_ctx* c, bdpt_bvh_info* out) {
   if (!c || !out) return BDPT_E_INVALID;

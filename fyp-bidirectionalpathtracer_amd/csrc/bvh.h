@@ -6,7 +6,52 @@
 #include <cstdint>
 #include <vector>
 
+#include <cstdlib>
+#include <exception>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
 namespace bdpt {
+// Worker threads of the host-side builder.  An exception thrown on a worker (std::bad_alloc from the large per-chunk
+// allocations of a 10 M-triangle scene, above all) must not reach std::terminate: it is kept, every thread is joined,
+// and join() rethrows it on the caller's thread, where bdpt_set_scene turns it into BDPT_E_NOMEM.  Leaving the scope
+// early (the caller's own chunk threw) joins the threads as well.
+class WorkerScope {
+ public:
+  template <class F>
+  void spawn(F f) {
+    mPool.emplace_back([this, f] {
+      try {
+        if (std::getenv("BDPT_TEST_THROW_IN_WORKER")) throw std::bad_alloc();  // test hook: tests/test_bvh_builder.py
+        f();
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mLock);
+        if (!mError) mError = std::current_exception();
+      }
+    });
+  }
+  void join() {
+    for (std::thread& t : mPool) t.join();
+    mPool.clear();
+    if (mError) {
+      std::exception_ptr e = mError;
+      mError = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  ~WorkerScope() {
+    for (std::thread& t : mPool)
+      if (t.joinable()) t.join();
+  }
+
+ private:
+  std::vector<std::thread> mPool;
+  std::exception_ptr mError;
+  std::mutex mLock;
+};
+
 
 // 64-byte four-child node with child boxes quantised to 8 bits per plane relative to the node's
 // own box: plane = origin[axis] + q * scale[axis], scale a power of two.  Quantisation rounds outward, so a

@@ -105,14 +105,14 @@ void parallelFor(size_t n, int threads, const F& f) {
     f((size_t)0, n, 0);
     return;
   }
-  std::vector<std::thread> pool;
+  WorkerScope pool;
   const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
   for (int t = 1; t < threads; t++) {
     const size_t a = std::min(n, chunk * (size_t)t), b = std::min(n, a + chunk);
-    if (a < b) pool.emplace_back([&f, a, b, t] { f(a, b, t); });
+    if (a < b) pool.spawn([&f, a, b, t] { f(a, b, t); });
   }
   f((size_t)0, std::min(n, chunk), 0);
-  for (std::thread& th : pool) th.join();
+  pool.join();
 }
 
 // [0, n) in chunks of `chunk` items handed out through an atomic counter (work per item may differ by orders of
@@ -133,10 +133,10 @@ void parallelChunks(size_t n, int threads, size_t chunk, const F& f) {
       f(c, c * chunk, std::min(n, (c + 1) * chunk));
     }
   };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  WorkerScope pool;
+  for (int t = 1; t < threads; t++) pool.spawn(worker);
   worker();
-  for (std::thread& th : pool) th.join();
+  pool.join();
 }
 
 struct BuildData {
@@ -869,10 +869,12 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         buildSubtree(B, L, 0, 0, 1, nullptr);
       }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
-    worker();
-    for (std::thread& th : pool) th.join();
+    {
+      WorkerScope pool;
+      for (int t = 1; t < threads; t++) pool.spawn(worker);
+      worker();
+      pool.join();
+    }
     lap("subtrees");
     // the lists are appended in the order of `deferred` (children stay after parents); every list knows where it
     // lands, so the copies run side by side

@@ -21,14 +21,14 @@ void hostFor(size_t n, int threads, const F& f) {
     f((size_t)0, n);
     return;
   }
-  std::vector<std::thread> pool;
+  WorkerScope pool;  // bvh.h: a worker's exception is rethrown here, after every thread has been joined
   const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
   for (int t = 1; t < threads; t++) {
     const size_t a = std::min(n, chunk * (size_t)t), b = std::min(n, a + chunk);
-    if (a < b) pool.emplace_back([&f, a, b] { f(a, b); });
+    if (a < b) pool.spawn([&f, a, b] { f(a, b); });
   }
   f((size_t)0, std::min(n, chunk));
-  for (std::thread& th : pool) th.join();
+  pool.join();
 }
 
 }  // namespace
@@ -226,7 +226,7 @@ using namespace bdpt;
 extern "C" {
 
 // ---- host-only checks of the builder (no GPU, no context) ------------------------------------------------------
-int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg, uint32_t msgCap) {
+int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg, uint32_t msgCap) try {
   auto say = [&](const std::string& m) {
     if (msg && msgCap) {
       std::snprintf(msg, msgCap, "%s", m.c_str());
@@ -421,9 +421,13 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* d, bdpt_bvh_info* out, char* msg
   for (size_t i = used.size() - kBvhPadRecs; i < used.size(); i++)
     if (used[i]) return say("a pad record is referenced");
   return BDPT_OK;
+} catch (const std::bad_alloc&) {
+  return BDPT_E_NOMEM;  // (also when a worker thread ran out of memory: bvh.h WorkerScope)
+} catch (...) {
+  return BDPT_E_INVALID;
 }
 
-int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info) {
+int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info) try {
   if (!d || !out_hash || !d->positions || !d->indices) return BDPT_E_INVALID;
   // a scene with materials goes through everything bdpt_set_scene does (flags, alpha classification, pre-splitting)
   SceneBvh sb;
@@ -461,6 +465,10 @@ int bdpt_bvh_build_hash(const bdpt_scene_desc* d, int threads, uint64_t* out_has
     out_info->numAlwaysPass = sb.numAlwaysPass;
   }
   return BDPT_OK;
+} catch (const std::bad_alloc&) {
+  return BDPT_E_NOMEM;  // (also when a worker thread ran out of memory: bvh.h WorkerScope)
+} catch (...) {
+  return BDPT_E_INVALID;
 }
 
 void* bdpt_host_bvh_create(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, int classify, bdpt_bvh_info* info) {
@@ -533,13 +541,17 @@ int bdpt_host_bvh_trace(void* h, const float* rays, uint32_t n, int mode, int br
   if (threads <= 1 || n < 64) {
     work(0, n);
   } else {
-    std::vector<std::thread> pool;
+    WorkerScope pool;
     const size_t chunk = ((size_t)n + (size_t)threads - 1) / (size_t)threads;
     for (int t = 0; t < threads; t++) {
       const size_t a = std::min<size_t>(n, chunk * (size_t)t), b = std::min<size_t>(n, a + chunk);
-      if (a < b) pool.emplace_back(work, a, b);
+      if (a < b) pool.spawn([&work, a, b] { work(a, b); });
     }
-    for (std::thread& th : pool) th.join();
+    try {
+      pool.join();
+    } catch (...) {
+      return BDPT_E_NOMEM;
+    }
   }
   if (out_visits) {
     out_visits[0] = nodes.load();

@@ -932,16 +932,14 @@ bool decodeHdr(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, st
           }
         }
       }
-    } else {  // flat scanline (old-style repeat markers are not produced by any current writer and are refused)
+    } else {
+      // flat scanline.  A pixel with mantissas (1, 1, 1) is a legal dark RGBE value AND Radiance's old-style repeat
+      // marker; FreeImage 3.17's HDR reader (what the reference decodes probes with) knows only the new-style RLE and
+      // takes everything else as flat pixels, so such a pixel is a pixel here too.
       if (n - p < (size_t)W * 4) {
         err = "truncated .hdr pixel data";
         return false;
       }
-      for (uint32_t x = 0; x < W; x++)
-        if (d[p + (size_t)x * 4] == 1 && d[p + (size_t)x * 4 + 1] == 1 && d[p + (size_t)x * 4 + 2] == 1) {
-          err = "old-style run-length .hdr scanlines are not supported";
-          return false;
-        }
       std::memcpy(row.data(), d + p, (size_t)W * 4);
       p += (size_t)W * 4;
     }

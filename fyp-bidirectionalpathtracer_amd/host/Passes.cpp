@@ -247,6 +247,8 @@ bool ResourceManager::updateEnvironmentMap(const std::string& filename) {
   Texture::SharedPtr tmpEnv = Texture::create2D(128, 128, ResourceFormat::RGBA32Float);
   if (!tmpEnv) return false;
   tmpEnv->clear(filename == "" ? vec4{0.5f, 0.5f, 0.8f, 1.0f} : vec4{0.0f, 0.0f, 0.0f, 1.0f}, mpContext->getStream());
+  // the map is read by frames on other (non-blocking) streams: the fill must have landed before anyone is told about it
+  (void)hipStreamSynchronize(mpContext->getStream());
   manageTextureResource(kEnvironmentMap, tmpEnv);
   mEnvMapFilename = filename;
   return true;

@@ -4,6 +4,7 @@ dropping of pieces the alpha test can never pass must leave every query's answer
 all triangles (with the reference's per-material opacity, Falcor Raytracing/RtModel.cpp:221-224) gives.
 No GPU, no oracle: both sides are the product's own host code."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -245,3 +246,28 @@ def test_builder_edge_cases_all_dropped_no_texcoords_huge_tiling_degenerate(pkg)
         assert ((a[0] >= 0) == (b[0] >= 0)).all() and (mode == 2 or (a[0] == b[0]).all())
     lib.bdpt_host_bvh_destroy(h0)
     lib.bdpt_host_bvh_destroy(h1)
+
+
+def test_an_exception_on_a_builder_worker_thread_comes_back_as_an_error_code(pkg):
+    """The builder's worker threads make the large allocations of a big scene; std::bad_alloc thrown on one of them
+    must not reach std::terminate.  BDPT_TEST_THROW_IN_WORKER makes every worker throw (bvh.h WorkerScope): the host
+    hooks return BDPT_E_NOMEM instead of aborting the process, and a normal build works again afterwards."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "pkg = ge.load_package(); lib = pkg.load_library()\n"
+        "sc = pkg.Scene.atrium(1, 80000)\n"
+        "h = C.c_uint64(); info = pkg.abi.BvhInfo()\n"
+        "os.environ['BDPT_TEST_THROW_IN_WORKER'] = '1'\n"
+        "a = lib.bdpt_bvh_build_hash(C.byref(sc.desc), 4, C.byref(h), C.byref(info))\n"
+        "msg = C.create_string_buffer(64)\n"
+        "b = lib.bdpt_bvh_build_check(C.byref(sc.desc), C.byref(info), msg, 64)\n"
+        "del os.environ['BDPT_TEST_THROW_IN_WORKER']\n"
+        "c = lib.bdpt_bvh_build_hash(C.byref(sc.desc), 4, C.byref(h), C.byref(info))\n"
+        "print('codes', a, b, c, info.numTriangles)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]  # (an uncaught exception on a std::thread would have aborted: rc -6)
+    assert "codes -4 -4 0 80000" in r.stdout, r.stdout

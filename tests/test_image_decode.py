@@ -296,6 +296,31 @@ def test_png_jpeg_textured_scene_frame_matches_oracle(pkg, ob, tmp_path):
     scene.close()
 
 
+def test_radiance_hdr_flat_scanline_with_a_dark_111_pixel(pkg, tmp_path):
+    """A flat (uncompressed) scanline may hold a pixel whose mantissas are (1, 1, 1) — a legal dark grey and also
+    Radiance's OLD-style repeat marker.  FreeImage's reader (the reference's) knows only new-style run-length scanlines
+    and reads everything else as flat pixels, so the pixel decodes as a pixel: 1 * 2^(e - 136) per channel."""
+    lib = pkg.load_library()
+    h, w = 2, 9
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., :3] = 100
+    rgbe[..., 3] = 130
+    rgbe[0, 4] = (1, 1, 1, 121)   # the would-be marker, in the middle of a row
+    rgbe[1, 0] = (1, 1, 1, 3)     # ... and as a row's first pixel
+    path = tmp_path / "flat111.hdr"
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        f.write(rgbe.tobytes())
+    ww, hh = C.c_uint32(), C.c_uint32()
+    msg = C.create_string_buffer(256)
+    out = np.zeros((h, w, 4), np.float32)
+    assert lib.bdpt_image_load_hdr(str(path).encode(), C.byref(ww), C.byref(hh), out.ctypes.data, out.size, msg, 256) == 0, msg.value
+    want = np.ones((h, w, 4), np.float32)
+    want[..., :3] = (rgbe[..., :3].astype(np.float64) * np.ldexp(1.0, rgbe[..., 3].astype(np.int32) - 136)[..., None]).astype(np.float32)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert out[0, 4, 0] == np.float32(2.0 ** (121 - 136)) and out[1, 0, 2] == np.float32(2.0 ** (3 - 136))
+
+
 def _write_hdr(path, img, rle, bottom_up=False, magic=b"#?RADIANCE"):
     """float image [h, w, 3] -> Radiance RGBE file (what the encoder of any HDR tool writes); returns the RGBE bytes."""
     h, w, _ = img.shape

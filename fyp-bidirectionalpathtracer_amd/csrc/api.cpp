@@ -665,6 +665,10 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
     // Lazy rounds: each costs three small launches and cannot finish faster than its slowest ray, so there are few:
     // two or three rounds of kLazyBatchDiv-th shares, the last of which takes every candidate that is left.
     c->lazyRounds = np >= (1u << 18) ? 3 : 2;
+    if (const char* e = std::getenv("BDPT_LAZY_ROUNDS")) {  // measurement knob (tools/prof_tile.sh): 1 .. kMaxLazyRounds
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= kMaxLazyRounds) c->lazyRounds = v;
+    }
     // the largest batch any round can ask for: the last round of the front-loaded schedule takes what is left
     const uint32_t batch = numConnectPairs(D);
     if ((rc = devAlloc(c, c->frameAllocs, &P.misE, (size_t)(D + 1) * np))) return rc;

@@ -1411,6 +1411,15 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
              P.rayHead + (size_t)cls * kRayCursorBlock};
   uint8_t* vis = P.rayVis + P.rayBase[cls];
   uint32_t& g = G.shadow[cnt ? 1 : 0];
+#if BDPT_POOL_ANYHIT
+  if (cnt) {
+    if (!g) g = persistentGrid(trace_shadow_pool_kernel<true>, numCUs);
+    hipLaunchKernelGGL(trace_shadow_pool_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
+  } else {
+    if (!g) g = persistentGrid(trace_shadow_pool_kernel<false>, numCUs);
+    hipLaunchKernelGGL(trace_shadow_pool_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
+  }
+#else
   if (cnt) {
     if (!g) g = persistentGrid(trace_shadow_kernel<true>, numCUs);
     hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
@@ -1418,6 +1427,7 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
     if (!g) g = persistentGrid(trace_shadow_kernel<false>, numCUs);
     hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
   }
+#endif
 }
 
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st) {
@@ -1473,8 +1483,13 @@ void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode,
 void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap, const uint32_t* count, uint32_t* head, uint8_t* vis,
                            DevCounters* counters, float tmin, int numCUs, hipStream_t st) {
   RayQueue Q{planes, cap, cap, 1u, count, head};
+#if BDPT_POOL_ANYHIT
+  const uint32_t g = persistentGrid(trace_shadow_pool_kernel<true>, numCUs);
+  hipLaunchKernelGGL(trace_shadow_pool_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
+#else
   const uint32_t g = persistentGrid(trace_shadow_kernel<true>, numCUs);
   hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
+#endif
 }
 void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st) {
   if (!n) return;

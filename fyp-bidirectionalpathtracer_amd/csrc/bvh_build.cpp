@@ -85,6 +85,9 @@ struct TmpNode {
 #define BDPT_SPLIT_MAX_PER_TRI 255
 #endif
 constexpr int kBins = BDPT_SAH_BINS;
+constexpr uint32_t kStablePartitionMin = 1u << 16;  // nodes of at least this many references are partitioned stably, in parallel
+constexpr size_t kPartitionChunk = 1u << 14;
+constexpr uint32_t kCollapseGrain = 1u << 15;  // binary subtrees of at most this many nodes are collapsed to four-wide nodes by one worker each
 // Leaves hold at most two triangles.  Measured on the bench frame (profiles/README.md r2): leaves of <= 1 / 2 / 3 / 4 / 8
 // triangles give 23.6 / 19.1 / 19.5 / 20.1 / 23.0 ms per frame — a triangle test costs half a node visit and leaf runs of
 // different lengths idle lanes, while one-triangle leaves double the node array past the 4 MiB L2 of an XCD.
@@ -278,32 +281,54 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
       b = std::min(std::max(b, 0), kBins - 1);
       return b <= bestSplit;
     };
-    // Two-pointer partition (the bidirectional algorithm of std::partition, spelled out so that the permutation is
-    // this file's own definition): every element is tested exactly once, at its original position.  For large nodes
-    // the tests — a cache-missing gather per triangle — are evaluated up front by all threads; the swaps stay serial.
-    uint32_t* lo_p = order.data() + first;
-    uint32_t* hi_p = lo_p + count;
-    uint32_t* const base = lo_p;
-    std::vector<uint8_t> flags;
-    if (threads > 1 && count >= (1u << 16)) {
-      flags.resize(count);
-      parallelFor(count, threads, [&](size_t a, size_t b, int) {
-        for (size_t k = a; k < b; k++) flags[k] = goesLeft(base[k]) ? 1 : 0;
+    uint32_t* const base = order.data() + first;
+    if (count >= kStablePartitionMin) {
+      // Large nodes (the top of the tree: a few dozen nodes that together touch every reference several times): a STABLE
+      // partition — lefts in their order, then rights in theirs — in three parallel passes: the tests (a cache-missing
+      // gather per reference), a scatter into a scratch copy at offsets from per-chunk counts, the copy back.  The chunks
+      // are fixed-size, not per-thread, and the rule is chosen by the node's SIZE, so the permutation — and with it the
+      // tree — does not depend on the thread count.
+      const size_t nChunks = ((size_t)count + kPartitionChunk - 1) / kPartitionChunk;
+      std::vector<uint8_t> flags(count);
+      std::vector<uint32_t> lefts(nChunks + 1, 0), scratch(count);
+      parallelChunks(count, threads, kPartitionChunk, [&](size_t ci, size_t a, size_t b) {
+        uint32_t n = 0;
+        for (size_t k = a; k < b; k++) {
+          const uint8_t f = goesLeft(base[k]) ? 1 : 0;
+          flags[k] = f;
+          n += f;
+        }
+        lefts[ci + 1] = n;
       });
+      for (size_t ci = 0; ci < nChunks; ci++) lefts[ci + 1] += lefts[ci];
+      const uint32_t nLeft = lefts[nChunks];
+      parallelChunks(count, threads, kPartitionChunk, [&](size_t ci, size_t a, size_t b) {
+        uint32_t l = lefts[ci], r = nLeft + ((uint32_t)a - lefts[ci]);
+        for (size_t k = a; k < b; k++) {
+          if (flags[k])
+            scratch[l++] = base[k];
+          else
+            scratch[r++] = base[k];
+        }
+      });
+      parallelChunks(count, threads, kPartitionChunk, [&](size_t, size_t a, size_t b) { std::memcpy(base + a, scratch.data() + a, (b - a) * sizeof(uint32_t)); });
+      mid = nLeft;
+    } else {
+      // Two-pointer partition (the bidirectional algorithm of std::partition, spelled out so that the permutation is
+      // this file's own definition): every element is tested exactly once, at its original position.
+      uint32_t* lo_p = base;
+      uint32_t* hi_p = lo_p + count;
+      for (;;) {
+        while (lo_p != hi_p && goesLeft(*lo_p)) ++lo_p;
+        if (lo_p == hi_p) break;
+        --hi_p;
+        while (lo_p != hi_p && !goesLeft(*hi_p)) --hi_p;
+        if (lo_p == hi_p) break;
+        std::swap(*lo_p, *hi_p);
+        ++lo_p;
+      }
+      mid = (uint32_t)(lo_p - base);
     }
-    const bool pre = !flags.empty();
-    auto test = [&](const uint32_t* q) { return pre ? flags[(size_t)(q - base)] != 0 : goesLeft(*q); };
-    for (;;) {
-      while (lo_p != hi_p && test(lo_p)) ++lo_p;
-      if (lo_p == hi_p) break;
-      --hi_p;
-      while (lo_p != hi_p && !test(hi_p)) --hi_p;
-      if (lo_p == hi_p) break;
-      std::swap(*lo_p, *hi_p);  // flags stay indexed by ORIGINAL position: both elements have been tested already
-      ++lo_p;
-    }
-    auto it = order.begin() + (lo_p - order.data());
-    mid = (uint32_t)(it - (order.begin() + first));
   }
   if (mid == 0 || mid == count) {
     // median split on the widest centroid axis (also the degenerate all-equal case)
@@ -808,14 +833,18 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         splitTriangle(G, recs[t], (uint32_t)t, pc, alpha ? opt.clipper : nullptr, o);
       }
     });
-    size_t total = 0;
-    for (const RefOut& o : part) total += o.tri.size();
-    boxes.reserve(total);
-    refTri.reserve(total);
-    for (const RefOut& o : part) {
-      boxes.insert(boxes.end(), o.boxes.begin(), o.boxes.end());
-      refTri.insert(refTri.end(), o.tri.begin(), o.tri.end());
-    }
+    std::vector<size_t> at(part.size() + 1, 0);
+    for (size_t ci = 0; ci < part.size(); ci++) at[ci + 1] = at[ci] + part[ci].tri.size();
+    boxes.resize(at.back());
+    refTri.resize(at.back());
+    parallelChunks(part.size(), threads, 16, [&](size_t, size_t c0, size_t c1) {  // every chunk knows where it lands
+      for (size_t ci = c0; ci < c1; ci++) {
+        std::copy(part[ci].boxes.begin(), part[ci].boxes.end(), boxes.begin() + (long)at[ci]);
+        std::copy(part[ci].tri.begin(), part[ci].tri.end(), refTri.begin() + (long)at[ci]);
+        RefOut().boxes.swap(part[ci].boxes);  // (release as we go: the pieces are as large as the result)
+        RefOut().tri.swap(part[ci].tri);
+      }
+    });
   }
   {
     uint32_t dropped = 0;
@@ -831,7 +860,9 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
 
   std::vector<uint32_t> order(n);
-  for (uint32_t i = 0; i < n; i++) order[i] = i;
+  parallelFor(n, threads, [&](size_t a, size_t b, int) {
+    for (size_t i = a; i < b; i++) order[i] = (uint32_t)i;
+  });
   const BuildData B{boxes, cent, order};
   lap("records");
 
@@ -943,8 +974,12 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   // within the device stack.  Shallow subtrees (most of the nodes) become four-wide; only the few
   // deep, skinny paths of a SAH tree keep two-wide nodes.
   std::vector<uint16_t> height(tmp.size(), 0);
+  std::vector<uint32_t> subtreeNodes(tmp.size(), 1);  // binary nodes in the subtree (itself included)
   for (size_t t = tmp.size(); t-- > 0;)  // children are always created after their parent
-    if (tmp[t].left >= 0) height[t] = (uint16_t)(1 + std::max(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]));
+    if (tmp[t].left >= 0) {
+      height[t] = (uint16_t)(1 + std::max(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]));
+      subtreeNodes[t] = 1 + subtreeNodes[(size_t)tmp[t].left] + subtreeNodes[(size_t)tmp[t].right];
+    }
   std::vector<Wide> wide;
   std::vector<std::pair<int32_t, int32_t>> slots;  // per wide node: where its index must be written
   uint32_t wDepth = 0, wStack = 0;
@@ -953,50 +988,98 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       uint32_t src, depth, stackAbove;
       int32_t slotNode, slotIdx;
     };
-    std::vector<Job> jobs;
-    jobs.push_back(Job{0, 0, 0, -1, -1});
-    while (!jobs.empty()) {
-      Job j = jobs.back();
-      jobs.pop_back();
-      Wide w;
-      w.src = j.src;
-      w.depth = j.depth;
-      w.nk = 0;
-      if (tmp[j.src].left < 0) {  // root is a single leaf
-        w.kids[w.nk++] = j.src;
-      } else {
-        w.kids[w.nk++] = (uint32_t)tmp[j.src].left;
-        w.kids[w.nk++] = (uint32_t)tmp[j.src].right;
-        while (w.nk < 4) {
-          int best = -1;
-          float bestArea = -1.0f;
-          for (int k = 0; k < w.nk; k++)
-            if (tmp[w.kids[k]].left >= 0) {
-              float ar = tmp[w.kids[k]].box.area();
-              if (ar > bestArea) {
-                bestArea = ar;
-                best = k;
+    // One subtree, depth first, appended to (W, SL); `defer` (may be null) receives the jobs of subtrees of at most
+    // kCollapseGrain binary nodes instead of descending into them.
+    auto collapse = [&](Job rootJob, std::vector<Wide>& W, std::vector<std::pair<int32_t, int32_t>>& SL, std::vector<Job>* defer, uint32_t& dMax,
+                        uint32_t& sMax) {
+      std::vector<Job> jobs;
+      jobs.push_back(rootJob);
+      while (!jobs.empty()) {
+        Job j = jobs.back();
+        jobs.pop_back();
+        Wide w;
+        w.src = j.src;
+        w.depth = j.depth;
+        w.nk = 0;
+        if (tmp[j.src].left < 0) {  // root is a single leaf
+          w.kids[w.nk++] = j.src;
+        } else {
+          w.kids[w.nk++] = (uint32_t)tmp[j.src].left;
+          w.kids[w.nk++] = (uint32_t)tmp[j.src].right;
+          while (w.nk < 4) {
+            int best = -1;
+            float bestArea = -1.0f;
+            for (int k = 0; k < w.nk; k++)
+              if (tmp[w.kids[k]].left >= 0) {
+                float ar = tmp[w.kids[k]].box.area();
+                if (ar > bestArea) {
+                  bestArea = ar;
+                  best = k;
+                }
               }
-            }
-          if (best < 0) break;
-          // stack need if we widen: j.stackAbove + nk (= (nk+1)-1) + tallest remaining child
-          const uint32_t t = w.kids[best];
-          uint32_t tallest = std::max<uint32_t>(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]);
-          for (int k = 0; k < w.nk; k++)
-            if (k != best) tallest = std::max<uint32_t>(tallest, height[w.kids[k]]);
-          if (j.stackAbove + (uint32_t)w.nk + tallest > (uint32_t)kBvhMaxStack) break;
-          w.kids[best] = (uint32_t)tmp[t].left;
-          w.kids[w.nk++] = (uint32_t)tmp[t].right;
+            if (best < 0) break;
+            // stack need if we widen: j.stackAbove + nk (= (nk+1)-1) + tallest remaining child
+            const uint32_t t = w.kids[best];
+            uint32_t tallest = std::max<uint32_t>(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]);
+            for (int k = 0; k < w.nk; k++)
+              if (k != best) tallest = std::max<uint32_t>(tallest, height[w.kids[k]]);
+            if (j.stackAbove + (uint32_t)w.nk + tallest > (uint32_t)kBvhMaxStack) break;
+            w.kids[best] = (uint32_t)tmp[t].left;
+            w.kids[w.nk++] = (uint32_t)tmp[t].right;
+          }
         }
+        const uint32_t self = (uint32_t)W.size();
+        W.push_back(w);
+        SL.push_back({j.slotNode, j.slotIdx});
+        dMax = std::max(dMax, j.depth);
+        const uint32_t need = j.stackAbove + (uint32_t)(w.nk - 1);
+        sMax = std::max(sMax, need);
+        for (int k = w.nk - 1; k >= 0; k--)
+          if (tmp[w.kids[k]].left >= 0) {
+            const Job child{w.kids[k], j.depth + 1, need, (int32_t)self, k};
+            if (defer && subtreeNodes[w.kids[k]] <= kCollapseGrain)
+              defer->push_back(child);
+            else
+              jobs.push_back(child);
+          }
       }
-      const uint32_t self = (uint32_t)wide.size();
-      wide.push_back(w);
-      slots.push_back({j.slotNode, j.slotIdx});
-      wDepth = std::max(wDepth, j.depth);
-      const uint32_t need = j.stackAbove + (uint32_t)(w.nk - 1);
-      wStack = std::max(wStack, need);
-      for (int k = w.nk - 1; k >= 0; k--)
-        if (tmp[w.kids[k]].left >= 0) jobs.push_back(Job{w.kids[k], j.depth + 1, need, (int32_t)self, k});
+    };
+    // The top of the tree by one thread; the subtrees below kCollapseGrain nodes side by side, each into its own list,
+    // appended in the order they were met.  The grain is a constant, so the node order does not depend on the thread count.
+    std::vector<Job> deferred;
+    collapse(Job{0, 0, 0, -1, -1}, wide, slots, tmp.size() > 4 * (size_t)kCollapseGrain ? &deferred : nullptr, wDepth, wStack);
+    if (!deferred.empty()) {
+      struct Local {
+        std::vector<Wide> w;
+        std::vector<std::pair<int32_t, int32_t>> sl;
+        uint32_t dMax = 0, sMax = 0;
+      };
+      std::vector<Local> local(deferred.size());
+      parallelChunks(deferred.size(), threads, 1, [&](size_t j, size_t, size_t) {
+        Local& L = local[j];
+        L.w.reserve(subtreeNodes[deferred[j].src] / 2 + 4);
+        L.sl.reserve(subtreeNodes[deferred[j].src] / 2 + 4);
+        Job r = deferred[j];
+        const int32_t parentNode = r.slotNode, parentIdx = r.slotIdx;
+        r.slotNode = -2;  // marks the list's root: its slot is a node of the top part
+        collapse(r, L.w, L.sl, nullptr, L.dMax, L.sMax);
+        L.sl[0] = {parentNode, parentIdx};
+      });
+      std::vector<size_t> at(deferred.size() + 1);
+      at[0] = wide.size();
+      for (size_t j = 0; j < deferred.size(); j++) at[j + 1] = at[j] + local[j].w.size();
+      wide.resize(at.back());
+      slots.resize(at.back());
+      parallelChunks(deferred.size(), threads, 1, [&](size_t j, size_t, size_t) {
+        const Local& L = local[j];
+        std::copy(L.w.begin(), L.w.end(), wide.begin() + (long)at[j]);
+        slots[at[j]] = L.sl[0];  // (a node of the top part: global index already)
+        for (size_t i = 1; i < L.sl.size(); i++) slots[at[j] + i] = {L.sl[i].first + (int32_t)at[j], L.sl[i].second};
+      });
+      for (const Local& L : local) {
+        wDepth = std::max(wDepth, L.dMax);
+        wStack = std::max(wStack, L.sMax);
+      }
     }
   }
   lap("collapse");

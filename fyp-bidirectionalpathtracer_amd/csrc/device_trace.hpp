@@ -53,29 +53,28 @@ BD void travInit(TravState& T, f3 o, f3 d, float tmin, float tmax) {
   T.cur = (finite && (tmax > tmin)) ? 0 : kDone;
 }
 
-// Stack entry e of a ray: LDS row e below KL, the context's overflow area from KL on (KL = kStackEntries: all in LDS).
-// STRIDE = columns per workgroup (kWave: one column per lane), col = this ray's column.
-template <int KL, int STRIDE = kWave>
-BD int* ovfSlot(const SceneDev& S, int e, int col) {
-  return S.stackOvf + (size_t)(e - KL) * S.stackOvfStride + (size_t)blockIdx.x * STRIDE + col;
+// Stack entry e of this lane: LDS row e below KL, the context's overflow area from KL on (KL = kStackEntries: all in LDS).
+template <int KL>
+BD int* ovfSlot(const SceneDev& S, int e) {
+  return S.stackOvf + (size_t)(e - KL) * S.stackOvfStride + (size_t)blockIdx.x * kWave + (threadIdx.x & 63u);
 }
-template <int KL, int STRIDE = kWave>
-BD void stackStore(const SceneDev& S, int* stk, int e, int ref, int col = (int)(threadIdx.x & 63u)) {
+template <int KL>
+BD void stackStore(const SceneDev& S, int* stk, int e, int ref) {
   if (KL < kStackEntries && e >= KL)
-    *ovfSlot<KL, STRIDE>(S, e, col) = ref;
+    *ovfSlot<KL>(S, e) = ref;
   else
-    stk[e * STRIDE] = ref;
+    stk[e * kWave] = ref;
 }
-template <int KL, int STRIDE = kWave>
-BD int travPop(const SceneDev& S, TravState& T, const int* stk, int col = (int)(threadIdx.x & 63u)) {
+template <int KL>
+BD int travPop(const SceneDev& S, TravState& T, const int* stk) {
   if (T.sp == 0) return kDone;
   T.sp--;
-  if (KL < kStackEntries && T.sp >= KL) return *ovfSlot<KL, STRIDE>(S, T.sp, col);
-  return stk[T.sp * STRIDE];
+  if (KL < kStackEntries && T.sp >= KL) return *ovfSlot<KL>(S, T.sp);
+  return stk[T.sp * kWave];
 }
-template <int KL, int STRIDE = kWave>
-BD void travPush(const SceneDev& S, TravState& T, int* stk, int ref, int col = (int)(threadIdx.x & 63u)) {
-  stackStore<KL, STRIDE>(S, stk, T.sp, ref, col);
+template <int KL>
+BD void travPush(const SceneDev& S, TravState& T, int* stk, int ref) {
+  stackStore<KL>(S, stk, T.sp, ref);
   T.sp++;
 }
 
@@ -86,8 +85,8 @@ BD float ubyte(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  /
 // bytes are picked per axis by the ray's direction sign (one select per axis for all four children).
 // ORDER 1 (closest hit): children are entered nearest first, the rest stacked far to near; ORDER 2: the nearest is
 // entered, the rest stacked in slot order; ORDER 0 (any hit): slot order.
-template <int ORDER, int KL = kStackEntries, int STRIDE = kWave>
-BD void nodeStep(const SceneDev& S, TravState& T, int* stk, int col = (int)(threadIdx.x & 63u)) {
+template <int ORDER, int KL = kStackEntries>
+BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
   const uint4* np = S.recs + (size_t)T.cur * kRecF4;
   // origin.xyz, exponents + leaf bits | lo.x lo.y lo.z hi.x | hi.y hi.z childBase childOffsets   (bvh.h BvhRec)
   const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -132,19 +131,19 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk, int col = (int)(thre
 #pragma unroll
       for (int c = 3; c >= 0; c--) {
         const int rc = (c == 3) ? r3 : ((c == 2) ? r2 : ((c == 1) ? r1 : r0));
-        stk[sp * STRIDE] = rc;
+        stk[sp * kWave] = rc;
         sp += (hit[c] && c != near) ? 1 : 0;
       }
     } else {  // near the end of the LDS rows: every store picks its place
 #pragma unroll
       for (int c = 3; c >= 0; c--) {
         const int rc = (c == 3) ? r3 : ((c == 2) ? r2 : ((c == 1) ? r1 : r0));
-        if (hit[c] && c != near) stackStore<KL, STRIDE>(S, stk, sp++, rc, col);
+        if (hit[c] && c != near) stackStore<KL>(S, stk, sp++, rc);
       }
     }
     T.sp = sp;
     const int rn = (near == 3) ? r3 : ((near == 2) ? r2 : ((near == 1) ? r1 : r0));
-    T.cur = any ? rn : travPop<KL, STRIDE>(S, T, stk, col);
+    T.cur = any ? rn : travPop<KL>(S, T, stk);
   } else if (ORDER == 1) {
     float t0 = hit[0] ? tn[0] : 3.0e38f, t1 = hit[1] ? tn[1] : 3.0e38f, t2 = hit[2] ? tn[2] : 3.0e38f, t3 = hit[3] ? tn[3] : 3.0e38f;
     r0 = hit[0] ? r0 : kDone;
@@ -169,15 +168,15 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk, int col = (int)(thre
 #undef BDPT_CSWAP
     // misses sorted to the back (t = 3e38, ref = kDone): push far to near, enter the nearest
     if (KL >= kStackEntries || T.sp <= KL - 3) {
-      if (r3 != kDone) travPush<kStackEntries, STRIDE>(S, T, stk, r3, col);
-      if (r2 != kDone) travPush<kStackEntries, STRIDE>(S, T, stk, r2, col);
-      if (r1 != kDone) travPush<kStackEntries, STRIDE>(S, T, stk, r1, col);
+      if (r3 != kDone) travPush<kStackEntries>(S, T, stk, r3);
+      if (r2 != kDone) travPush<kStackEntries>(S, T, stk, r2);
+      if (r1 != kDone) travPush<kStackEntries>(S, T, stk, r1);
     } else {  // near the end of the LDS rows
-      if (r3 != kDone) travPush<KL, STRIDE>(S, T, stk, r3, col);
-      if (r2 != kDone) travPush<KL, STRIDE>(S, T, stk, r2, col);
-      if (r1 != kDone) travPush<KL, STRIDE>(S, T, stk, r1, col);
+      if (r3 != kDone) travPush<KL>(S, T, stk, r3);
+      if (r2 != kDone) travPush<KL>(S, T, stk, r2);
+      if (r1 != kDone) travPush<KL>(S, T, stk, r1);
     }
-    T.cur = (r0 != kDone) ? r0 : travPop<KL, STRIDE>(S, T, stk, col);
+    T.cur = (r0 != kDone) ? r0 : travPop<KL>(S, T, stk);
   } else {
     // Branch-free: walk the slots from 3 down to 0 keeping the last hit in `next`; a newly found hit
     // pushes the previous one.  The LDS store is unconditional (a slot above sp is scratch), only the
@@ -188,7 +187,7 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk, int col = (int)(thre
 #pragma unroll
       for (int c = 2; c >= 0; c--) {
         const int rc = (c == 2) ? r2 : ((c == 1) ? r1 : r0);
-        stk[sp * STRIDE] = next;
+        stk[sp * kWave] = next;
         sp += (hit[c] && next != kDone) ? 1 : 0;
         next = hit[c] ? rc : next;
       }
@@ -196,12 +195,12 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk, int col = (int)(thre
 #pragma unroll
       for (int c = 2; c >= 0; c--) {
         const int rc = (c == 2) ? r2 : ((c == 1) ? r1 : r0);
-        if (hit[c] && next != kDone) stackStore<KL, STRIDE>(S, stk, sp++, next, col);
+        if (hit[c] && next != kDone) stackStore<KL>(S, stk, sp++, next);
         next = hit[c] ? rc : next;
       }
     }
     T.sp = sp;
-    if (next == kDone) next = travPop<KL, STRIDE>(S, T, stk, col);
+    if (next == kDone) next = travPop<KL>(S, T, stk);
     T.cur = next;
   }
 }
@@ -507,195 +506,6 @@ __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueu
   }
 }
 
-
-
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 4, profiles/README.md "wave specialisation"): the any-hit kernel with the rays UNBOUND from the
-// lanes.  A wave keeps kPoolSlots rays in LDS (origin, direction, tmax, ray id, traversal cursor, stack pointer and a
-// kPoolStack-row stack per ray; deeper entries in the context's overflow area) and alternates between two DENSE
-// phases: a node phase, in which every lane takes a ray that stands on an interior node and gives it up to
-// BDPT_NODE_BURST visits, and a leaf phase, in which every lane takes a ray that waits at a leaf (or has run out of
-// stack) and intersects / retires it.  Which lane serves which ray changes from phase to phase, so no lane idles
-// behind a ray that is in the other phase — the half of every VALU instruction trace_shadow_kernel leaves unused
-// (lane utilisation 0.53).  The price: about 10 LDS reads and 2 writes per ray and phase, stack rows indexed by ray
-// (two-way bank conflicts instead of none).  Specialised WAVES of a workgroup (traversal waves with fewer registers
-// than a leaf / shade wave) cannot be had inside one kernel — a kernel's VGPR allocation is one number for all of its
-// waves — so the phases are specialised in TIME within a wave instead.  Any-hit answers do not depend on the
-// traversal order: visibility bytes identical to trace_shadow_kernel.  Built only with -DBDPT_POOL_ANYHIT=1.
-// ------------------------------------------------------------------------------------------------
-#ifndef BDPT_POOL_ANYHIT
-#define BDPT_POOL_ANYHIT 0
-#endif
-#if BDPT_POOL_ANYHIT
-#ifndef BDPT_POOL_SLOTS
-#define BDPT_POOL_SLOTS 128
-#endif
-#ifndef BDPT_POOL_NODE_MIN
-#define BDPT_POOL_NODE_MIN 48  // node-ready rays that start a node phase while leaf-ready rays are waiting
-#endif
-#ifndef BDPT_POOL_REFILL
-#define BDPT_POOL_REFILL 32    // empty slots that trigger a fetch from the ray queue
-#endif
-constexpr int kPoolSlots = BDPT_POOL_SLOTS;  // multiple of 64
-constexpr int kPoolHalves = kPoolSlots / kWave;
-constexpr int kEmptySlot = (int)0x80000001;  // cursor value of a slot without a ray (kDone = stack exhausted: retire)
-enum : int { PF_OX = 0, PF_OY, PF_OZ, PF_DX, PF_DY, PF_DZ, PF_TMAX, PF_RID, PF_CUR, PF_SP, PF_COUNT };
-
-template <bool COUNT>
-__global__ __launch_bounds__(kWave) void trace_shadow_pool_kernel(SceneDev S, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
-                                                                  float shadowTmin) {
-  __shared__ int s_stack[kPoolStack * kPoolSlots];
-  __shared__ uint32_t s_ray[PF_COUNT * kPoolSlots];  // field f of slot s at s_ray[f * kPoolSlots + s]
-  __shared__ uint32_t s_list[kWave];
-  const int lane = (int)(threadIdx.x & 63u);
-  const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t nNodes = 0, nTris = 0, nAlpha = 0;
-  int maxSp = 0;
-  bool exhausted = false;
-  uint32_t q = blockIdx.x % Q.numSub, tried = 0, chunkPos = 0, chunkEnd = 0, chunk = kFetchChunk;
-  const uint32_t wavesPerList = (gridDim.x + Q.numSub - 1) / Q.numSub;
-#pragma unroll
-  for (int h = 0; h < kPoolHalves; h++) s_ray[PF_CUR * kPoolSlots + h * kWave + lane] = (uint32_t)kEmptySlot;
-  __syncthreads();
-  for (;;) {
-    // ---- what the pool holds: lane looks at slots lane, lane + 64, ...
-    int cur[kPoolHalves];
-    unsigned long long emptyM[kPoolHalves], nodeM[kPoolHalves], leafM[kPoolHalves];
-    int nEmpty = 0, nNode = 0, nLeaf = 0;
-#pragma unroll
-    for (int h = 0; h < kPoolHalves; h++) {
-      cur[h] = (int)s_ray[PF_CUR * kPoolSlots + h * kWave + lane];
-      emptyM[h] = __ballot(cur[h] == kEmptySlot);
-      nodeM[h] = __ballot(cur[h] >= 0);
-      leafM[h] = ~(emptyM[h] | nodeM[h]);
-      nEmpty += __popcll(emptyM[h]);
-      nNode += __popcll(nodeM[h]);
-      nLeaf += __popcll(leafM[h]);
-    }
-    // ---- refill from the ray queue (wave-uniform chunk fetch as in trace_shadow_kernel)
-    if (!exhausted && nEmpty >= BDPT_POOL_REFILL) {
-#pragma unroll
-      for (int h = 0; h < kPoolHalves; h++) {
-        const int idle = __popcll(emptyM[h]);
-        if (idle == 0 || exhausted) continue;
-        while (chunkPos >= chunkEnd && !exhausted) {
-          const uint32_t nq = Q.count[q * kCursorStride];
-          uint32_t base = nq;
-          if (__hip_atomic_load(&Q.head[q * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq) {
-            uint32_t share = (nq / wavesPerList + kWave - 1) & ~(uint32_t)(kWave - 1);
-            chunk = share < (uint32_t)kWave ? (uint32_t)kWave : (share > kFetchChunk ? kFetchChunk : share);
-            if (lane == 0) base = atomicAdd(&Q.head[q * kCursorStride], chunk);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          }
-          if (base < nq) {
-            chunkPos = base;
-            chunkEnd = (base + chunk < nq) ? base + chunk : nq;
-            tried = 0;
-          } else {
-            q = (q + 1 == Q.numSub) ? 0u : q + 1;
-            if (++tried >= Q.numSub) exhausted = true;
-          }
-        }
-        if (exhausted) continue;
-        const uint32_t avail = chunkEnd - chunkPos;
-        const uint32_t take = ((uint32_t)idle < avail) ? (uint32_t)idle : avail;
-        const uint32_t rank = (uint32_t)__popcll(emptyM[h] & below);
-        if (cur[h] == kEmptySlot && rank < take) {
-          const uint32_t idx = q * Q.subCap + chunkPos + rank;
-          const float* r = Q.rays + idx;
-          const size_t c = Q.cap;
-          const float ox = r[0], oy = r[c], oz = r[2 * c], dx = r[3 * c], dy = r[4 * c], dz = r[5 * c], tmax = r[6 * c];
-          const int slot = h * kWave + lane;
-          s_ray[PF_OX * kPoolSlots + slot] = __float_as_uint(ox);
-          s_ray[PF_OY * kPoolSlots + slot] = __float_as_uint(oy);
-          s_ray[PF_OZ * kPoolSlots + slot] = __float_as_uint(oz);
-          s_ray[PF_DX * kPoolSlots + slot] = __float_as_uint(dx);
-          s_ray[PF_DY * kPoolSlots + slot] = __float_as_uint(dy);
-          s_ray[PF_DZ * kPoolSlots + slot] = __float_as_uint(dz);
-          s_ray[PF_TMAX * kPoolSlots + slot] = __float_as_uint(tmax);
-          s_ray[PF_RID * kPoolSlots + slot] = idx;
-          // (travInit: a ray with a NaN or an empty interval misses without traversal)
-          const bool finite = (ox == ox) && (oy == oy) && (oz == oz) && (dx == dx) && (dy == dy) && (dz == dz);
-          s_ray[PF_CUR * kPoolSlots + slot] = (uint32_t)((finite && (tmax > shadowTmin)) ? 0 : kDone);
-          s_ray[PF_SP * kPoolSlots + slot] = 0u;
-        }
-        chunkPos += take;
-      }
-      __syncthreads();
-      continue;  // look at the pool again
-    }
-    if (nNode == 0 && nLeaf == 0) {
-      if (exhausted) break;
-      continue;  // (cannot happen: an empty pool has kPoolSlots >= BDPT_POOL_REFILL empty slots and refills above)
-    }
-    // ---- which phase: node visits while enough rays can take one, else the leaves
-    const bool nodePhase = nNode >= BDPT_POOL_NODE_MIN || nLeaf == 0;
-    // the first 64 rays of the phase's class, in slot order: s_list[k] = slot of the k-th
-    {
-      uint32_t before = 0;
-#pragma unroll
-      for (int h = 0; h < kPoolHalves; h++) {
-        const unsigned long long m = nodePhase ? nodeM[h] : leafM[h];
-        const uint32_t r = before + (uint32_t)__popcll(m & below);
-        if (((m >> lane) & 1ull) && r < (uint32_t)kWave) s_list[r] = (uint32_t)(h * kWave + lane);
-        before += (uint32_t)__popcll(m);
-      }
-    }
-    __syncthreads();
-    const int nSel = nodePhase ? (nNode < kWave ? nNode : kWave) : (nLeaf < kWave ? nLeaf : kWave);
-    if (lane < nSel) {
-      const int slot = (int)s_list[lane];
-      int* stk = s_stack + slot;
-      TravState T;
-      T.o = mk(__uint_as_float(s_ray[PF_OX * kPoolSlots + slot]), __uint_as_float(s_ray[PF_OY * kPoolSlots + slot]),
-               __uint_as_float(s_ray[PF_OZ * kPoolSlots + slot]));
-      T.d = mk(__uint_as_float(s_ray[PF_DX * kPoolSlots + slot]), __uint_as_float(s_ray[PF_DY * kPoolSlots + slot]),
-               __uint_as_float(s_ray[PF_DZ * kPoolSlots + slot]));
-      T.tmin = shadowTmin;
-      T.tmax = __uint_as_float(s_ray[PF_TMAX * kPoolSlots + slot]);
-      T.cur = (int)s_ray[PF_CUR * kPoolSlots + slot];
-      T.sp = (int)s_ray[PF_SP * kPoolSlots + slot];
-      T.best.prim = -1;
-      T.best.t = T.tmax;
-      T.best.u = T.best.v = 0.0f;
-      if (nodePhase) {
-        T.idir = mk(clampedRcp(T.d.x), clampedRcp(T.d.y), clampedRcp(T.d.z));
-        T.neg = (T.d.x < 0.0f ? 1u : 0u) | (T.d.y < 0.0f ? 2u : 0u) | (T.d.z < 0.0f ? 4u : 0u);
-#pragma unroll 1
-        for (int k = 0; k < BDPT_NODE_BURST && T.cur >= 0; k++) {
-          if (COUNT) nNodes++;
-          nodeStep<0, kPoolStack, kPoolSlots>(S, T, stk, slot);
-          if (COUNT) maxSp = T.sp > maxSp ? T.sp : maxSp;
-        }
-      } else {
-        T.idir = mk(0);
-        T.neg = 0u;
-        bool finished = (T.cur == kDone);
-        if (!finished) {
-          finished = leafStep<2, COUNT>(S, T, nTris, nAlpha);
-          if (!finished) {
-            T.cur = travPop<kPoolStack, kPoolSlots>(S, T, stk, slot);
-            finished = (T.cur == kDone);
-          }
-        }
-        if (finished) {
-          vis[s_ray[PF_RID * kPoolSlots + slot]] = (T.best.prim < 0) ? (uint8_t)1 : (uint8_t)0;
-          T.cur = kEmptySlot;
-        }
-      }
-      s_ray[PF_CUR * kPoolSlots + slot] = (uint32_t)T.cur;
-      s_ray[PF_SP * kPoolSlots + slot] = (uint32_t)T.sp;
-    }
-    __syncthreads();
-  }
-  if (COUNT) {
-    waveAddCount(counters, C_NODE_SHADOW, nNodes);
-    waveAddCount(counters, C_TRI_SHADOW, nTris);
-    waveAddCount(counters, C_ALPHA_SHADOW, nAlpha);
-    if (maxSp > 0) atomicMax(&counters->v[blockIdx.x % kCounterShards][C_STACK_MAX], (unsigned long long)maxSp);
-  }
-}
-#endif  // BDPT_POOL_ANYHIT
 
 #undef BD
 }  // namespace bdpt

@@ -25,13 +25,7 @@ constexpr int kMaxPersistentPerCU = 32;  // resident one-wave workgroups per CU 
 // workgroup and lane only, so no two persistent traversal launches of one context may be resident at once — every
 // launchWalk / launchTraceShadow of a context goes to the caller's stream, the context's second stream only runs
 // generators (api.cpp bdpt_execute, evFork / evJoin), and the test hooks synchronise the device first.
-// EXPERIMENT knob (round 4): stack rows per ray the pool variant of the any-hit kernel keeps in LDS (device_trace.hpp
-// trace_shadow_pool_kernel, -DBDPT_POOL_ANYHIT=1); its rays' deeper entries use the same overflow area.
-#ifndef BDPT_POOL_STACK
-#define BDPT_POOL_STACK 16
-#endif
-constexpr int kPoolStack = BDPT_POOL_STACK < KSTACK ? BDPT_POOL_STACK : KSTACK;
-constexpr int kStackOvfRows = KSTACK - (kStackLds < kPoolStack ? kStackLds : kPoolStack);
+constexpr int kStackOvfRows = KSTACK - kStackLds;
 constexpr int kShadeRecF4 = 7;  // float4s per triangle shading record (7 used = 112 B)
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 // Hot single-word atomics top out near 90 M/s on this chip (MI355X_MICROARCH.md "dequeue"), so

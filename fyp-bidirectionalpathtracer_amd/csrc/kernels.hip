@@ -870,27 +870,43 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
   waveAddCount(F.counters, C_RAYS_SPLAT, emit ? 1u : 0u);
 }
 
-// Connections: lane g of a pixel's group owns camera length g + 1 and walks the light lengths.  The group first
-// puts the pixel's light vertices (lane g loads light vertex g) and eye positions into LDS, so every vertex record
-// leaves memory once; the slot index keeps the reference's (totalLength, cameraLength) numbering, which is all the
-// gather stage needs.
+// Connections.  Lane g of a pixel's group LOADS camera length g + 1 (its vertex record, the two path colours and the
+// direction to its predecessor) and light vertex g (into LDS), so every vertex record leaves memory once.  The pairs
+// themselves — camera length c in 1..D-1 with light length l in 1..D-c, D(D-1)/2 of them — form a triangle; handed out by
+// camera length (round 2) the lane of c = 1 evaluated seven pairs while the lane of c = 7 evaluated one and every lane
+// sat through all eight rounds: lane utilisation 0.50 in a kernel bound by VALU issue.  Now they are dealt to the group's
+// lanes DENSELY: pair ordinal it * G + g goes to lane g in round it (ceil(D(D-1)/2G) rounds: 4 instead of 8 at depth 8),
+// and the lane fetches the eye side of its pair from the lane that holds it (__shfl, 23 values) and the light side
+// from LDS.  The arithmetic of a pair is what it was; only the order in which the rays are appended changes, and the
+// slot index keeps the reference's (totalLength, cameraLength) numbering, which is all the gather stage needs.
+// The l = 0 pairs (c in 2..D-1) never carry a ray: their slot is written as empty by the lane of c.
 template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
   constexpr int kPix = kWave / G;
-  __shared__ float4 s_light[kPix][G][4];  // q0..q3 of light vertex g (zeros past the end of the sub-path)
-  __shared__ float4 s_eyePos[kPix][G];    // position of eye vertex g + 1 (zero past the end)
+  __shared__ float4 s_light[kPix][G][4];       // q0..q3 of light vertex g (zeros past the end of the sub-path)
+  __shared__ float4 s_eyePos[kPix][G];         // position of eye vertex g + 1 (zero past the end)
+  __shared__ uint8_t s_pair[G * (G - 1) / 2];  // pair ordinal -> (cameraLength << 4) | lightLength, for this launch's depth
   bool act = false;
   uint32_t i = 0;
   int g = 0;
   if (!queueGroup<G>(P.qcount, P.pathSubCap, act, i, g)) return;
   const int e = (int)(threadIdx.x / G);
   const uint32_t p = act ? P.queue[0][i] : 0u;
-  const int D = (int)F.p.maxDepth;
+  const int D = (int)F.p.maxDepth;  // <= G: the context is sized for it (launcher)
   const int eyeLast = act ? (int)P.eyeLast[p] : 0;
   const int lightLast = act ? (int)P.lightLast[p] : -1;
   const f3 camPos = ld3(F.cam.posW);
   const int cameraLength = g + 1;
   const bool camAct = act && cameraLength <= D - 1;
+  const int nEval = (D * (D - 1)) / 2;
+  for (int q = (int)threadIdx.x; q < nEval; q += kWave) {  // ordinal q: camera lengths in order, light lengths 1..D-c within
+    int c = 1, r = q;
+    while (r >= D - c) {
+      r -= D - c;
+      c++;
+    }
+    s_pair[q] = (uint8_t)((c << 4) | (r + 1));
+  }
   {
     float4 l0 = make_float4(0, 0, 0, 0), l1 = l0, l2 = l0, l3 = l0;
     if (act && g <= lightLast && g < D) {
@@ -923,15 +939,39 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
     cprevPos = mk(q.x, q.y, q.z);
   }
   const f3 woE = normalize(cprevPos - ce.pos);
+  if (camAct && cameraLength >= 2)  // (c, l = 0): total length c, never evaluated (BDPTMain.rt.hlsl:217 skips lightLength 0 below)
+    P.slotRay[(size_t)(2 * D + ((cameraLength - 1) * cameraLength) / 2 - 1 + (cameraLength - 1)) * P.Np + p] = kNoRay;
+  const int groupBase = (int)threadIdx.x - g;
+  const int rounds = (nEval + G - 1) / G;
   uint32_t nConn = 0;
-  for (int lightLength = 0; lightLength <= D - 1; lightLength++) {
-    const int totalLength = cameraLength + lightLength;  // 2..D; pairs of smaller totals come first: (t-1)t/2 - 1 of them
-    const bool pairAct = camAct && totalLength <= D && !(cameraLength == 1 && lightLength == 0);
-    const int slot = 2 * D + ((totalLength - 1) * totalLength) / 2 - 1 + (cameraLength - 1);
+  for (int it = 0; it < rounds; it++) {
+    const int ord = it * G + g;
+    const bool pairAct = act && ord < nEval;
+    const int cl = (ord < nEval) ? (int)s_pair[ord] : ((1 << 4) | 1);
+    const int c = cl >> 4, lightLength = cl & 15, totalLength = c + lightLength;
+    const int slot = 2 * D + ((totalLength - 1) * totalLength) / 2 - 1 + (c - 1);
+    // the eye side of the pair, from the lane that loaded camera length c
+    const int src = groupBase + c - 1;
+    Vtx ev;
+    ev.pos = mk(__shfl(ce.pos.x, src), __shfl(ce.pos.y, src), __shfl(ce.pos.z, src));
+    ev.N = mk(__shfl(ce.N.x, src), __shfl(ce.N.y, src), __shfl(ce.N.z, src));
+    ev.dif = mk(__shfl(ce.dif.x, src), __shfl(ce.dif.y, src), __shfl(ce.dif.z, src));
+    if (GGX) {
+      ev.spec = mk(__shfl(ce.spec.x, src), __shfl(ce.spec.y, src), __shfl(ce.spec.z, src));
+      ev.rough = __shfl(ce.rough, src);
+      ev.isSpec = __shfl(ce.isSpec ? 1 : 0, src) != 0;
+    } else {
+      ev.spec = mk(0);
+      ev.rough = 0.0f;
+      ev.isSpec = false;
+    }
+    const f3 aEs = mk(__shfl(aE.x, src), __shfl(aE.y, src), __shfl(aE.z, src));
+    const f3 aLs = mk(__shfl(aL.x, src), __shfl(aL.y, src), __shfl(aL.z, src));
+    const f3 woEs = mk(__shfl(woE.x, src), __shfl(woE.y, src), __shfl(woE.z, src));
     bool emit = false;
     f3 dirAB = mk(0), shade = mk(0);
     float lengthAB = 0.0f;
-    if (pairAct && lightLength != 0) {
+    if (pairAct) {
       const float4 q0 = s_light[e][lightLength][0], q1 = s_light[e][lightLength][1], q2 = s_light[e][lightLength][2];
       Vtx le;
       le.pos = mk(q0.x, q0.y, q0.z);
@@ -949,36 +989,36 @@ __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev
       }
       const float4 qp = s_light[e][lightLength - 1][0];  // light vertex lightLength - 1 (zero past the end)
       const f3 lprev = mk(qp.x, qp.y, qp.z);
-      const f3 vecAB = le.pos - ce.pos;
+      const f3 vecAB = le.pos - ev.pos;
       const float invLengthAB = 1.0f / length(vecAB);
       const f3 dirG = vecAB * invLengthAB;
-      const float cosA = fabsf(dot(ce.N, dirG));
+      const float cosA = fabsf(dot(ev.N, dirG));
       const float cosB = fabsf(dot(le.N, dirG));
       const float Gt = cosA * cosB * invLengthAB * invLengthAB;
-      const f3 connectDir = normalize(ce.pos - le.pos);
+      const f3 connectDir = normalize(ev.pos - le.pos);
       const f3 woL = normalize(lprev - le.pos);
-      f3 c;
+      f3 cst;
       const f3 fsL = evalBRDF<GGX>(connectDir, woL, le.N, le.N, le.dif, le.spec, le.rough, le.isSpec);
       if (allZero(fsL)) {
-        c = fsL;
+        cst = fsL;
       } else {
-        const f3 fsE = evalBRDF<GGX>(-connectDir, woE, ce.N, ce.N, ce.dif, ce.spec, ce.rough, ce.isSpec);
+        const f3 fsE = evalBRDF<GGX>(-connectDir, woEs, ev.N, ev.N, ev.dif, ev.spec, ev.rough, ev.isSpec);
         if (allZero(fsE)) {
-          c = fsE;
+          cst = fsE;
         } else {
-          const f3 cst = (fsL * Gt) * fsE;
-          c = (aL * cst) * aE;
+          const f3 k = (fsL * Gt) * fsE;
+          cst = (aLs * k) * aEs;
         }
       }
-      shade = clampVec(applyStrategyWeight(F, P, p, c, totalLength, cameraLength, lightLength), F.p.clampUpper);
+      shade = clampVec(applyStrategyWeight(F, P, p, cst, totalLength, c, lightLength), F.p.clampUpper);
       if (isnan3(shade)) shade = mk(0);
       if (!allZero(shade)) {
         emit = true;
-        lengthAB = length(le.pos - ce.pos);
-        dirAB = (le.pos - ce.pos) / lengthAB;
+        lengthAB = length(le.pos - ev.pos);
+        dirAB = (le.pos - ev.pos) / lengthAB;
       }
     }
-    const uint32_t id = emitRay(P, RAY_PAIRS, emit, ce.pos, dirAB, lengthAB, shade);
+    const uint32_t id = emitRay(P, RAY_PAIRS, emit, ev.pos, dirAB, lengthAB, shade);
     if (pairAct) P.slotRay[(size_t)slot * P.Np + p] = id;
     nConn += emit ? 1u : 0u;
   }
@@ -1411,15 +1451,6 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
              P.rayHead + (size_t)cls * kRayCursorBlock};
   uint8_t* vis = P.rayVis + P.rayBase[cls];
   uint32_t& g = G.shadow[cnt ? 1 : 0];
-#if BDPT_POOL_ANYHIT
-  if (cnt) {
-    if (!g) g = persistentGrid(trace_shadow_pool_kernel<true>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_pool_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
-  } else {
-    if (!g) g = persistentGrid(trace_shadow_pool_kernel<false>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_pool_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
-  }
-#else
   if (cnt) {
     if (!g) g = persistentGrid(trace_shadow_kernel<true>, numCUs);
     hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
@@ -1427,7 +1458,6 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
     if (!g) g = persistentGrid(trace_shadow_kernel<false>, numCUs);
     hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
   }
-#endif
 }
 
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st) {
@@ -1483,13 +1513,8 @@ void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode,
 void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap, const uint32_t* count, uint32_t* head, uint8_t* vis,
                            DevCounters* counters, float tmin, int numCUs, hipStream_t st) {
   RayQueue Q{planes, cap, cap, 1u, count, head};
-#if BDPT_POOL_ANYHIT
-  const uint32_t g = persistentGrid(trace_shadow_pool_kernel<true>, numCUs);
-  hipLaunchKernelGGL(trace_shadow_pool_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
-#else
   const uint32_t g = persistentGrid(trace_shadow_kernel<true>, numCUs);
   hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
-#endif
 }
 void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st) {
   if (!n) return;

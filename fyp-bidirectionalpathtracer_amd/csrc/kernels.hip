@@ -838,7 +838,6 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
     dirToCamera = normalize(camPos - lv.pos);
     disToCamera = length(camPos - lv.pos);
     if (dot(cameraN, dirToCamera) < 0) {
-      emit = true;  // the reference traces this ray whatever the value (its write saturates the target pixel)
       float d1 = dot(dirToCamera, U) / dot(U, U);
       float d2 = dot(dirToCamera, Vc) / dot(Vc, Vc);
       float d3 = dot(dirToCamera, Wc) / dot(Wc, Wc);
@@ -847,6 +846,10 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
       float fx = rintf(px * (float)F.W - F.p.pixelJitter[0]);
       float fy = rintf(py * (float)F.H - F.p.pixelJitter[1]);
       const bool inside = (fx >= 0.0f && fx < (float)F.W && fy >= 0.0f && fy < (float)F.H);
+      // The reference traces this ray whatever the value (its write saturates the target pixel) — but a target outside
+      // the frame has no pixel to write (quirk 8: the out-of-range UAV write is dropped), so such a ray decides nothing
+      // and is not traced.
+      emit = inside;
       if (inside) {
         target = (uint32_t)splatIndex(F.sl, F.W, (uint32_t)(int)fx, (uint32_t)(int)fy);
         float theta1 = saturate(fabsf(dot(dirToCamera, cameraN)));

@@ -31,7 +31,7 @@ def _assert_frame_equals_oracle(pkg, ob, scene, pipe, gp, p, label):
     c, o = pipe.ctx.counters().as_dict(), cnt.as_dict()
     # identical walks; the GPU path only skips shadow rays whose outcome cannot change the image
     assert c["raysEyeExtend"] == o["raysEyeExtend"] and c["raysLightExtend"] == o["raysLightExtend"], label
-    assert c["raysSplat"] == o["raysSplat"] and c["raysNee"] <= o["raysNee"] and c["raysConnect"] <= o["raysConnect"], label
+    assert c["raysSplat"] <= o["raysSplat"] and c["raysNee"] <= o["raysNee"] and c["raysConnect"] <= o["raysConnect"], label
     assert c["pixelsValid"] == o["pixelsValid"] and c["splatsLanded"] == o["splatsLanded"], label
     orc.close()
     return c, o

@@ -1158,22 +1158,37 @@ BD void pairFromOrdinal(int D, int ord, int& totalLength, int& cameraLength) {
   cameraLength = ord + 1;
 }
 
+// G lanes per pending pixel (8, or 16 for contexts sized beyond depth 8, as the generators): lane g examines pair ordinal
+// base + g of the current chunk, the group's candidates are counted with one __ballot, and the first `batch` of them in
+// ordinal order get a ray — the very rays, in the very slots of lazyRay, one lane per pixel found by walking the
+// ordinals one by one (round 3: up to 90 serial steps per lane at depth 16, lane utilisation 0.14,
+// profiles/r4/config5/pmc_summary.txt).
+template <int G>
 __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
                                                          const uint32_t* __restrict__ listCount, int batch) {
   bool act = false;
   uint32_t i = 0;
-  if (!queueChunk(listCount, P.pathSubCap, act, i)) return;
+  int g = 0;
+  if (!queueGroup<G>(listCount, P.pathSubCap, act, i, g)) return;
   const uint32_t p = act ? list[i] : 0u;
   const int D = (int)F.p.maxDepth;
   const int nPairs = (int)numConnectPairs((uint32_t)D);
-  int ord = act ? (int)P.lazyCursor[p] : nPairs;
   const int eyeLast = act ? (int)P.eyeLast[p] : 0, lightLast = act ? (int)P.lightLast[p] : -1;
-  uint32_t nRays = 0;
   const bool lightGhost = act && (int)P.lightReal[p] < lightLast;  // last light vertex is a copy of its predecessor
-  for (int b = 0; b < batch; b++) {
-    int totalLength = 0, cameraLength = 0, lightLength = 0;
-    for (; ord < nPairs; ord++) {
-      if (P.slotRay[(size_t)(2 * D + ord) * P.Np + p] != kNoRay) continue;  // had a ray: it was occluded
+  const int lane = (int)(threadIdx.x & 63u), groupShift = lane - g;
+  const unsigned long long groupMask = ((1ull << G) - 1ull) << groupShift, below = (1ull << lane) - 1ull;
+  int base = act ? (int)P.lazyCursor[p] : nPairs;  // first ordinal of the chunk the group looks at (group-uniform)
+  int cursor = base;                               // what the pixel's cursor becomes
+  int taken = 0;                                   // rays this round has given the pixel so far (group-uniform)
+  uint32_t nRays = 0;
+  for (;;) {
+    const bool live = act && taken < batch && base < nPairs;
+    if (__ballot(live) == 0ull) break;  // (wave-uniform: emitRay below is a wave collective)
+    const int ord = base + g;
+    bool cand = false;
+    int cameraLength = 0, lightLength = 0;
+    if (live && ord < nPairs && P.slotRay[(size_t)(2 * D + ord) * P.Np + p] == kNoRay) {  // (a slot with a ray: it was occluded)
+      int totalLength = 0;
       pairFromOrdinal(D, ord, totalLength, cameraLength);
       lightLength = totalLength - cameraLength;
       // Vertices past the end of a sub-path are all the zero vertex and a ghost repeats its predecessor,
@@ -1183,9 +1198,12 @@ __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, 
       const int cmin = (cameraLength <= eyeLast) ? cameraLength : eyeLast + 1;
       int lmin = (lightLength > lightLast) ? lightLast + 1 : ((lightGhost && lightLength == lightLast) ? lightLast - 1 : lightLength);
       if (cmin == 1 && lmin == 0) lmin = 1;  // (cameraLength 1, lightLength 0) has total length 1: not a pair
-      if (cameraLength == cmin && lightLength == lmin) break;
+      cand = (cameraLength == cmin && lightLength == lmin);
     }
-    const bool emit = act && ord < nPairs;
+    const unsigned long long cm = __ballot(cand) & groupMask;
+    const int rank = __popcll(cm & below), n = __popcll(cm);
+    const bool emit = cand && taken + rank < batch;
+    const unsigned long long lastM = __ballot(cand && taken + rank == batch - 1) & groupMask;  // the candidate that fills the round
     f3 posA = mk(0), dirAB = mk(0);
     float lengthAB = 0.0f;
     if (emit) {
@@ -1193,13 +1211,25 @@ __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, 
       const f3 posB = (lightLength <= lightLast) ? ldPlane3(P, PATH_LIGHT, lightLength, F_POS, p) : mk(0);
       lengthAB = length(posB - posA);
       dirAB = (posB - posA) / lengthAB;
-      ord++;
     }
     const uint32_t id = emitRay(P, RAY_PAIRS, emit, posA, dirAB, lengthAB, mk(0));
-    if (act) P.lazyRay[(size_t)b * P.Np + p] = id;
+    if (emit) P.lazyRay[(size_t)(taken + rank) * P.Np + p] = id;
     nRays += emit ? 1u : 0u;
+    if (live) {
+      if (lastM != 0ull) {  // the round is full: the cursor stops behind the candidate that filled it
+        cursor = base + (__ffsll((long long)lastM) - 1 - groupShift) + 1;
+        taken = batch;
+      } else {
+        taken += n;
+        base += G;
+        cursor = base < nPairs ? base : nPairs;
+      }
+    }
   }
-  if (act) P.lazyCursor[p] = (uint8_t)ord;
+  if (act) {
+    for (int b = taken + g; b < batch; b += G) P.lazyRay[(size_t)b * P.Np + p] = kNoRay;  // slots the round did not fill
+    if (g == 0) P.lazyCursor[p] = (uint8_t)cursor;
+  }
   waveAddCount(F.counters, C_RAYS_CONNECT, nRays);
   waveAddCount(F.counters, C_RAYS_LAZY, nRays);
 }
@@ -1469,7 +1499,10 @@ void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint3
 }
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(lazy_gen_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, list, listCount, batch);
+  if (P.D1 > 9)  // the depth the context is sized for: 16 lanes per pixel, as the generators
+    hipLaunchKernelGGL(lazy_gen_kernel<16>, dim3(queueGrid(P) * 16), dim3(kWave), 0, st, F, P, list, listCount, batch);
+  else
+    hipLaunchKernelGGL(lazy_gen_kernel<8>, dim3(queueGrid(P) * 8), dim3(kWave), 0, st, F, P, list, listCount, batch);
 }
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
                      uint32_t* nextList, uint32_t* nextCount, hipStream_t st) {

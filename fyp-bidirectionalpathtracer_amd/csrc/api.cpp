@@ -15,6 +15,7 @@
 #include <cstring>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -322,6 +323,16 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->S.stackOvf = c->stackOvf;
   c->S.stackOvfStride = c->stackOvfStride;
 
+  // BDPT_BUILD_VERBOSE: where the set-up time goes (stderr), as bvh_build.cpp's own laps
+  const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
+  auto tLap = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[set_scene] %-18s %.3f s\n", what, std::chrono::duration<double>(t - tLap).count());
+    tLap = t;
+  };
+  lap("validate");
   // traversal flags, alpha classification, spatial pre-splitting and the tree itself: scene_bvh.cpp
   SceneBvh sb;
   try {
@@ -330,6 +341,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     fail(c, "scene: out of host memory while building the acceleration structure");
     return BDPT_E_NOMEM;
   }
+  lap("buildSceneBvh");
   Bvh& bvh = sb.bvh;
   const std::vector<uint32_t>& alphaTris = sb.alphaTris;
   if (bvh.maxStack > (uint32_t)kBvhMaxStack) {
@@ -353,7 +365,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->bvhInfo.numAlwaysPass = sb.numAlwaysPass;
 
   // per-primitive shading records: 3 x (position, normal, uv) + material id, 112 B
-  std::vector<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4, 0.0f);
+  BigVec<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4);  // (sized, not zeroed: the loop writes every float)
   hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
     for (size_t t = t0; t < t1; t++) {
       float* r = &shade[t * kShadeRecF4 * 4];
@@ -373,14 +385,17 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
       }
       uint32_t mid = d->triMaterial[t];
       std::memcpy(r + 24, &mid, 4);
+      for (int k = 25; k < kShadeRecF4 * 4; k++) r[k] = 0.0f;
     }
   });
 
+  lap("shading records");
   int rc;
   const BvhRec* dRecs;
   const float* dShade;
   if ((rc = devUpload(c, c->sceneAllocs, &dRecs, bvh.recs.data(), bvh.recs.size()))) return rc;
   if ((rc = devUpload(c, c->sceneAllocs, &dShade, shade.data(), shade.size()))) return rc;
+  lap("upload tree+shade");
   c->S.recs = reinterpret_cast<const uint4*>(dRecs);
   c->S.shade = reinterpret_cast<const float4*>(dShade);
   c->S.numRecs = (uint32_t)bvh.recs.size();

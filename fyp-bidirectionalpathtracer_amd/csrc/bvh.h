@@ -8,12 +8,39 @@
 
 #include <cstdlib>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
 
 namespace bdpt {
+// std::vector whose resize() leaves new elements UNINITIALISED (default-initialisation instead of value-initialisation):
+// the builder's arrays are hundreds of megabytes each and are filled by parallel loops right after they are sized;
+// letting one thread zero them first — and take every page fault — cost more than the loops (round 4: 8 GB of such
+// fills in a 10 M-triangle build).  Only for element types whose default-initialisation does nothing, and only where
+// every element is written before it is read.
+template <class T>
+struct NoInitAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAllocator<U>;
+  };
+  NoInitAllocator() = default;
+  template <class U>
+  NoInitAllocator(const NoInitAllocator<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <class U, class A0, class... A>
+  void construct(U* p, A0&& a0, A&&... a) {
+    ::new (static_cast<void*>(p)) U(static_cast<A0&&>(a0), static_cast<A&&>(a)...);
+  }
+};
+template <class T>
+using BigVec = std::vector<T, NoInitAllocator<T>>;
+
 // Worker threads of the host-side builder.  An exception thrown on a worker (std::bad_alloc from the large per-chunk
 // allocations of a 10 M-triangle scene, above all) must not reach std::terminate: it is kept, every thread is joined,
 // and join() rethrows it on the caller's thread, where bdpt_set_scene turns it into BDPT_E_NOMEM.  Leaving the scope
@@ -118,10 +145,10 @@ constexpr uint32_t kTriLastOfLeaf = 4u;  // BvhTri::flags bit set by packBvh (de
 constexpr uint32_t kBvhPadRecs = 4;      // zero records behind the array (a leaf fetch reads past a leaf's last triangle)
 
 struct Bvh {
-  std::vector<BvhNode> nodes;
-  std::vector<BvhTri> tris;  // in leaf order: one record per REFERENCE (a split triangle appears once per piece)
-  std::vector<float> refBox; // 6 floats (lo, hi) per entry of `tris`: bounds of the piece the reference stands for
-  std::vector<BvhRec> recs;  // packed device form of the two (packBvh)
+  BigVec<BvhNode> nodes;
+  BigVec<BvhTri> tris;   // in leaf order: one record per REFERENCE (a split triangle appears once per piece)
+  BigVec<float> refBox;  // 6 floats (lo, hi) per entry of `tris`: bounds of the piece the reference stands for
+  BigVec<BvhRec> recs;   // packed device form of the two (packBvh)
   uint32_t maxDepth = 0;     // depth of the four-wide tree
   uint32_t maxStack = 0;     // worst-case number of simultaneously stacked references
   float sahCost = 0.0f;

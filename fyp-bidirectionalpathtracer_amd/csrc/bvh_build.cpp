@@ -48,12 +48,21 @@ struct Box {
   }
 };
 
-struct TmpNode {
+struct TmpNode {  // (no member initialisers: arrays of these are sized without being touched, bvh.h BigVec)
   Box box;
-  int32_t left = -1, right = -1;  // children (tmp indices) or -1
-  uint32_t first = 0, count = 0;  // leaf range in `order`
-  uint32_t depth = 0;
+  int32_t left, right;    // children (tmp indices) or -1
+  uint32_t first, count;  // leaf range in `order`
+  uint32_t depth;
 };
+inline TmpNode makeTmpNode(uint32_t first, uint32_t count, uint32_t depth) {
+  TmpNode n;
+  n.box.reset();
+  n.left = n.right = -1;
+  n.first = first;
+  n.count = count;
+  n.depth = depth;
+  return n;
+}
 
 #ifndef BDPT_SAH_BINS
 #define BDPT_SAH_BINS 16
@@ -143,9 +152,9 @@ void parallelChunks(size_t n, int threads, size_t chunk, const F& f) {
 }
 
 struct BuildData {
-  const std::vector<Box>& boxes;
-  const std::vector<float>& cent;
-  std::vector<uint32_t>& order;
+  const BigVec<Box>& boxes;
+  const BigVec<float>& cent;
+  BigVec<uint32_t>& order;
 };
 
 struct Bins {
@@ -162,9 +171,9 @@ struct Bins {
 
 // Bounds of a node and the position of its split (0 = leaf).  `threads` > 1 shares the two O(count) scans.
 uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t depth, int threads, Box& nodeBox) {
-  const std::vector<Box>& boxes = B.boxes;
-  const std::vector<float>& cent = B.cent;
-  std::vector<uint32_t>& order = B.order;
+  const BigVec<Box>& boxes = B.boxes;
+  const BigVec<float>& cent = B.cent;
+  BigVec<uint32_t>& order = B.order;
   Box nb, cb;
   nb.reset();
   cb.reset();
@@ -289,8 +298,9 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
       // are fixed-size, not per-thread, and the rule is chosen by the node's SIZE, so the permutation — and with it the
       // tree — does not depend on the thread count.
       const size_t nChunks = ((size_t)count + kPartitionChunk - 1) / kPartitionChunk;
-      std::vector<uint8_t> flags(count);
-      std::vector<uint32_t> lefts(nChunks + 1, 0), scratch(count);
+      BigVec<uint8_t> flags(count);
+      BigVec<uint32_t> scratch(count);
+      std::vector<uint32_t> lefts(nChunks + 1, 0);
       parallelChunks(count, threads, kPartitionChunk, [&](size_t ci, size_t a, size_t b) {
         uint32_t n = 0;
         for (size_t k = a; k < b; k++) {
@@ -347,7 +357,7 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
 
 // Whole subtree under nodes[root] (its first / count / depth already set), depth first, appended to `nodes`.
 // Children are always created after their parent.
-void buildSubtree(const BuildData& B, std::vector<TmpNode>& nodes, uint32_t root, uint32_t splitBelow, int threads,
+void buildSubtree(const BuildData& B, BigVec<TmpNode>& nodes, uint32_t root, uint32_t splitBelow, int threads,
                   std::vector<uint32_t>* deferred) {
   std::vector<uint32_t> todo{root};
   while (!todo.empty()) {
@@ -362,13 +372,7 @@ void buildSubtree(const BuildData& B, std::vector<TmpNode>& nodes, uint32_t root
     const uint32_t mid = splitNode(B, first, count, depth, threads, nb);
     nodes[ni].box = nb;
     if (mid == 0) continue;
-    TmpNode l, r;
-    l.first = first;
-    l.count = mid;
-    l.depth = depth + 1;
-    r.first = first + mid;
-    r.count = count - mid;
-    r.depth = depth + 1;
+    const TmpNode l = makeTmpNode(first, mid, depth + 1), r = makeTmpNode(first + mid, count - mid, depth + 1);
     const uint32_t li = (uint32_t)nodes.size();
     nodes.push_back(l);
     nodes.push_back(r);
@@ -637,8 +641,8 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
 
   // Triangle records exactly as the device intersects them: the "actual" triangle is
   // (v0, v0+e1, v0+e2) in fp32, so bounds are taken from those points.
-  std::vector<BvhTri> recs(nTris);
-  std::vector<Box> triBox(nTris);
+  BigVec<BvhTri> recs(nTris);  // (every field of every record is written by the loop below)
+  BigVec<Box> triBox(nTris);
   Box scene;
   scene.reset();
   {
@@ -807,8 +811,8 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   }
   lap("priorities");
   // pass 2: the references, triangle order (chunks are contiguous triangle ranges, appended in order)
-  std::vector<Box> boxes;
-  std::vector<uint32_t> refTri;
+  BigVec<Box> boxes;
+  BigVec<uint32_t> refTri;
   {
     std::vector<RefOut> part((nTris + kRefChunk - 1) / kRefChunk);  // one per chunk, appended in chunk order below
     parallelChunks(nTris, threads, kRefChunk, [&](size_t ci, size_t t0, size_t t1) {
@@ -852,14 +856,14 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     out.numDropped = dropped;
   }
   const uint32_t n = (uint32_t)boxes.size();  // references from here on
-  std::vector<float> cent((size_t)n * 3);
+  BigVec<float> cent((size_t)n * 3);
   parallelFor(n, threads, [&](size_t r0, size_t r1, int) {
     for (size_t r = r0; r < r1; r++)
       for (int k = 0; k < 3; k++) cent[r * 3 + (size_t)k] = 0.5f * (boxes[r].lo[k] + boxes[r].hi[k]);
   });
   if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
 
-  std::vector<uint32_t> order(n);
+  BigVec<uint32_t> order(n);
   parallelFor(n, threads, [&](size_t a, size_t b, int) {
     for (size_t i = a; i < b; i++) order[i] = (uint32_t)i;
   });
@@ -869,15 +873,9 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   // Phase 1: one thread splits the top of the tree (large nodes share their scans among all threads) and
   // defers every subtree of at most `grain` triangles.  Phase 2: the deferred subtrees are built concurrently,
   // largest first, each into its own node list.  Phase 3: the lists are appended; children stay after parents.
-  std::vector<TmpNode> tmp;
+  BigVec<TmpNode> tmp;
   tmp.reserve((size_t)n / 2 + 16);
-  {
-    TmpNode root;
-    root.first = 0;
-    root.count = n;
-    root.depth = 0;
-    tmp.push_back(root);
-  }
+  tmp.push_back(makeTmpNode(0, n, 0));
   if (threads <= 1 || n < (1u << 15)) {
     buildSubtree(B, tmp, 0, 0, 1, nullptr);
   } else {
@@ -888,13 +886,13 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     std::sort(deferred.begin(), deferred.end(), [&](uint32_t a, uint32_t b) {
       return tmp[a].count > tmp[b].count || (tmp[a].count == tmp[b].count && a < b);
     });
-    std::vector<std::vector<TmpNode>> local(deferred.size());
+    std::vector<BigVec<TmpNode>> local(deferred.size());
     std::atomic<size_t> next{0};
     auto worker = [&] {
       for (;;) {
         const size_t j = next.fetch_add(1);
         if (j >= deferred.size()) return;
-        std::vector<TmpNode>& L = local[j];
+        BigVec<TmpNode>& L = local[j];
         L.reserve((size_t)tmp[deferred[j]].count / 2 + 4);
         L.push_back(tmp[deferred[j]]);
         buildSubtree(B, L, 0, 0, 1, nullptr);
@@ -914,7 +912,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     for (size_t j = 0; j < deferred.size(); j++) at[j + 1] = at[j] + local[j].size() - 1;
     tmp.resize(at.back());
     parallelChunks(deferred.size(), threads, 1, [&](size_t j, size_t, size_t) {
-      const std::vector<TmpNode>& L = local[j];
+      const BigVec<TmpNode>& L = local[j];
       const int32_t off = (int32_t)at[j] - 1;  // local index i >= 1 -> off + i
       TmpNode rootNode = L[0];
       if (rootNode.left >= 0) {
@@ -1185,7 +1183,10 @@ bool packBvh(Bvh& bvh, int threads) {
     }
     if (next >= 0x7fffffffull) return false;
   }
-  bvh.recs.assign((size_t)next + kBvhPadRecs, BvhRec{});  // + zero pad records: the device fetches up to four records per leaf visit
+  // every record below `next` is written by the loop below (a node at pos[i], a leaf's triangles behind base[i]); the pad
+  // records behind them — the device fetches up to four records per leaf visit — are zero
+  bvh.recs.resize((size_t)next + kBvhPadRecs);
+  for (uint32_t k = 0; k < kBvhPadRecs; k++) bvh.recs[(size_t)next + k] = BvhRec{};
   bool ok = true;
   std::mutex failMutex;
   parallelFor(nn, threads, [&](size_t i0, size_t i1, int) {

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +36,14 @@ void hostFor(size_t n, int threads, const F& f) {
 
 void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, bool classify, SceneBvh& out) {
   if (threads <= 0) threads = bvhBuildThreads();
+  const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
+  auto tLap = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[scene_bvh] %-12s %.3f s\n", what, std::chrono::duration<double>(t - tLap).count());
+    tLap = t;
+  };
   const uint32_t n = d->numTriangles;
   // per-triangle traversal flags: BLAS OPAQUE iff AlphaModeOpaque (Falcor Raytracing/RtModel.cpp:221-224),
   // TRIANGLE_CULL_DISABLE iff double-sided (Raytracing/RtScene.cpp:175-178)
@@ -47,8 +56,10 @@ void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, flo
   });
   out.numAlphaMode = out.numAlwaysPass = 0;
   for (uint32_t t = 0; t < n; t++) out.numAlphaMode += (out.triFlags[t] & kTriNonOpaque) ? 1u : 0u;
+  lap("flags");
   out.clipper.reset();
   if (out.numAlphaMode) out.clipper.reset(new AlphaClipper(d));  // (the host-side trace hook runs the alpha test through it)
+  lap("clipper");
   if (classify && out.numAlphaMode) {
     std::atomic<uint32_t> pass{0};
     hostFor(n, threads, [&](size_t t0, size_t t1) {
@@ -62,6 +73,7 @@ void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, flo
     });
     out.numAlwaysPass = pass.load();
   }
+  lap("classify");
   // non-opaque triangles get an alpha-test record (device_scene.hpp alphaTestFails); its index travels in BvhTri::aux
   out.triAux.assign(n, 0u);
   out.alphaTris.clear();
@@ -75,6 +87,7 @@ void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, flo
   opt.splitBudget = splitBudget;
   opt.splitBudgetAlpha = splitBudgetAlpha;
   opt.clipper = classify ? out.clipper.get() : nullptr;
+  lap("aux");
   buildBvh(d->positions, d->indices, n, out.triFlags.data(), out.bvh, opt, out.triAux.data());
 }
 

@@ -151,10 +151,21 @@ void parallelChunks(size_t n, int threads, size_t chunk, const F& f) {
   pool.join();
 }
 
+// What the tree is built over: one 40-byte record per reference — the box of the piece it stands for, the box's
+// centre, and its index in the reference list.  The records THEMSELVES are permuted as nodes are partitioned (round 4;
+// before, an index array was permuted and every scan of a node gathered boxes and centres through it): every pass over
+// a node — bounds, binning, the partition — then streams a contiguous range instead of gathering 36 bytes per element
+// from a gigabyte of boxes, which is what bounded the builder on 16 host threads.
+struct Ref {
+  Box box;
+  float cent[3];
+  uint32_t id;
+};
+static_assert(sizeof(Ref) == 40, "reference record");
+
 struct BuildData {
-  const BigVec<Box>& boxes;
-  const BigVec<float>& cent;
-  BigVec<uint32_t>& order;
+  BigVec<Ref>& refs;     // permuted in place: a node owns a contiguous range
+  BigVec<Ref>& scratch;  // as large as refs: the stable partition of large nodes scatters through it
 };
 
 struct Bins {
@@ -171,9 +182,7 @@ struct Bins {
 
 // Bounds of a node and the position of its split (0 = leaf).  `threads` > 1 shares the two O(count) scans.
 uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t depth, int threads, Box& nodeBox) {
-  const BigVec<Box>& boxes = B.boxes;
-  const BigVec<float>& cent = B.cent;
-  BigVec<uint32_t>& order = B.order;
+  Ref* const base = B.refs.data() + first;
   Box nb, cb;
   nb.reset();
   cb.reset();
@@ -188,9 +197,8 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
       n0.reset();
       c0.reset();
       for (size_t k = a; k < b; k++) {
-        const uint32_t tr = order[first + k];
-        n0.grow(boxes[tr]);
-        c0.grow(&cent[(size_t)tr * 3]);
+        n0.grow(base[k].box);
+        c0.grow(base[k].cent);
       }
       pn[(size_t)t] = n0;
       pc[(size_t)t] = c0;
@@ -201,9 +209,8 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
     }
   } else {
     for (uint32_t k = 0; k < count; k++) {
-      const uint32_t t = order[first + k];
-      nb.grow(boxes[t]);
-      cb.grow(&cent[(size_t)t * 3]);
+      nb.grow(base[k].box);
+      cb.grow(base[k].cent);
     }
   }
   nodeBox = nb;
@@ -226,12 +233,12 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
     }
     auto binRange = [&](size_t a, size_t b, Bins& bins) {
       for (size_t k = a; k < b; k++) {
-        const uint32_t t = order[first + k];
+        const Ref& r = base[k];
         for (int axis = 0; axis < 3; axis++) {
           if (!use[axis]) continue;
-          int bi = (int)((cent[(size_t)t * 3 + axis] - lo[axis]) * scale[axis]);
+          int bi = (int)((r.cent[axis] - lo[axis]) * scale[axis]);
           bi = std::min(std::max(bi, 0), kBins - 1);
-          bins.bb[axis][bi].grow(boxes[t]);
+          bins.bb[axis][bi].grow(r.box);
           bins.bc[axis][bi]++;
         }
       }
@@ -285,29 +292,23 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
   if (bestAxis >= 0) {
     const float lo = cb.lo[bestAxis], ext = cb.hi[bestAxis] - cb.lo[bestAxis];
     const float scale = (float)kBins / ext;
-    auto goesLeft = [&](uint32_t t) {
-      int b = (int)((cent[(size_t)t * 3 + bestAxis] - lo) * scale);
+    auto goesLeft = [&](const Ref& r) {
+      int b = (int)((r.cent[bestAxis] - lo) * scale);
       b = std::min(std::max(b, 0), kBins - 1);
       return b <= bestSplit;
     };
-    uint32_t* const base = order.data() + first;
     if (count >= kStablePartitionMin) {
       // Large nodes (the top of the tree: a few dozen nodes that together touch every reference several times): a STABLE
-      // partition — lefts in their order, then rights in theirs — in three parallel passes: the tests (a cache-missing
-      // gather per reference), a scatter into a scratch copy at offsets from per-chunk counts, the copy back.  The chunks
-      // are fixed-size, not per-thread, and the rule is chosen by the node's SIZE, so the permutation — and with it the
+      // partition — lefts in their order, then rights in theirs — in three parallel passes: count the lefts of every
+      // chunk, scatter the records into the scratch array at offsets from those counts, copy back.  The chunks are
+      // fixed-size, not per-thread, and the rule is chosen by the node's SIZE, so the permutation — and with it the
       // tree — does not depend on the thread count.
       const size_t nChunks = ((size_t)count + kPartitionChunk - 1) / kPartitionChunk;
-      BigVec<uint8_t> flags(count);
-      BigVec<uint32_t> scratch(count);
+      Ref* const tmp = B.scratch.data() + first;
       std::vector<uint32_t> lefts(nChunks + 1, 0);
       parallelChunks(count, threads, kPartitionChunk, [&](size_t ci, size_t a, size_t b) {
         uint32_t n = 0;
-        for (size_t k = a; k < b; k++) {
-          const uint8_t f = goesLeft(base[k]) ? 1 : 0;
-          flags[k] = f;
-          n += f;
-        }
+        for (size_t k = a; k < b; k++) n += goesLeft(base[k]) ? 1u : 0u;
         lefts[ci + 1] = n;
       });
       for (size_t ci = 0; ci < nChunks; ci++) lefts[ci + 1] += lefts[ci];
@@ -315,19 +316,19 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
       parallelChunks(count, threads, kPartitionChunk, [&](size_t ci, size_t a, size_t b) {
         uint32_t l = lefts[ci], r = nLeft + ((uint32_t)a - lefts[ci]);
         for (size_t k = a; k < b; k++) {
-          if (flags[k])
-            scratch[l++] = base[k];
+          if (goesLeft(base[k]))
+            tmp[l++] = base[k];
           else
-            scratch[r++] = base[k];
+            tmp[r++] = base[k];
         }
       });
-      parallelChunks(count, threads, kPartitionChunk, [&](size_t, size_t a, size_t b) { std::memcpy(base + a, scratch.data() + a, (b - a) * sizeof(uint32_t)); });
+      parallelChunks(count, threads, kPartitionChunk, [&](size_t, size_t a, size_t b) { std::memcpy(base + a, tmp + a, (b - a) * sizeof(Ref)); });
       mid = nLeft;
     } else {
       // Two-pointer partition (the bidirectional algorithm of std::partition, spelled out so that the permutation is
       // this file's own definition): every element is tested exactly once, at its original position.
-      uint32_t* lo_p = base;
-      uint32_t* hi_p = lo_p + count;
+      Ref* lo_p = base;
+      Ref* hi_p = lo_p + count;
       for (;;) {
         while (lo_p != hi_p && goesLeft(*lo_p)) ++lo_p;
         if (lo_p == hi_p) break;
@@ -347,9 +348,8 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
     if (e1 > e0 && e1 >= e2) axis = 1;
     if (e2 > e0 && e2 > e1) axis = 2;
     mid = count / 2;
-    std::nth_element(order.begin() + first, order.begin() + first + mid, order.begin() + first + count, [&](uint32_t a, uint32_t b) {
-      const float ka = cent[(size_t)a * 3 + axis], kb = cent[(size_t)b * 3 + axis];
-      return ka < kb || (ka == kb && a < b);
+    std::nth_element(base, base + mid, base + count, [&](const Ref& a, const Ref& b) {
+      return a.cent[axis] < b.cent[axis] || (a.cent[axis] == b.cent[axis] && a.id < b.id);
     });
   }
   return mid;
@@ -810,8 +810,9 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     }
   }
   lap("priorities");
-  // pass 2: the references, triangle order (chunks are contiguous triangle ranges, appended in order)
-  BigVec<Box> boxes;
+  // pass 2: the references, triangle order (chunks are contiguous triangle ranges, appended in order), as the
+  // 40-byte records the tree is built over (box, centre, reference index) + the triangle every reference belongs to
+  BigVec<Ref> refs;
   BigVec<uint32_t> refTri;
   {
     std::vector<RefOut> part((nTris + kRefChunk - 1) / kRefChunk);  // one per chunk, appended in chunk order below
@@ -839,12 +840,18 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     });
     std::vector<size_t> at(part.size() + 1, 0);
     for (size_t ci = 0; ci < part.size(); ci++) at[ci + 1] = at[ci] + part[ci].tri.size();
-    boxes.resize(at.back());
+    refs.resize(at.back());
     refTri.resize(at.back());
     parallelChunks(part.size(), threads, 16, [&](size_t, size_t c0, size_t c1) {  // every chunk knows where it lands
       for (size_t ci = c0; ci < c1; ci++) {
-        std::copy(part[ci].boxes.begin(), part[ci].boxes.end(), boxes.begin() + (long)at[ci]);
-        std::copy(part[ci].tri.begin(), part[ci].tri.end(), refTri.begin() + (long)at[ci]);
+        const RefOut& o = part[ci];
+        for (size_t j = 0; j < o.tri.size(); j++) {
+          Ref& r = refs[at[ci] + j];
+          r.box = o.boxes[j];
+          for (int k = 0; k < 3; k++) r.cent[k] = 0.5f * (o.boxes[j].lo[k] + o.boxes[j].hi[k]);
+          r.id = (uint32_t)(at[ci] + j);
+          refTri[at[ci] + j] = o.tri[j];
+        }
         RefOut().boxes.swap(part[ci].boxes);  // (release as we go: the pieces are as large as the result)
         RefOut().tri.swap(part[ci].tri);
       }
@@ -855,19 +862,10 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     for (uint32_t t = 0; t < nTris; t++) dropped += state[t] == 2 ? 1u : 0u;
     out.numDropped = dropped;
   }
-  const uint32_t n = (uint32_t)boxes.size();  // references from here on
-  BigVec<float> cent((size_t)n * 3);
-  parallelFor(n, threads, [&](size_t r0, size_t r1, int) {
-    for (size_t r = r0; r < r1; r++)
-      for (int k = 0; k < 3; k++) cent[r * 3 + (size_t)k] = 0.5f * (boxes[r].lo[k] + boxes[r].hi[k]);
-  });
+  const uint32_t n = (uint32_t)refs.size();  // references from here on
   if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
-
-  BigVec<uint32_t> order(n);
-  parallelFor(n, threads, [&](size_t a, size_t b, int) {
-    for (size_t i = a; i < b; i++) order[i] = (uint32_t)i;
-  });
-  const BuildData B{boxes, cent, order};
+  BigVec<Ref> scratch(n >= kStablePartitionMin ? n : 0);  // (only nodes of that size partition through it)
+  const BuildData B{refs, scratch};
   lap("records");
 
   // Phase 1: one thread splits the top of the tree (large nodes share their scans among all threads) and
@@ -937,10 +935,10 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   out.refBox.resize((size_t)n * 6);
   parallelFor(n, threads, [&](size_t a, size_t b, int) {
     for (size_t i = a; i < b; i++) {
-      out.tris[i] = recs[refTri[order[i]]];
+      out.tris[i] = recs[refTri[refs[i].id]];
       for (int k = 0; k < 3; k++) {
-        out.refBox[i * 6 + (size_t)k] = boxes[order[i]].lo[k];
-        out.refBox[i * 6 + 3 + (size_t)k] = boxes[order[i]].hi[k];
+        out.refBox[i * 6 + (size_t)k] = refs[i].box.lo[k];
+        out.refBox[i * 6 + 3 + (size_t)k] = refs[i].box.hi[k];
       }
     }
   });

@@ -71,7 +71,6 @@ struct bdpt_ctx {
   int numStages = 0;
   bool evCreated = false;
   int lazyRounds = 3;
-  int genSchedule = 0;  // measurement knob BDPT_GEN_SCHEDULE: 1 = all three generators side by side BEFORE any tracing
   LaunchGrids grids{};  // persistent-grid sizes for this context's device
   int* stackOvf = nullptr;      // overflow rows of the persistent kernels' traversal stacks (kernels.h kStackLds)
   uint32_t stackOvfStride = 0;  // lanes per row: every wave a persistent grid can hold
@@ -681,7 +680,6 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
     // Lazy rounds: each costs three small launches and cannot finish faster than its slowest ray, so there are few:
     // two or three rounds of kLazyBatchDiv-th shares, the last of which takes every candidate that is left.
     c->lazyRounds = np >= (1u << 18) ? 3 : 2;
-    if (const char* e = std::getenv("BDPT_GEN_SCHEDULE")) c->genSchedule = std::atoi(e);
     if (const char* e = std::getenv("BDPT_LAZY_ROUNDS")) {  // measurement knob (tools/prof_tile.sh): 1 .. kMaxLazyRounds
       const int v = std::atoi(e);
       if (v >= 1 && v <= kMaxLazyRounds) c->lazyRounds = v;
@@ -882,11 +880,11 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
     launchGenConnect(c->S, F, P, c->walkStream);
     HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
     launchGenNee(c->S, F, P, st);
-    HIPCHK(c, hipStreamWaitEvent(st, c->genSchedule == 1 ? c->evJoin : c->evSplat, 0));
+    HIPCHK(c, hipStreamWaitEvent(st, c->evSplat, 0));
     stageMark(c, st, "gen_terms");
     launchTraceShadow(c->S, F, P, RAY_TERMS, c->grids, c->numCUs, st);
     stageMark(c, st, "trace_terms");
-    if (c->genSchedule != 1) HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
+    HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
   }
   launchTraceShadow(c->S, F, P, RAY_PAIRS, c->grids, c->numCUs, st);
   stageMark(c, st, "trace_pairs");

@@ -512,3 +512,24 @@ def test_tiled_multi_gpu_host_program_compiles_links_and_runs(tmp_path):
     lib = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "fyp-bidirectionalpathtracer_amd", "csrc", "libbdpt_amd.so")],
                          capture_output=True, text=True).stdout
     assert "nccl" not in lib
+
+
+def test_timeline_summary_on_a_synthetic_kernel_trace(tmp_path):
+    """tools/timeline_summary.py (profiles/r4/tile8/timeline.txt): wall per frame, union of kernel intervals, time a
+    kernel ran alone — on a hand-made rocprofv3 kernel-trace csv whose answers are known."""
+    import subprocess
+    import sys
+    rows = ["\"Kind\",\"Kernel_Name\",\"Start_Timestamp\",\"End_Timestamp\""]
+    t = 1000000
+    for f in range(6):  # frame period 1 ms: init 0.1 ms, walk 0.5 ms overlapping trace 0.4 ms by 0.2 ms, then 0.2 ms idle
+        rows.append('"KERNEL_DISPATCH","void bdpt::init_paths_kernel<true>(bdpt::SceneDev)",%d,%d' % (t, t + 100000))
+        rows.append('"KERNEL_DISPATCH","void bdpt::walk_kernel<true, false, false>(bdpt::SceneDev)",%d,%d' % (t + 100000, t + 600000))
+        rows.append('"KERNEL_DISPATCH","void bdpt::trace_shadow_kernel<false>(bdpt::SceneDev)",%d,%d' % (t + 400000, t + 800000))
+        t += 1000000
+    p = tmp_path / "trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "timeline_summary.py"), str(p), "4"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert "wall 1.000 ms per frame" in r.stdout and "busy (union of kernels) 0.800 ms per frame = 80.0 %" in r.stdout and "idle 0.200 ms" in r.stdout
+    walk = [ln for ln in r.stdout.splitlines() if ln.startswith("walk_kernel")][0].split()
+    assert walk[1:] == ["1.00", "0.500", "500.0", "0.300"]  # launches, sum ms/frame, mean us, alone ms/frame

@@ -379,3 +379,21 @@ def test_exported_scene_frame_matches_oracle_and_the_in_memory_scene(pkg, ob, ex
     # the two frames are different noise realisations of (nearly) the same image — compare what is stable, the means
     ma, mb = frames["memory"][..., :3].mean(), frames["loaded"][..., :3].mean()
     assert abs(ma - mb) < 0.05 * ma, (float(ma), float(mb))
+
+
+@pytest.mark.gpu
+def test_bench_runs_a_supplied_scene_file(pkg, exported_atrium):
+    """`bench.py --scene-file X.fscene`: a supplied asset goes through bdpt_scene_load and the line says so
+    (data "file", the file's name in config.workload) — the switch a real Sponza OBJ would use."""
+    import json
+    import subprocess
+    import sys
+    _, _, _, outdir = exported_atrium
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scene-file", os.path.join(outdir, "scene.fscene"), "--steps", "3", "--warmup", "1",
+                        "--width", "320", "--height", "180", "--depth", "4", "--no-cpu-baseline", "--no-single-pass", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["data"] == "file" and "scene.fscene" in d["config"]["workload"] and "24000 triangles" in d["config"]["workload"]
+    assert d["value"] > 0 and d["roofline"]["pmc_build_match"] is None and d["config"]["visits_per_ray"]["closest_nodes"] > 1

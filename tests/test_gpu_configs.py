@@ -53,6 +53,22 @@ def test_config3_textured_ggx_depth8_matches_oracle(pkg, ob):
     scene.close()
 
 
+def test_heavy_tailed_atrium_matches_oracle(pkg, ob):
+    """The stress variant of the stand-in (bdpt_scene_create_atrium_uneven: two-triangle walls and floors of up to
+    180 m^2 beside ornaments of square millimetres, bench.py's "stress" line): a tree with leaves six decades apart in
+    size answers every query as the oracle's own tree does — frames bit-identical at depth 6, both material models."""
+    import torch
+    scene = pkg.Scene.atrium_uneven(1, 60000)
+    for mat in (0, 1):
+        pipe = pkg.FramePipeline(scene, 128, 72, max_depth=6, mat_index=mat)
+        gp, p = pipe.render_frame()
+        torch.cuda.synchronize()
+        c, _ = _assert_frame_equals_oracle(pkg, ob, scene, pipe, gp, p, f"uneven atrium mat {mat}")
+        assert c["pixelsValid"] > 0.5 * 128 * 72
+        pipe.close()
+    scene.close()
+
+
 def test_config3_bench_frame_bands_equal_full_frame(pkg):
     """configs[2] at full size — exactly the frame bench.py times (1920x1080, depth 8, 262,144 triangles)."""
     scene = pkg.Scene.atrium(1, 262144)

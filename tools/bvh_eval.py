@@ -56,7 +56,8 @@ def main():
     ap.add_argument("--rays", type=int, default=100000)
     ap.add_argument("--variants", default="0,0,0;-1,-1,1")
     args = ap.parse_args()
-    scene = pkg.Scene.courtyard(2, args.triangles, args.foliage) if args.scene == "courtyard" else pkg.Scene.atrium(1, args.triangles)
+    scene = (pkg.Scene.courtyard(2, args.triangles, args.foliage) if args.scene == "courtyard" else
+             pkg.Scene.atrium_uneven(1, args.triangles) if args.scene == "atrium_uneven" else pkg.Scene.atrium(1, args.triangles))
     cam = scene.camera(16 / 9)
     rng = np.random.default_rng(7)
     ref = None

@@ -592,180 +592,6 @@ uint32_t splitTriangle(const SplitGrid& G, const BvhTri& r, uint32_t t, const Pi
   return made;
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Insertion-based optimisation of the finished binary tree (after Bittner, Hapala, Havran, "Fast insertion-based
-// optimization of bounding volume hierarchies", CGF 2013): a top-down builder decides every split with what it sees
-// at that node; afterwards, the nodes that cost most for what they hold are taken out — the node and its parent
-// removed, its two subtrees put back where they add the least surface area (a branch-and-bound search from the
-// root) — for a number of passes.  Leaves are not touched, so the references, their order and every query's answer
-// stay what they were; what changes is how many boxes a ray meets on its way.  Sequential and deterministic.
-// The binary height stays within the traversal stack's budget (an insertion that would exceed it is not considered).
-// ------------------------------------------------------------------------------------------------
-void optimizeByReinsertion(BigVec<TmpNode>& tmp, const BvhBuildOptions& opt, int threads) {
-  (void)threads;
-  const char* e = std::getenv("BDPT_REINSERT_PASSES");
-  const int passes = e ? std::atoi(e) : 0;
-  const char* eb = std::getenv("BDPT_REINSERT_BATCH");
-  const double batchFrac = eb ? std::atof(eb) : 0.01;
-  (void)opt;
-  const size_t N = tmp.size();
-  if (passes <= 0 || N < 64) return;
-  std::vector<int32_t> parent(N, -1);
-  std::vector<uint8_t> height(N, 0);
-  for (size_t t = N; t-- > 0;)
-    if (tmp[t].left >= 0) {
-      parent[(size_t)tmp[t].left] = (int32_t)t;
-      parent[(size_t)tmp[t].right] = (int32_t)t;
-      height[t] = (uint8_t)(1 + std::max(height[(size_t)tmp[t].left], height[(size_t)tmp[t].right]));
-    }
-  auto areaOf = [&](int32_t i) { return tmp[(size_t)i].box.area(); };
-  auto unionArea = [](const Box& a, const Box& b) {
-    Box u = a;
-    u.grow(b);
-    return u.area();
-  };
-  auto refit = [&](int32_t i) {  // boxes and heights from node i up to the root
-    while (i >= 0) {
-      TmpNode& nd = tmp[(size_t)i];
-      Box b = tmp[(size_t)nd.left].box;
-      b.grow(tmp[(size_t)nd.right].box);
-      nd.box = b;
-      height[(size_t)i] = (uint8_t)(1 + std::max(height[(size_t)nd.left], height[(size_t)nd.right]));
-      i = parent[(size_t)i];
-    }
-  };
-  auto depthOf = [&](int32_t i) {
-    int d = 0;
-    while (parent[(size_t)i] >= 0) {
-      i = parent[(size_t)i];
-      d++;
-    }
-    return d;
-  };
-  struct QE {
-    float induced;
-    int32_t node;
-    int depth;
-    bool operator<(const QE& o) const { return induced > o.induced || (induced == o.induced && node > o.node); }  // min-heap
-  };
-  std::vector<QE> heap;
-  const int maxDepth = kBinaryMaxDepth - 1;
-  // best node to become the sibling of subtree X (box xb, height hx)
-  auto findBest = [&](const Box& xb, int hx) {
-    const float xa = xb.area();
-    float bestCost = 1e30f;
-    int32_t best = -1;
-    heap.clear();
-    heap.push_back(QE{0.0f, 0, 0});
-    while (!heap.empty()) {
-      std::pop_heap(heap.begin(), heap.end());
-      const QE q = heap.back();
-      heap.pop_back();
-      if (q.induced + xa >= bestCost) break;  // nothing below can beat the best (lower bound)
-      const TmpNode& y = tmp[(size_t)q.node];
-      const float direct = unionArea(y.box, xb);
-      // the new node sits at depth q.depth; X and Y below it at q.depth + 1
-      const bool fits = q.node != 0 && q.depth + 1 + std::max(hx, (int)height[(size_t)q.node]) <= maxDepth;  // (the root stays the root)
-      if (fits && q.induced + direct < bestCost) {
-        bestCost = q.induced + direct;
-        best = q.node;
-      }
-      if (y.left >= 0) {
-        const float ci = q.induced + (direct - y.box.area());
-        if (ci + xa < bestCost) {
-          heap.push_back(QE{ci, y.left, q.depth + 1});
-          std::push_heap(heap.begin(), heap.end());
-          heap.push_back(QE{ci, y.right, q.depth + 1});
-          std::push_heap(heap.begin(), heap.end());
-        }
-      }
-    }
-    return best;
-  };
-  std::vector<std::pair<float, int32_t>> cand;
-  std::vector<uint8_t> touched(N, 0);
-  for (int pass = 0; pass < passes; pass++) {
-    cand.clear();
-    for (size_t t = 1; t < N; t++) {
-      const TmpNode& nd = tmp[t];
-      if (nd.left < 0 || parent[t] <= 0) continue;  // leaves, the root's children: not candidates
-      const float a = nd.box.area(), al = areaOf(nd.left), ar = areaOf(nd.right);
-      const float mmin = std::min(al, ar);
-      const float m = a * (a / std::max(0.5f * (al + ar), 1e-30f)) * (a / std::max(mmin, 1e-30f));  // M_area * M_sum * M_min
-      cand.push_back({m, (int32_t)t});
-    }
-    const size_t take = std::max<size_t>(1, (size_t)((double)cand.size() * batchFrac));
-    std::partial_sort(cand.begin(), cand.begin() + (long)std::min(take, cand.size()), cand.end(),
-                      [](const std::pair<float, int32_t>& a, const std::pair<float, int32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
-    std::fill(touched.begin(), touched.end(), 0);
-    for (size_t c = 0; c < std::min(take, cand.size()); c++) {
-      const int32_t n = cand[c].second;
-      const int32_t p = parent[(size_t)n];
-      if (p <= 0 || touched[(size_t)n] || touched[(size_t)p]) continue;
-      const int32_t g = parent[(size_t)p];
-      const int32_t sib = tmp[(size_t)p].left == n ? tmp[(size_t)p].right : tmp[(size_t)p].left;
-      int32_t sub[2] = {tmp[(size_t)n].left, tmp[(size_t)n].right};
-      if (areaOf(sub[0]) < areaOf(sub[1])) std::swap(sub[0], sub[1]);  // the larger subtree first
-      // take n and p out: the sibling moves up
-      if (tmp[(size_t)g].left == p)
-        tmp[(size_t)g].left = sib;
-      else
-        tmp[(size_t)g].right = sib;
-      parent[(size_t)sib] = g;
-      refit(g);
-      int32_t freeNode[2] = {n, p};
-      for (int k = 0; k < 2; k++) {
-        const int32_t x = sub[k];
-        int32_t y = findBest(tmp[(size_t)x].box, (int)height[(size_t)x]);
-        if (y < 0) y = sib;  // (no position within the depth budget found: back beside the old sibling's place is always legal)
-        const int32_t nn = freeNode[k];
-        const int32_t py = parent[(size_t)y];
-        TmpNode& nd = tmp[(size_t)nn];
-        nd.left = y;
-        nd.right = x;
-        nd.count = 0;
-        parent[(size_t)y] = nn;
-        parent[(size_t)x] = nn;
-        parent[(size_t)nn] = py;
-        if (tmp[(size_t)py].left == y)
-          tmp[(size_t)py].left = nn;
-        else
-          tmp[(size_t)py].right = nn;
-        touched[(size_t)nn] = 1;
-        refit(nn);
-      }
-      (void)depthOf;
-    }
-  }
-  // children after parents again (the collapse and the height pass walk the array backwards): depth-first re-index
-  BigVec<TmpNode> out2;
-  out2.reserve(N);
-  std::vector<int32_t> stackIdx;
-  std::vector<std::pair<int32_t, int32_t>> st;  // (old index, new parent index or -1), with side in sign bit of a second vector
-  std::vector<int32_t> newIndex(N, -1);
-  std::vector<std::pair<int32_t, uint32_t>> work;  // (old index, depth)
-  work.push_back({0, 0u});
-  while (!work.empty()) {
-    const auto w = work.back();
-    work.pop_back();
-    newIndex[(size_t)w.first] = (int32_t)out2.size();
-    TmpNode nd = tmp[(size_t)w.first];
-    nd.depth = w.second;
-    out2.push_back(nd);
-    if (nd.left >= 0) {
-      work.push_back({nd.right, w.second + 1});
-      work.push_back({nd.left, w.second + 1});
-    }
-  }
-  for (TmpNode& nd : out2)
-    if (nd.left >= 0) {
-      nd.left = newIndex[(size_t)nd.left];
-      nd.right = newIndex[(size_t)nd.right];
-    }
-  tmp.swap(out2);
-}
-
 }  // namespace
 
 int bvhBuildThreads() {
@@ -1104,8 +930,6 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   }
 
   lap("append");
-  optimizeByReinsertion(tmp, opt, threads);
-  lap("reinsert");
   // Leaf-ordered triangle list.
   out.tris.resize(n);
   out.refBox.resize((size_t)n * 6);

@@ -325,20 +325,19 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
       parallelChunks(count, threads, kPartitionChunk, [&](size_t, size_t a, size_t b) { std::memcpy(base + a, tmp + a, (b - a) * sizeof(Ref)); });
       mid = nLeft;
     } else {
-      // Two-pointer partition (the bidirectional algorithm of std::partition, spelled out so that the permutation is
-      // this file's own definition): every element is tested exactly once, at its original position.
-      Ref* lo_p = base;
-      Ref* hi_p = lo_p + count;
-      for (;;) {
-        while (lo_p != hi_p && goesLeft(*lo_p)) ++lo_p;
-        if (lo_p == hi_p) break;
-        --hi_p;
-        while (lo_p != hi_p && !goesLeft(*hi_p)) --hi_p;
-        if (lo_p == hi_p) break;
-        std::swap(*lo_p, *hi_p);
-        ++lo_p;
+      // Small nodes: the same stable partition by one thread, through the scratch array (the range is the node's own).
+      // One rule for every node size: a builder that partitions in parallel — the passes above, or a device — produces
+      // the very same permutation.
+      Ref* const tmp = B.scratch.data() + first;
+      uint32_t l = 0, r = 0;
+      for (uint32_t k = 0; k < count; k++) {
+        if (goesLeft(base[k]))
+          base[l++] = base[k];  // (l <= k: never overwrites an element not yet read)
+        else
+          tmp[r++] = base[k];
       }
-      mid = (uint32_t)(lo_p - base);
+      std::memcpy(base + l, tmp, (size_t)r * sizeof(Ref));
+      mid = l;
     }
   }
   if (mid == 0 || mid == count) {
@@ -348,7 +347,8 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
     if (e1 > e0 && e1 >= e2) axis = 1;
     if (e2 > e0 && e2 > e1) axis = 2;
     mid = count / 2;
-    std::nth_element(base, base + mid, base + count, [&](const Ref& a, const Ref& b) {
+    // (a full sort, not nth_element: the order inside the halves is then defined, and with it the whole permutation)
+    std::sort(base, base + count, [&](const Ref& a, const Ref& b) {
       return a.cent[axis] < b.cent[axis] || (a.cent[axis] == b.cent[axis] && a.id < b.id);
     });
   }
@@ -864,7 +864,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   }
   const uint32_t n = (uint32_t)refs.size();  // references from here on
   if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
-  BigVec<Ref> scratch(n >= kStablePartitionMin ? n : 0);  // (only nodes of that size partition through it)
+  BigVec<Ref> scratch(n);  // every partition scatters through the node's own range of it
   const BuildData B{refs, scratch};
   lap("records");
 

@@ -336,7 +336,14 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   // traversal flags, alpha classification, spatial pre-splitting and the tree itself: scene_bvh.cpp
   SceneBvh sb;
   try {
-    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb);
+    // the binary tree is built on this context's device (bvh_device.hip): the same tree the host code builds, bit for bit
+    std::string treeError;
+    int treeDevice = c->device;
+    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb, buildBinaryTreeOnDevice, &treeDevice, &treeError);
+    if (!treeError.empty()) {
+      fail(c, "scene: " + treeError);
+      return BDPT_E_HIP;
+    }
   } catch (const std::bad_alloc&) {
     fail(c, "scene: out of host memory while building the acceleration structure");
     return BDPT_E_NOMEM;
@@ -1064,6 +1071,21 @@ int bdpt_accumulate_tile(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_
   ENTER(c);
   launchAccumulateTile(lastFrame, curFrame, accumCount, maxAccumCount, c->P.pix, c->P.Np, reinterpret_cast<hipStream_t>(stream));
   HIPCHK(c, hipGetLastError());
+  return BDPT_OK;
+}
+
+// Test hook: which builder the host-only hash / check hooks (bdpt_bvh_build_hash, bdpt_bvh_build_check, bdpt_host_bvh_*)
+// use for the binary tree: device >= 0 the device implementation on that device, < 0 the host code (the default).
+int bdpt_test_tree_builder(int device) {
+  static int sDevice = 0;
+  if (device < 0) {
+    bvhSetDefaultTreeBuilder(nullptr, nullptr);
+    return BDPT_OK;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return BDPT_E_HIP;
+  sDevice = device;
+  bvhSetDefaultTreeBuilder(buildBinaryTreeOnDevice, &sDevice);
   return BDPT_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -166,6 +167,69 @@ struct BvhRefClipper {
   virtual bool clip(uint32_t tri, double (*poly)[2], int& n) const = 0;
 };
 
+// ---- what the binary-tree stage of the builder works on (bvh_build.cpp on the host, bvh_device.hip on the device) ----
+#ifndef BDPT_SAH_BINS
+#define BDPT_SAH_BINS 16
+#endif
+#ifndef BDPT_LEAF_MAX
+#define BDPT_LEAF_MAX 2
+#endif
+constexpr int kBvhBins = BDPT_SAH_BINS;           // SAH bins per axis
+constexpr uint32_t kBvhLeafMax = BDPT_LEAF_MAX;   // references per leaf, at most 8 (three count bits in a leaf reference)
+constexpr int kBvhBinaryMaxDepth = kBvhMaxStack;  // depth budget of the binary tree: a two-wide path stacks one reference per level
+struct BvhBox {
+  float lo[3], hi[3];
+  // (host-side helpers; the device code of bvh_device.hip spells the same arithmetic out itself)
+  void reset() {
+    lo[0] = lo[1] = lo[2] = 1e30f;
+    hi[0] = hi[1] = hi[2] = -1e30f;
+  }
+  void grow(const BvhBox& b) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = b.lo[a] < lo[a] ? b.lo[a] : lo[a];  // std::min(lo, b.lo)
+      hi[a] = hi[a] < b.hi[a] ? b.hi[a] : hi[a];  // std::max(hi, b.hi)
+    }
+  }
+  void grow(const float* p) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = p[a] < lo[a] ? p[a] : lo[a];
+      hi[a] = hi[a] < p[a] ? p[a] : hi[a];
+    }
+  }
+  float area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+  }
+};
+// One reference: the box of the piece it stands for, the box's centre, its index in the reference list.  The
+// records themselves are permuted as nodes are partitioned; a node owns a contiguous range.
+struct BvhBuildRef {
+  BvhBox box;
+  float cent[3];
+  uint32_t id;
+};
+static_assert(sizeof(BvhBuildRef) == 40, "reference record");
+struct BvhBuildNode {  // (no member initialisers: arrays of these are sized without being touched)
+  BvhBox box;
+  int32_t left, right;    // children (indices into the node list, always behind their parent) or -1
+  uint32_t first, count;  // leaf: its range of the reference array
+  uint32_t depth;
+};
+static_assert(sizeof(BvhBuildNode) == 44, "binary node");
+// Builds the binary tree over refs[0, n) — binned SAH, stable partitions, median fallback: the decisions, the order of the
+// references and the tree of bvh_build.cpp's host code, bit for bit — somewhere else (bdpt_set_scene plugs in the device
+// implementation, bvh_device.hip).  `refs` stays as it is; order[i] is the reference (its index = its id) at position i
+// of the leaf order the nodes' ranges speak of.  nodes[0] is the root; children come after their parents.  false + err
+// on failure.
+using BvhTreeBuilder = bool (*)(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
+// Test hook: the tree builder buildBvh uses when its options name none (null = the host code).  bdpt_test_tree_builder
+// (api.cpp) points it at the device implementation so that the host-only hash / check hooks can be run over a
+// device-built tree and compared with the host-built one.
+void bvhSetDefaultTreeBuilder(BvhTreeBuilder f, void* user);
+// the device implementation (bvh_device.hip); `user` points at the device ordinal (int)
+bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
+
 struct BvhBuildOptions {
   int threads = 0;                // <= 0: bvhBuildThreads()
   // Spatial pre-splitting (bvh_build.cpp "References"): extra references the builder may create, as a fraction of the
@@ -173,6 +237,9 @@ struct BvhBuildOptions {
   float splitBudget = -1.0f;      // < 0: the build default (BDPT_SPLIT_BUDGET)
   float splitBudgetAlpha = -1.0f; // < 0: the build default (BDPT_SPLIT_BUDGET_ALPHA)
   const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
+  BvhTreeBuilder treeBuilder = nullptr;    // null: the host code builds the binary tree
+  void* treeBuilderUser = nullptr;
+  std::string* error = nullptr;            // receives the tree builder's message when it fails (the build then has no nodes)
 };
 
 // positions: 3 floats per vertex; indices: 3 per triangle; triFlags: per triangle (may be null).

@@ -23,37 +23,8 @@
 namespace bdpt {
 namespace {
 
-struct Box {
-  float lo[3], hi[3];
-  void reset() {
-    lo[0] = lo[1] = lo[2] = 1e30f;
-    hi[0] = hi[1] = hi[2] = -1e30f;
-  }
-  void grow(const Box& b) {
-    for (int a = 0; a < 3; a++) {
-      lo[a] = std::min(lo[a], b.lo[a]);
-      hi[a] = std::max(hi[a], b.hi[a]);
-    }
-  }
-  void grow(const float* p) {
-    for (int a = 0; a < 3; a++) {
-      lo[a] = std::min(lo[a], p[a]);
-      hi[a] = std::max(hi[a], p[a]);
-    }
-  }
-  float area() const {
-    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-    if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
-    return 2.0f * (dx * dy + dy * dz + dz * dx);
-  }
-};
-
-struct TmpNode {  // (no member initialisers: arrays of these are sized without being touched, bvh.h BigVec)
-  Box box;
-  int32_t left, right;    // children (tmp indices) or -1
-  uint32_t first, count;  // leaf range in `order`
-  uint32_t depth;
-};
+using Box = BvhBox;            // bvh.h: shared with the device-side tree builder
+using TmpNode = BvhBuildNode;  // the binary tree: children always behind their parent
 inline TmpNode makeTmpNode(uint32_t first, uint32_t count, uint32_t depth) {
   TmpNode n;
   n.box.reset();
@@ -93,16 +64,16 @@ inline TmpNode makeTmpNode(uint32_t first, uint32_t count, uint32_t depth) {
 #ifndef BDPT_SPLIT_MAX_PER_TRI
 #define BDPT_SPLIT_MAX_PER_TRI 255
 #endif
-constexpr int kBins = BDPT_SAH_BINS;
+constexpr int kBins = kBvhBins;
 constexpr uint32_t kStablePartitionMin = 1u << 16;  // nodes of at least this many references are partitioned stably, in parallel
 constexpr size_t kPartitionChunk = 1u << 14;
 constexpr uint32_t kCollapseGrain = 1u << 15;  // binary subtrees of at most this many nodes are collapsed to four-wide nodes by one worker each
 // Leaves hold at most two triangles.  Measured on the bench frame (profiles/README.md r2): leaves of <= 1 / 2 / 3 / 4 / 8
 // triangles give 23.6 / 19.1 / 19.5 / 20.1 / 23.0 ms per frame — a triangle test costs half a node visit and leaf runs of
 // different lengths idle lanes, while one-triangle leaves double the node array past the 4 MiB L2 of an XCD.
-constexpr uint32_t kLeafMax = BDPT_LEAF_MAX;  // at most 8 (three count bits in a leaf reference)
+constexpr uint32_t kLeafMax = kBvhLeafMax;
 constexpr float kCostTraverse = 1.0f, kCostTri = 1.0f;
-constexpr int kBinaryMaxDepth = kBvhMaxStack;  // depth budget of the intermediate binary tree: a two-wide path stacks one reference per level, so the device stack bounds it (a budget of 48 let a 10 M-triangle scene of overlapping cards through that bdpt_set_scene then had to refuse)
+constexpr int kBinaryMaxDepth = kBvhBinaryMaxDepth;  // depth budget of the intermediate binary tree: a two-wide path stacks one reference per level, so the device stack bounds it (a budget of 48 let a 10 M-triangle scene of overlapping cards through that bdpt_set_scene then had to refuse)
 
 inline uint32_t ceilLog2(uint32_t x) {
   uint32_t l = 0;
@@ -156,12 +127,7 @@ void parallelChunks(size_t n, int threads, size_t chunk, const F& f) {
 // before, an index array was permuted and every scan of a node gathered boxes and centres through it): every pass over
 // a node — bounds, binning, the partition — then streams a contiguous range instead of gathering 36 bytes per element
 // from a gigabyte of boxes, which is what bounded the builder on 16 host threads.
-struct Ref {
-  Box box;
-  float cent[3];
-  uint32_t id;
-};
-static_assert(sizeof(Ref) == 40, "reference record");
+using Ref = BvhBuildRef;
 
 struct BuildData {
   BigVec<Ref>& refs;     // permuted in place: a node owns a contiguous range
@@ -594,6 +560,13 @@ uint32_t splitTriangle(const SplitGrid& G, const BvhTri& r, uint32_t t, const Pi
 
 }  // namespace
 
+static BvhTreeBuilder gDefaultTreeBuilder = nullptr;
+static void* gDefaultTreeBuilderUser = nullptr;
+void bvhSetDefaultTreeBuilder(BvhTreeBuilder f, void* user) {
+  gDefaultTreeBuilder = f;
+  gDefaultTreeBuilderUser = user;
+}
+
 int bvhBuildThreads() {
   if (const char* e = std::getenv("BDPT_BUILD_THREADS")) {
     const int v = std::atoi(e);
@@ -847,8 +820,11 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         const RefOut& o = part[ci];
         for (size_t j = 0; j < o.tri.size(); j++) {
           Ref& r = refs[at[ci] + j];
-          r.box = o.boxes[j];
-          for (int k = 0; k < 3; k++) r.cent[k] = 0.5f * (o.boxes[j].lo[k] + o.boxes[j].hi[k]);
+          for (int k = 0; k < 3; k++) {  // (+ 0.0f: -0 becomes +0, so that no minimum or maximum depends on the order in which equal zeros meet)
+            r.box.lo[k] = o.boxes[j].lo[k] + 0.0f;
+            r.box.hi[k] = o.boxes[j].hi[k] + 0.0f;
+            r.cent[k] = 0.5f * (r.box.lo[k] + r.box.hi[k]) + 0.0f;
+          }
           r.id = (uint32_t)(at[ci] + j);
           refTri[at[ci] + j] = o.tri[j];
         }
@@ -864,19 +840,37 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   }
   const uint32_t n = (uint32_t)refs.size();  // references from here on
   if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
-  BigVec<Ref> scratch(n);  // every partition scatters through the node's own range of it
+  BigVec<TmpNode> tmp;
+  BigVec<uint32_t> order;  // filled by a plugged-in tree builder: the leaf order as reference ids (the host code permutes `refs` itself)
+  const BvhTreeBuilder treeBuilder = opt.treeBuilder ? opt.treeBuilder : gDefaultTreeBuilder;
+  void* const treeBuilderUser = opt.treeBuilder ? opt.treeBuilderUser : gDefaultTreeBuilderUser;
+  const bool plugged = treeBuilder && n > 0;
+  BigVec<Ref> scratch(plugged ? 0 : n);  // every partition scatters through the node's own range of it
   const BuildData B{refs, scratch};
   lap("records");
-
-  // Phase 1: one thread splits the top of the tree (large nodes share their scans among all threads) and
-  // defers every subtree of at most `grain` triangles.  Phase 2: the deferred subtrees are built concurrently,
-  // largest first, each into its own node list.  Phase 3: the lists are appended; children stay after parents.
-  BigVec<TmpNode> tmp;
-  tmp.reserve((size_t)n / 2 + 16);
-  tmp.push_back(makeTmpNode(0, n, 0));
-  if (threads <= 1 || n < (1u << 15)) {
+  if (plugged) {
+    // the binary tree is built elsewhere (bdpt_set_scene: on the device, bvh_device.hip) — the same decisions, the same
+    // order of the references, the same tree as the host code below; children come after their parents there too
+    std::string err;
+    if (!treeBuilder(treeBuilderUser, refs.data(), n, order, tmp, err) || tmp.empty() || order.size() != n) {
+      if (opt.error) *opt.error = err.empty() ? "tree builder failed" : err;
+      out.nodes.clear();
+      out.tris.clear();
+      out.refBox.clear();
+      out.recs.clear();
+      return;
+    }
+    lap("device tree");
+  } else if (threads <= 1 || n < (1u << 15)) {
+    // The host code.  Phase 1: one thread splits the top of the tree (large nodes share their scans among all threads)
+    // and defers every subtree of at most `grain` triangles.  Phase 2: the deferred subtrees are built concurrently,
+    // largest first, each into its own node list.  Phase 3: the lists are appended; children stay after parents.
+    tmp.reserve((size_t)n / 2 + 16);
+    tmp.push_back(makeTmpNode(0, n, 0));
     buildSubtree(B, tmp, 0, 0, 1, nullptr);
   } else {
+    tmp.reserve((size_t)n / 2 + 16);
+    tmp.push_back(makeTmpNode(0, n, 0));
     const uint32_t grain = std::max<uint32_t>(4096, n / (uint32_t)(threads * 8));
     std::vector<uint32_t> deferred;
     buildSubtree(B, tmp, 0, grain, threads, &deferred);
@@ -935,10 +929,11 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   out.refBox.resize((size_t)n * 6);
   parallelFor(n, threads, [&](size_t a, size_t b, int) {
     for (size_t i = a; i < b; i++) {
-      out.tris[i] = recs[refTri[refs[i].id]];
+      const Ref& r = plugged ? refs[order[i]] : refs[i];
+      out.tris[i] = recs[refTri[r.id]];
       for (int k = 0; k < 3; k++) {
-        out.refBox[i * 6 + (size_t)k] = refs[i].box.lo[k];
-        out.refBox[i * 6 + 3 + (size_t)k] = refs[i].box.hi[k];
+        out.refBox[i * 6 + (size_t)k] = r.box.lo[k];
+        out.refBox[i * 6 + 3 + (size_t)k] = r.box.hi[k];
       }
     }
   });

@@ -1,0 +1,983 @@
+// bvh_device.hip — the binary-tree stage of the acceleration-structure build ON THE DEVICE.
+//
+// Replaces what the reference leaves to the DXR driver on the GPU as well — BLAS / TLAS builds issued by
+// Falcor/Framework/Source/Raytracing/RtModel.cpp:181-254 and RtScene.cpp:220-308 — for the part of this build that is
+// data-parallel over the references: the binned-SAH binary tree.  (The references themselves — alpha classification,
+// pre-splitting, clipping — and the four-wide collapse / quantisation / packing stay on the host: bvh_build.cpp.)
+//
+// Level-synchronous: every level of the tree is a handful of flat launches over all n references —
+//   bounds   node box + centroid box per active node            (ordered-uint atomics, wave-aggregated)
+//   prepare  leaf / forced-median / split candidate; bin grid   (one thread per node)
+//   bin      3 x 16 bins per candidate: box + count             (atomics)
+//   decide   the SAH sweep of bvh_build.cpp splitNode           (one thread per node, the same float operations in the same order)
+//   flags -> exclusive scan -> stable partition scatter         (lefts in their order, then rights in theirs)
+//   children two nodes per split node, in slot order
+// — and produces, bit for bit, the permutation of the references and the tree the host code produces (one partition
+// rule there too: bvh_build.cpp), so everything downstream, the packed records and the statistics of every query are
+// the same; tests/test_gpu_configs.py compares the two builders' hashes.  Median fallback (no useful SAH split, or the
+// depth budget): the node's range is sorted by (centroid, reference id) — by one wave for up to kMedianWave
+// references, on the host beyond that (it happens on degenerate inputs only).
+// Float min / max through atomics on an order-preserving uint encoding: exact, order-independent.  The host turns -0
+// into +0 when it makes the references, so no box component depends on the order in which equal zeros met.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bvh.h"
+
+namespace bdpt {
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+// Slots of at most kSmall references are handled by one wave each (k_small: bounds, bins in LDS, the sweep — no atomics
+// on memory); larger ones by the flat launches over the references.  The slot number a reference carries has
+// kSmallBit set when its slot is a small one (kNone has it too: "nothing here for the flat launches").
+constexpr uint32_t kSmall = 1024, kSmallBit = 0x80000000u;
+constexpr uint32_t kMedianWave = 2048;  // median-fallback nodes up to this many references are sorted by one wave
+enum : uint32_t { ST_LEAF = 0u, ST_SPLIT = 1u, ST_MEDIAN = 2u };
+constexpr int kBinWords = 7;  // lo3 hi3 (encoded) + count
+
+#define BDV __device__ __forceinline__
+BDV uint32_t enc(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+BDV float dec(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+BDV float areaOf(const float* lo, const float* hi) {  // BvhBox::area
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+BDV uint32_t ceilLog2(uint32_t x) {
+  uint32_t l = 0;
+  while ((1u << l) < x) l++;
+  return l;
+}
+
+// The bins of a large slot: ranges of more than kSmall references are disjoint, so first / (kSmall + 1) is unique.
+BDV size_t binsOf(uint32_t first) { return (size_t)(first / (kSmall + 1)) * 3 * kBvhBins * kBinWords; }
+
+// One level's active nodes ("slots").  Two of these ping-pong.
+struct Level {
+  uint32_t* node;    // tree node index of the slot
+  uint32_t* first;   // its range of the reference array
+  uint32_t* count;
+  uint32_t* depth;
+  uint32_t* state;   // ST_*
+  uint32_t* bnd;     // 12 encoded floats per slot: node box lo3 hi3, centroid box lo3 hi3
+  float* lo;         // 3 per slot: bin grid origin per axis (centroid box lo)
+  float* scale;      // 3 per slot: kBins / extent, 0 where the axis is not used
+  uint32_t* axis;    // SPLIT: best axis
+  uint32_t* maxis;   // the median fallback's axis: the widest centroid axis
+  uint32_t* split;   // SPLIT: last bin of the left side
+  uint32_t* nLeft;
+  uint32_t* sorted;  // MEDIAN: range already sorted
+  uint32_t* child;   // slot of the left child in the next level (right = +1)
+};
+
+struct Tree {  // node arrays (struct of arrays), capacity 2n
+  float* box;  // 6 per node
+  int32_t* left;
+  int32_t* right;
+  uint32_t* first;
+  uint32_t* count;
+  uint32_t* depth;
+};
+
+struct Counters {
+  uint32_t numSplit;       // slots that get two children this level
+  uint32_t numMedianNew;   // MEDIAN slots whose range is not sorted yet
+  uint32_t numMedianBig;   // of those: too large for the wave sort
+  uint32_t pad;
+};
+
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_init_root(Level L, Tree T, uint32_t n) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  L.node[0] = 0;
+  L.first[0] = 0;
+  L.count[0] = n;
+  L.depth[0] = 0;
+  for (int j = 0; j < 12; j++) L.bnd[j] = ((j % 6) < 3) ? enc(1e30f) : enc(-1e30f);
+  T.left[0] = -1;
+  T.right[0] = -1;
+  T.first[0] = 0;
+  T.count[0] = n;
+  T.depth[0] = 0;
+}
+
+// A block of the flat launches over the references covers kChunk consecutive ones.  Near the root a slot's range spans
+// many blocks, and all of a block's atomics would meet on the same few words: so a block first reduces, among its own
+// references, those of ONE large slot — that of its first reference that has one — in registers / LDS, and only the
+// result goes to memory; references of other large slots (range borders) go straight there.
+constexpr uint32_t kChunkPer = 8, kChunk = 256 * kChunkPer;
+BDV uint32_t blockSlot(const uint32_t* __restrict__ nodeOf, uint32_t base, uint32_t n, uint32_t* sFirst) {
+  if (threadIdx.x == 0) *sFirst = kNone;
+  __syncthreads();
+  for (uint32_t j = 0; j < kChunkPer; j++) {  // (stops at the first round that finds one: the rounds are in index order)
+    const uint32_t k = base + j * 256 + threadIdx.x;
+    if (k < n && !(nodeOf[k] & kSmallBit)) atomicMin(sFirst, k - base);
+    __syncthreads();
+    const uint32_t f = *sFirst;
+    __syncthreads();  // (nobody starts the next round's atomics before everybody has read this round's result)
+    if (f != kNone) return nodeOf[base + f];
+  }
+  return kNone;
+}
+
+// node box and centroid box of every active node
+__global__ __launch_bounds__(256) void k_bounds(const BvhBuildRef* __restrict__ refs, const uint32_t* __restrict__ nodeOf, uint32_t n, Level L) {
+  __shared__ uint32_t sFirst;
+  const uint32_t base = blockIdx.x * kChunk;
+  const uint32_t a0 = blockSlot(nodeOf, base, n, &sFirst);
+  if (a0 == kNone) return;
+  float v[12];
+  for (int j = 0; j < 12; j++) v[j] = ((j % 6) < 3) ? 1e30f : -1e30f;
+  bool any = false;
+  for (uint32_t i = 0; i < kChunkPer; i++) {
+    const uint32_t k = base + i * 256 + threadIdx.x;
+    if (k >= n) break;
+    const uint32_t a = nodeOf[k];
+    if (a & kSmallBit) continue;
+    const BvhBuildRef r = refs[k];
+    if (a == a0) {
+      any = true;
+      for (int j = 0; j < 3; j++) {
+        v[j] = fminf(v[j], r.box.lo[j]);
+        v[3 + j] = fmaxf(v[3 + j], r.box.hi[j]);
+        v[6 + j] = fminf(v[6 + j], r.cent[j]);
+        v[9 + j] = fmaxf(v[9 + j], r.cent[j]);
+      }
+    } else {
+      uint32_t* b = L.bnd + (size_t)a * 12;
+      for (int j = 0; j < 3; j++) {
+        atomicMin(&b[j], enc(r.box.lo[j]));
+        atomicMax(&b[3 + j], enc(r.box.hi[j]));
+        atomicMin(&b[6 + j], enc(r.cent[j]));
+        atomicMax(&b[9 + j], enc(r.cent[j]));
+      }
+    }
+  }
+  if (__ballot(any) == 0ull) return;
+  for (int j = 0; j < 12; j++) {
+    float x = v[j];
+    for (int off = 32; off > 0; off >>= 1) {
+      const float y = __shfl_xor(x, off);
+      x = ((j % 6) < 3) ? fminf(x, y) : fmaxf(x, y);
+    }
+    v[j] = x;
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    uint32_t* b = L.bnd + (size_t)a0 * 12;
+    for (int j = 0; j < 12; j++) {
+      if ((j % 6) < 3)
+        atomicMin(&b[j], enc(v[j]));
+      else
+        atomicMax(&b[j], enc(v[j]));
+    }
+  }
+}
+
+// per slot: the node's box goes to the tree; leaf / forced median / split candidate; the bin grid (splitNode)
+__global__ void k_prepare(Level L, Tree T, uint32_t nA, Counters* C, uint32_t* __restrict__ bins) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA || L.count[a] <= kSmall) return;
+  const uint32_t* b = L.bnd + (size_t)a * 12;
+  float nb[6], cb[6];
+  for (int j = 0; j < 6; j++) {
+    nb[j] = dec(b[j]);
+    cb[j] = dec(b[6 + j]);
+  }
+  const uint32_t node = L.node[a], count = L.count[a], depth = L.depth[a];
+  for (int j = 0; j < 6; j++) T.box[(size_t)node * 6 + j] = nb[j];
+  L.sorted[a] = 0;
+  L.nLeft[a] = 0;
+  L.child[a] = kNone;
+  if (count <= kBvhLeafMax) {
+    L.state[a] = ST_LEAF;
+    return;
+  }
+  const bool forceMedian = depth + ceilLog2((count + kBvhLeafMax - 1) / kBvhLeafMax) + 1 >= (uint32_t)kBvhBinaryMaxDepth;
+  for (int axis = 0; axis < 3; axis++) {
+    const float ext = cb[3 + axis] - cb[axis];
+    L.lo[(size_t)a * 3 + axis] = cb[axis];
+    L.scale[(size_t)a * 3 + axis] = (ext > 0.0f) ? (float)kBvhBins / ext : 0.0f;
+  }
+  // the median fallback's axis: the widest centroid axis (splitNode)
+  int maxis = 0;
+  const float e0 = cb[3] - cb[0], e1 = cb[4] - cb[1], e2 = cb[5] - cb[2];
+  if (e1 > e0 && e1 >= e2) maxis = 1;
+  if (e2 > e0 && e2 > e1) maxis = 2;
+  L.axis[a] = (uint32_t)maxis;
+  L.maxis[a] = (uint32_t)maxis;
+  L.split[a] = 0;
+  if (forceMedian) {
+    L.state[a] = ST_MEDIAN;
+    atomicAdd(&C->numMedianNew, 1u);
+    if (count > kMedianWave) atomicAdd(&C->numMedianBig, 1u);
+  } else {
+    L.state[a] = ST_SPLIT;
+    uint32_t* w = bins + binsOf(L.first[a]);
+    for (int i = 0; i < 3 * kBvhBins * kBinWords; i++) {
+      const int j = i % kBinWords;
+      w[i] = j < 3 ? enc(1e30f) : (j < 6 ? enc(-1e30f) : 0u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bin(const BvhBuildRef* __restrict__ refs, const uint32_t* __restrict__ nodeOf, uint32_t n, Level L,
+                                             uint32_t* __restrict__ bins) {
+  __shared__ uint32_t sFirst;
+  __shared__ uint32_t sBins[3 * kBvhBins * kBinWords];
+  const uint32_t base = blockIdx.x * kChunk;
+  uint32_t a0 = blockSlot(nodeOf, base, n, &sFirst);
+  if (a0 == kNone) return;
+  for (uint32_t i = threadIdx.x; i < 3 * kBvhBins * kBinWords; i += 256) {
+    const uint32_t j = i % kBinWords;
+    sBins[i] = j < 3 ? enc(1e30f) : (j < 6 ? enc(-1e30f) : 0u);
+  }
+  __syncthreads();
+  float lo0[3], sc0[3];
+  const bool split0 = L.state[a0] == ST_SPLIT;
+  for (int axis = 0; axis < 3; axis++) {
+    lo0[axis] = L.lo[(size_t)a0 * 3 + axis];
+    sc0[axis] = split0 ? L.scale[(size_t)a0 * 3 + axis] : 0.0f;
+  }
+  for (uint32_t i = 0; i < kChunkPer; i++) {
+    const uint32_t k = base + i * 256 + threadIdx.x;
+    if (k >= n) break;
+    const uint32_t a = nodeOf[k];
+    if (a & kSmallBit) continue;
+    if (a == a0) {
+      if (!split0) continue;
+      const BvhBuildRef r = refs[k];
+      for (int axis = 0; axis < 3; axis++) {
+        if (!(sc0[axis] > 0.0f)) continue;  // (use[axis] = ext > 0)
+        int bi = (int)((r.cent[axis] - lo0[axis]) * sc0[axis]);
+        bi = bi < 0 ? 0 : (bi > kBvhBins - 1 ? kBvhBins - 1 : bi);
+        uint32_t* w = sBins + (axis * kBvhBins + bi) * kBinWords;
+        for (int j = 0; j < 3; j++) {
+          atomicMin(&w[j], enc(r.box.lo[j]));
+          atomicMax(&w[3 + j], enc(r.box.hi[j]));
+        }
+        atomicAdd(&w[6], 1u);
+      }
+    } else {
+      if (L.state[a] != ST_SPLIT) continue;
+      const BvhBuildRef r = refs[k];
+      for (int axis = 0; axis < 3; axis++) {
+        const float sc = L.scale[(size_t)a * 3 + axis];
+        if (!(sc > 0.0f)) continue;
+        int bi = (int)((r.cent[axis] - L.lo[(size_t)a * 3 + axis]) * sc);
+        bi = bi < 0 ? 0 : (bi > kBvhBins - 1 ? kBvhBins - 1 : bi);
+        uint32_t* w = bins + binsOf(L.first[a]) + ((size_t)axis * kBvhBins + (size_t)bi) * kBinWords;
+        for (int j = 0; j < 3; j++) {
+          atomicMin(&w[j], enc(r.box.lo[j]));
+          atomicMax(&w[3 + j], enc(r.box.hi[j]));
+        }
+        atomicAdd(&w[6], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (!split0) return;
+  uint32_t* g = bins + binsOf(L.first[a0]);
+  for (uint32_t i = threadIdx.x; i < 3 * kBvhBins * kBinWords; i += 256) {
+    const uint32_t j = i % kBinWords;
+    if (sBins[i - j + 6] == 0u) continue;  // empty bin
+    if (j < 3)
+      atomicMin(&g[i], sBins[i]);
+    else if (j < 6)
+      atomicMax(&g[i], sBins[i]);
+    else
+      atomicAdd(&g[i], sBins[i]);
+  }
+}
+
+// One wave per small slot: what k_bounds, k_prepare, k_bin and k_decide do for the large ones — the same values (minima,
+// maxima and counts do not depend on the order; the sweep is the same float operations in the same order, one lane per
+// axis, the axes then compared in their order) — without an atomic on memory.
+__global__ __launch_bounds__(64) void k_small(const BvhBuildRef* __restrict__ refs, Level L, Tree T, uint32_t nA, Counters* C) {
+  __shared__ uint32_t sBins[3 * kBvhBins * kBinWords];
+  const uint32_t a = blockIdx.x, lane = threadIdx.x;
+  if (a >= nA) return;
+  const uint32_t count = L.count[a];
+  if (count > kSmall) return;
+  const uint32_t first = L.first[a];
+  float v[12];
+  for (int j = 0; j < 12; j++) v[j] = ((j % 6) < 3) ? 1e30f : -1e30f;
+  for (uint32_t i = lane; i < count; i += 64) {
+    const BvhBuildRef r = refs[first + i];
+    for (int j = 0; j < 3; j++) {
+      v[j] = fminf(v[j], r.box.lo[j]);
+      v[3 + j] = fmaxf(v[3 + j], r.box.hi[j]);
+      v[6 + j] = fminf(v[6 + j], r.cent[j]);
+      v[9 + j] = fmaxf(v[9 + j], r.cent[j]);
+    }
+  }
+  for (int j = 0; j < 12; j++) {
+    float x = v[j];
+    for (int off = 32; off > 0; off >>= 1) {
+      const float y = __shfl_xor(x, off);
+      x = ((j % 6) < 3) ? fminf(x, y) : fmaxf(x, y);
+    }
+    v[j] = x;
+  }
+  const uint32_t node = L.node[a], depth = L.depth[a];
+  if (lane == 0) {
+    for (int j = 0; j < 6; j++) T.box[(size_t)node * 6 + j] = v[j];
+    L.sorted[a] = 0;
+    L.nLeft[a] = 0;
+    L.child[a] = kNone;
+  }
+  if (count <= kBvhLeafMax) {
+    if (lane == 0) L.state[a] = ST_LEAF;
+    return;
+  }
+  const float* cb = v + 6;
+  float lo[3], sc[3];
+  for (int axis = 0; axis < 3; axis++) {
+    const float ext = cb[3 + axis] - cb[axis];
+    lo[axis] = cb[axis];
+    sc[axis] = (ext > 0.0f) ? (float)kBvhBins / ext : 0.0f;
+  }
+  int maxis = 0;
+  const float e0 = cb[3] - cb[0], e1 = cb[4] - cb[1], e2 = cb[5] - cb[2];
+  if (e1 > e0 && e1 >= e2) maxis = 1;
+  if (e2 > e0 && e2 > e1) maxis = 2;
+  if (lane == 0) {
+    for (int axis = 0; axis < 3; axis++) {
+      L.lo[(size_t)a * 3 + axis] = lo[axis];
+      L.scale[(size_t)a * 3 + axis] = sc[axis];
+    }
+    L.maxis[a] = (uint32_t)maxis;
+  }
+  const bool forceMedian = depth + ceilLog2((count + kBvhLeafMax - 1) / kBvhLeafMax) + 1 >= (uint32_t)kBvhBinaryMaxDepth;
+  if (forceMedian) {
+    if (lane == 0) {
+      L.axis[a] = (uint32_t)maxis;
+      L.split[a] = 0;
+      L.state[a] = ST_MEDIAN;
+      atomicAdd(&C->numMedianNew, 1u);
+    }
+    return;
+  }
+  for (uint32_t i = lane; i < 3 * kBvhBins * kBinWords; i += 64) {
+    const uint32_t j = i % kBinWords;
+    sBins[i] = j < 3 ? enc(1e30f) : (j < 6 ? enc(-1e30f) : 0u);
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < count; i += 64) {
+    const BvhBuildRef r = refs[first + i];
+    for (int axis = 0; axis < 3; axis++) {
+      if (!(sc[axis] > 0.0f)) continue;  // (use[axis] = ext > 0)
+      int bi = (int)((r.cent[axis] - lo[axis]) * sc[axis]);
+      bi = bi < 0 ? 0 : (bi > kBvhBins - 1 ? kBvhBins - 1 : bi);
+      uint32_t* w = sBins + (axis * kBvhBins + bi) * kBinWords;
+      for (int j = 0; j < 3; j++) {
+        atomicMin(&w[j], enc(r.box.lo[j]));
+        atomicMax(&w[3 + j], enc(r.box.hi[j]));
+      }
+      atomicAdd(&w[6], 1u);
+    }
+  }
+  __syncthreads();
+  // the sweep: lane `axis` does its axis
+  int mySplit = -1;
+  float myCost = 1e30f;
+  const float mySc = lane == 0 ? sc[0] : (lane == 1 ? sc[1] : sc[2]);
+  if (lane < 3 && mySc > 0.0f) {
+    const uint32_t* w = sBins + lane * kBvhBins * kBinWords;
+    float rightArea[kBvhBins];
+    uint32_t rightCnt[kBvhBins];
+    float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+    uint32_t cnt = 0;
+    for (int b = kBvhBins - 1; b > 0; b--) {
+      for (int j = 0; j < 3; j++) {
+        const float bl = dec(w[b * kBinWords + j]), bh = dec(w[b * kBinWords + 3 + j]);
+        blo[j] = bl < blo[j] ? bl : blo[j];
+        bhi[j] = bhi[j] < bh ? bh : bhi[j];
+      }
+      cnt += w[b * kBinWords + 6];
+      rightArea[b] = areaOf(blo, bhi);
+      rightCnt[b] = cnt;
+    }
+    for (int j = 0; j < 3; j++) {
+      blo[j] = 1e30f;
+      bhi[j] = -1e30f;
+    }
+    cnt = 0;
+    for (int b = 0; b < kBvhBins - 1; b++) {
+      for (int j = 0; j < 3; j++) {
+        const float bl = dec(w[b * kBinWords + j]), bh = dec(w[b * kBinWords + 3 + j]);
+        blo[j] = bl < blo[j] ? bl : blo[j];
+        bhi[j] = bhi[j] < bh ? bh : bhi[j];
+      }
+      cnt += w[b * kBinWords + 6];
+      if (cnt == 0 || rightCnt[b + 1] == 0) continue;
+      const float cost = areaOf(blo, bhi) * (float)cnt + rightArea[b + 1] * (float)rightCnt[b + 1];
+      if (cost < myCost) {
+        myCost = cost;
+        mySplit = b;
+      }
+    }
+  }
+  int bestAxis = -1, bestSplit = -1;
+  float bestCost = 1e30f;
+  for (int axis = 0; axis < 3; axis++) {
+    const float c = __shfl(myCost, axis);
+    const int sp = __shfl(mySplit, axis);
+    if (sp >= 0 && c < bestCost) {
+      bestCost = c;
+      bestAxis = axis;
+      bestSplit = sp;
+    }
+  }
+  if (lane == 0) {
+    if (bestAxis >= 0) {
+      L.axis[a] = (uint32_t)bestAxis;
+      L.split[a] = (uint32_t)bestSplit;
+      L.state[a] = ST_SPLIT;
+    } else {
+      L.axis[a] = (uint32_t)maxis;
+      L.split[a] = 0;
+      L.state[a] = ST_MEDIAN;
+      atomicAdd(&C->numMedianNew, 1u);
+    }
+  }
+}
+
+// the SAH sweep of splitNode: the same float operations in the same order
+__global__ void k_decide(Level L, uint32_t nA, const uint32_t* __restrict__ bins, Counters* C) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA || L.count[a] <= kSmall || L.state[a] != ST_SPLIT) return;
+  int bestAxis = -1, bestSplit = -1;
+  float bestCost = 1e30f;
+  for (int axis = 0; axis < 3; axis++) {
+    if (!(L.scale[(size_t)a * 3 + axis] > 0.0f)) continue;
+    const uint32_t* w = bins + binsOf(L.first[a]) + (size_t)axis * kBvhBins * kBinWords;
+    float rightArea[kBvhBins];
+    uint32_t rightCnt[kBvhBins];
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    uint32_t cnt = 0;
+    for (int b = kBvhBins - 1; b > 0; b--) {
+      for (int j = 0; j < 3; j++) {
+        const float bl = dec(w[b * kBinWords + j]), bh = dec(w[b * kBinWords + 3 + j]);
+        lo[j] = bl < lo[j] ? bl : lo[j];
+        hi[j] = hi[j] < bh ? bh : hi[j];
+      }
+      cnt += w[b * kBinWords + 6];
+      rightArea[b] = areaOf(lo, hi);
+      rightCnt[b] = cnt;
+    }
+    for (int j = 0; j < 3; j++) {
+      lo[j] = 1e30f;
+      hi[j] = -1e30f;
+    }
+    cnt = 0;
+    for (int b = 0; b < kBvhBins - 1; b++) {
+      for (int j = 0; j < 3; j++) {
+        const float bl = dec(w[b * kBinWords + j]), bh = dec(w[b * kBinWords + 3 + j]);
+        lo[j] = bl < lo[j] ? bl : lo[j];
+        hi[j] = hi[j] < bh ? bh : hi[j];
+      }
+      cnt += w[b * kBinWords + 6];
+      if (cnt == 0 || rightCnt[b + 1] == 0) continue;
+      const float cost = areaOf(lo, hi) * (float)cnt + rightArea[b + 1] * (float)rightCnt[b + 1];
+      if (cost < bestCost) {
+        bestCost = cost;
+        bestAxis = axis;
+        bestSplit = b;
+      }
+    }
+  }
+  if (bestAxis >= 0) {
+    L.axis[a] = (uint32_t)bestAxis;
+    L.split[a] = (uint32_t)bestSplit;
+  } else {  // no split position: the median fallback (the axis prepared above)
+    L.state[a] = ST_MEDIAN;
+    atomicAdd(&C->numMedianNew, 1u);
+    if (L.count[a] > kMedianWave) atomicAdd(&C->numMedianBig, 1u);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_flags(const BvhBuildRef* __restrict__ refs, const uint32_t* __restrict__ nodeOf, uint32_t n, Level L,
+                                               uint32_t* __restrict__ F) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t f = 0;
+  uint32_t a = nodeOf[k];
+  if (a != kNone) {
+    a &= ~kSmallBit;
+    const uint32_t st = L.state[a];
+    if (st == ST_SPLIT) {
+      const uint32_t axis = L.axis[a];
+      int b = (int)((refs[k].cent[axis] - L.lo[(size_t)a * 3 + axis]) * L.scale[(size_t)a * 3 + axis]);
+      b = b < 0 ? 0 : (b > kBvhBins - 1 ? kBvhBins - 1 : b);
+      f = b <= (int)L.split[a] ? 1u : 0u;
+    } else if (st == ST_MEDIAN) {
+      f = (k - L.first[a]) < L.count[a] / 2 ? 1u : 0u;  // (the range is sorted by then)
+    }
+  }
+  F[k] = f;
+}
+
+// ---- exclusive scan of a uint32 array (three launches: block sums, scan of the sums by one block, local scans) ----
+constexpr uint32_t kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t s[kScanBlock];
+  const size_t base = (size_t)blockIdx.x * kScanTile;
+  uint32_t acc = 0;
+  for (uint32_t j = 0; j < kScanPer; j++) {
+    const size_t i = base + (size_t)j * kScanBlock + threadIdx.x;
+    if (i < n) acc += in[i];
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t off = kScanBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(kScanBlock) void k_scan_of_sums(uint32_t* sums, uint32_t m, uint32_t* total) {  // one block
+  __shared__ uint32_t s[kScanBlock];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < m; base += kScanBlock) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < m ? sums[i] : 0u;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < kScanBlock; off <<= 1) {  // inclusive Hillis-Steele
+      const uint32_t t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < m) sums[i] = carry + s[threadIdx.x] - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == kScanBlock - 1) carry += s[kScanBlock - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ sums,
+                                                         const uint32_t* __restrict__ total, uint32_t* __restrict__ out) {
+  __shared__ uint32_t s[kScanBlock];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;  // each thread owns kScanPer consecutive elements
+  uint32_t v[kScanPer], acc = 0;
+  for (uint32_t j = 0; j < kScanPer; j++) {
+    v[j] = (base + j < n) ? in[base + j] : 0u;
+    acc += v[j];
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t off = 1; off < kScanBlock; off <<= 1) {
+    const uint32_t t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = sums[blockIdx.x] + s[threadIdx.x] - acc;
+  for (uint32_t j = 0; j < kScanPer; j++) {
+    if (base + j < n) out[base + j] = run;
+    run += v[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// lefts of every partitioned slot; a SAH split that puts everything on one side falls back to the median
+__global__ void k_nleft(Level L, uint32_t nA, const uint32_t* __restrict__ S, Counters* C) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA) return;
+  const uint32_t st = L.state[a];
+  if (st == ST_LEAF) return;
+  const uint32_t first = L.first[a], count = L.count[a];
+  const uint32_t nl = S[first + count] - S[first];
+  L.nLeft[a] = nl;
+  if (st == ST_SPLIT && (nl == 0 || nl == count)) {
+    L.state[a] = ST_MEDIAN;
+    atomicAdd(&C->numMedianNew, 1u);
+    if (count > kMedianWave) atomicAdd(&C->numMedianBig, 1u);
+  }
+}
+
+// MEDIAN slots of at most kMedianWave references: one wave sorts the range by (centroid on the slot's axis, id) — each
+// lane ranks its elements against all the others — into `tmp`, then copies it back.
+__global__ __launch_bounds__(64) void k_median_sort(BvhBuildRef* refs, BvhBuildRef* tmp, Level L, uint32_t nA) {
+  const uint32_t a = blockIdx.x;
+  if (a >= nA || L.state[a] != ST_MEDIAN || L.sorted[a] != 0 || L.count[a] > kMedianWave) return;
+  const uint32_t first = L.first[a], count = L.count[a], axis = L.maxis[a];
+  for (uint32_t i = threadIdx.x; i < count; i += 64) {
+    const BvhBuildRef r = refs[first + i];
+    const float ki = r.cent[axis];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < count; j++) {
+      const float kj = refs[first + j].cent[axis];
+      const uint32_t idj = refs[first + j].id;
+      rank += (kj < ki || (kj == ki && idj < r.id)) ? 1u : 0u;
+    }
+    tmp[first + rank] = r;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (uint32_t i = threadIdx.x; i < count; i += 64) refs[first + i] = tmp[first + i];
+  if (threadIdx.x == 0) L.sorted[a] = 1;
+}
+__global__ void k_median_list_big(Level L, uint32_t nA, uint32_t* list, uint32_t* listCount) {  // slots the host has to sort
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA || L.state[a] != ST_MEDIAN || L.sorted[a] != 0 || L.count[a] <= kMedianWave) return;
+  list[atomicAdd(listCount, 1u)] = a;
+}
+__global__ void k_mark_sorted(Level L, const uint32_t* list, uint32_t m) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) L.sorted[list[i]] = 1;
+}
+
+// slots that split: G[a] = 1 (scanned into the children's slots)
+__global__ void k_split_flags(Level L, uint32_t nA, uint32_t* G) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < nA) G[a] = L.state[a] != ST_LEAF ? 1u : 0u;
+}
+// two children per splitting slot, in slot order: tree nodes nodeBase + 2 rank, + 1; slots 2 rank, + 1 of the next level
+__global__ void k_children(Level L, uint32_t nA, const uint32_t* __restrict__ R, Level N, Tree T, uint32_t nodeBase) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA || L.state[a] == ST_LEAF) return;
+  const uint32_t rank = R[a], node = L.node[a];
+  const uint32_t first = L.first[a], count = L.count[a], nl = L.nLeft[a], depth = L.depth[a];
+  L.child[a] = 2 * rank;
+  for (int side = 0; side < 2; side++) {
+    const uint32_t c = nodeBase + 2 * rank + (uint32_t)side, s = 2 * rank + (uint32_t)side;
+    const uint32_t cf = side ? first + nl : first, cc = side ? count - nl : nl;
+    T.left[c] = -1;
+    T.right[c] = -1;
+    T.first[c] = cf;
+    T.count[c] = cc;
+    T.depth[c] = depth + 1;
+    N.node[s] = c;
+    N.first[s] = cf;
+    N.count[s] = cc;
+    N.depth[s] = depth + 1;
+    for (int j = 0; j < 12; j++) N.bnd[(size_t)s * 12 + j] = ((j % 6) < 3) ? enc(1e30f) : enc(-1e30f);
+  }
+  T.left[node] = (int32_t)(nodeBase + 2 * rank);
+  T.right[node] = (int32_t)(nodeBase + 2 * rank + 1);
+  T.count[node] = 0;  // (interior: bvh_build.cpp sets it so)
+}
+
+// stable partition of every splitting slot's range; everything else is carried over
+__global__ __launch_bounds__(256) void k_scatter(const BvhBuildRef* __restrict__ refs, const uint32_t* __restrict__ nodeOf, uint32_t n, Level L,
+                                                 const uint32_t* __restrict__ F, const uint32_t* __restrict__ S,
+                                                 BvhBuildRef* __restrict__ refsOut, uint32_t* __restrict__ nodeOfOut) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t a = nodeOf[k];
+  if (a != kNone) a &= ~kSmallBit;
+  if (a == kNone || L.state[a] == ST_LEAF) {
+    refsOut[k] = refs[k];
+    nodeOfOut[k] = kNone;
+    return;
+  }
+  const uint32_t first = L.first[a], nl = L.nLeft[a];
+  const uint32_t l = S[k] - S[first];
+  const uint32_t f = F[k];
+  const uint32_t dest = f ? first + l : first + nl + ((k - first) - l);
+  refsOut[dest] = refs[k];
+  const uint32_t childCount = f ? nl : L.count[a] - nl;
+  nodeOfOut[dest] = (L.child[a] + (f ? 0u : 1u)) | (childCount <= kSmall ? kSmallBit : 0u);
+}
+
+// the results in the host's formats: the leaf order as reference ids, the nodes as BvhBuildNode records
+__global__ void k_order(const BvhBuildRef* __restrict__ refs, uint32_t n, uint32_t* __restrict__ order) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) order[k] = refs[k].id;
+}
+__global__ void k_pack_nodes(Tree T, uint32_t numNodes, BvhBuildNode* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numNodes) return;
+  BvhBuildNode nd;
+  for (int j = 0; j < 3; j++) {
+    nd.box.lo[j] = T.box[(size_t)i * 6 + j];
+    nd.box.hi[j] = T.box[(size_t)i * 6 + 3 + j];
+  }
+  nd.left = T.left[i];
+  nd.right = T.right[i];
+  nd.first = T.first[i];
+  nd.count = T.count[i];
+  nd.depth = T.depth[i];
+  out[i] = nd;
+}
+
+// Device -> pageable host memory through pinned staging buffers, the host-side copies shared among a few threads (a
+// plain hipMemcpy into pageable memory runs at ~3 GB/s here; the node list of a 10 M-triangle scene is 1 GB).
+bool downloadStaged(void* dst, const void* src, size_t bytes, std::string& err) {
+  constexpr size_t kStage = 32u << 20;
+  constexpr int kBufs = 2, kCopyThreads = 4;
+  auto bad = [&](hipError_t e) {
+    err = std::string("device tree builder: download: ") + hipGetErrorString(e);
+    return false;
+  };
+  if (bytes <= (8u << 20)) {
+    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? true : bad(e);
+  }
+  void* stage[kBufs] = {};
+  hipEvent_t ev[kBufs] = {};
+  hipStream_t st = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  for (int i = 0; i < kBufs && e == hipSuccess; i++) {
+    e = hipHostMalloc(&stage[i], kStage, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+  }
+  const size_t nChunks = (bytes + kStage - 1) / kStage;
+  auto sizeOf = [&](size_t c) { return std::min(kStage, bytes - c * kStage); };
+  auto issue = [&](size_t c) {
+    hipError_t r = hipMemcpyAsync(stage[c % kBufs], static_cast<const char*>(src) + c * kStage, sizeOf(c), hipMemcpyDeviceToHost, st);
+    if (r == hipSuccess) r = hipEventRecord(ev[c % kBufs], st);
+    return r;
+  };
+  if (e == hipSuccess) e = issue(0);
+  for (size_t c = 0; c < nChunks && e == hipSuccess; c++) {
+    if (c + 1 < nChunks) e = issue(c + 1);  // (buffer (c + 1) % 2 was consumed in the previous round)
+    if (e == hipSuccess) e = hipEventSynchronize(ev[c % kBufs]);
+    if (e != hipSuccess) break;
+    const size_t sz = sizeOf(c), per = (sz + kCopyThreads - 1) / kCopyThreads;
+    char* const d = static_cast<char*>(dst) + c * kStage;
+    const char* const sp = static_cast<const char*>(stage[c % kBufs]);
+    std::thread th[kCopyThreads];
+    for (int t = 1; t < kCopyThreads; t++)
+      if ((size_t)t * per < sz) th[t] = std::thread([=] { std::memcpy(d + (size_t)t * per, sp + (size_t)t * per, std::min(per, sz - (size_t)t * per)); });
+    std::memcpy(d, sp, std::min(per, sz));
+    for (int t = 1; t < kCopyThreads; t++)
+      if (th[t].joinable()) th[t].join();
+  }
+  if (st) (void)hipStreamSynchronize(st);
+  for (int i = 0; i < kBufs; i++) {
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (stage[i]) (void)hipHostFree(stage[i]);
+  }
+  if (st) (void)hipStreamDestroy(st);
+  return e == hipSuccess ? true : bad(e);
+}
+
+template <class T>
+bool devAllocT(std::vector<void*>& pool, T** p, size_t count, std::string& err) {
+  void* q = nullptr;
+  if (hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) {
+    err = "device tree builder: out of device memory";
+    return false;
+  }
+  pool.push_back(q);
+  *p = static_cast<T*>(q);
+  return true;
+}
+
+struct Scan {
+  uint32_t* sums = nullptr;
+  uint32_t* total = nullptr;
+  uint32_t capTiles = 0;
+  void run(const uint32_t* in, uint32_t n, uint32_t* out, hipStream_t st) const {  // out has n + 1 entries
+    const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_sums, dim3(tiles), dim3(kScanBlock), 0, st, in, n, sums);
+    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(kScanBlock), 0, st, sums, tiles, total);
+    hipLaunchKernelGGL(k_scan_local, dim3(tiles), dim3(kScanBlock), 0, st, in, n, sums, total, out);
+  }
+};
+
+bool allocLevel(std::vector<void*>& pool, Level& L, size_t cap, std::string& err) {
+  return devAllocT(pool, &L.node, cap, err) && devAllocT(pool, &L.first, cap, err) && devAllocT(pool, &L.count, cap, err) &&
+         devAllocT(pool, &L.depth, cap, err) && devAllocT(pool, &L.state, cap, err) && devAllocT(pool, &L.bnd, cap * 12, err) &&
+         devAllocT(pool, &L.lo, cap * 3, err) && devAllocT(pool, &L.scale, cap * 3, err) && devAllocT(pool, &L.axis, cap, err) && devAllocT(pool, &L.maxis, cap, err) &&
+         devAllocT(pool, &L.split, cap, err) && devAllocT(pool, &L.nLeft, cap, err) && devAllocT(pool, &L.sorted, cap, err) &&
+         devAllocT(pool, &L.child, cap, err);
+}
+
+}  // namespace
+
+// The BvhTreeBuilder bdpt_set_scene plugs into buildBvh; `user` points at the device ordinal (int).
+bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err) {
+  const int device = user ? *static_cast<const int*>(user) : 0;
+  if (n == 0) return false;
+  if (hipSetDevice(device) != hipSuccess) {
+    err = "device tree builder: no such device";
+    return false;
+  }
+  const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bvh]   device %-10s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
+  // BDPT_BUILD_VERBOSE=2: synchronise after every stage and report where the levels' time goes
+  const bool stages = verbose && std::atoi(std::getenv("BDPT_BUILD_VERBOSE")) >= 2;
+  enum { S_BOUNDS, S_PREPARE, S_SMALL, S_BIN, S_DECIDE, S_FLAGS, S_SCAN, S_NLEFT, S_MEDIAN, S_CHILDREN, S_SCATTER, S_COUNT };
+  static const char* const stageName[S_COUNT] = {"bounds", "prepare", "small", "bin", "decide", "flags", "scan", "nleft+read", "median", "children", "scatter"};
+  double stageTime[S_COUNT] = {};
+  auto ts = std::chrono::steady_clock::now();
+  auto stage = [&](int id) {
+    if (!stages) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    stageTime[id] += std::chrono::duration<double>(t1 - ts).count();
+    ts = t1;
+  };
+  std::vector<void*> pool;
+  struct Free {
+    std::vector<void*>& p;
+    ~Free() {
+      for (void* q : p) (void)hipFree(q);
+    }
+  } freeAll{pool};
+  hipStream_t st = nullptr;  // the default stream: the build is a blocking call of set-up, not of the frame
+  auto ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err = std::string("device tree builder: ") + what + ": " + hipGetErrorString(e);
+    return false;
+  };
+  const size_t cap = n;                  // active slots per level: disjoint non-empty ranges
+  const size_t maxNodes = 2 * (size_t)n;  // a binary tree over n references has at most 2n - 1 nodes
+  BvhBuildRef *rA = nullptr, *rB = nullptr;
+  uint32_t *ofA = nullptr, *ofB = nullptr, *F = nullptr, *S = nullptr, *G = nullptr, *R = nullptr, *bins = nullptr, *bigList = nullptr, *bigCount = nullptr;
+  Counters* C = nullptr;
+  Level L[2];
+  Tree T;
+  Scan scan;
+  const size_t binWords = ((size_t)n / (kSmall + 1) + 1) * 3 * kBvhBins * kBinWords;  // (binsOf)
+  if (!devAllocT(pool, &rA, n, err) || !devAllocT(pool, &rB, n, err) || !devAllocT(pool, &ofA, n, err) || !devAllocT(pool, &ofB, n, err) ||
+      !devAllocT(pool, &F, (size_t)n + 1, err) || !devAllocT(pool, &S, (size_t)n + 1, err) || !devAllocT(pool, &G, cap + 1, err) ||
+      !devAllocT(pool, &R, cap + 1, err) || !devAllocT(pool, &bins, binWords, err) || !devAllocT(pool, &bigList, cap, err) ||
+      !devAllocT(pool, &bigCount, 1, err) || !devAllocT(pool, &C, 1, err) || !allocLevel(pool, L[0], cap, err) || !allocLevel(pool, L[1], cap, err) ||
+      !devAllocT(pool, &T.box, maxNodes * 6, err) || !devAllocT(pool, &T.left, maxNodes, err) || !devAllocT(pool, &T.right, maxNodes, err) ||
+      !devAllocT(pool, &T.first, maxNodes, err) || !devAllocT(pool, &T.count, maxNodes, err) || !devAllocT(pool, &T.depth, maxNodes, err))
+    return false;
+  scan.capTiles = (uint32_t)((std::max<size_t>(n, cap) + kScanTile - 1) / kScanTile) + 1;
+  if (!devAllocT(pool, &scan.sums, scan.capTiles, err) || !devAllocT(pool, &scan.total, 1, err)) return false;
+  lap("alloc");
+  if (!ok(hipMemcpy(rA, refs, (size_t)n * sizeof(BvhBuildRef), hipMemcpyHostToDevice), "upload")) return false;
+  lap("upload");
+
+  const dim3 blk(256);
+  auto gridFor = [](size_t m) { return dim3((unsigned)((m + 255) / 256)); };
+  auto chunksOf = [](size_t m) { return dim3((unsigned)((m + kChunk - 1) / kChunk)); };
+  hipLaunchKernelGGL(k_fill_u32, dim3(1024), blk, 0, st, ofA, n <= kSmall ? kSmallBit : 0u, (size_t)n);
+  hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, st, L[0], T, n);
+  uint32_t nA = 1, numNodes = 1;
+  int cur = 0;
+  std::vector<uint32_t> hostList;
+  std::vector<BvhBuildRef> hostRange;
+  for (int level = 0; nA > 0; level++) {
+    if (level > kBvhBinaryMaxDepth + 2) {
+      err = "device tree builder: depth budget exceeded";
+      return false;
+    }
+    Level& Lc = L[cur];
+    Level& Ln = L[cur ^ 1];
+    if (!ok(hipMemsetAsync(C, 0, sizeof(Counters), st), "memset")) return false;
+    if (stages) {
+      (void)hipDeviceSynchronize();
+      ts = std::chrono::steady_clock::now();
+    }
+    const auto tLevel = ts;
+    hipLaunchKernelGGL(k_bounds, chunksOf(n), blk, 0, st, rA, ofA, n, Lc);
+    stage(S_BOUNDS);
+    hipLaunchKernelGGL(k_prepare, gridFor(nA), blk, 0, st, Lc, T, nA, C, bins);
+    stage(S_PREPARE);
+    hipLaunchKernelGGL(k_small, dim3(nA), dim3(64), 0, st, rA, Lc, T, nA, C);
+    stage(S_SMALL);
+    hipLaunchKernelGGL(k_bin, chunksOf(n), blk, 0, st, rA, ofA, n, Lc, bins);
+    stage(S_BIN);
+    hipLaunchKernelGGL(k_decide, gridFor(nA), blk, 0, st, Lc, nA, bins, C);
+    stage(S_DECIDE);
+    hipLaunchKernelGGL(k_flags, gridFor(n), blk, 0, st, rA, ofA, n, Lc, F);
+    stage(S_FLAGS);
+    scan.run(F, n, S, st);
+    stage(S_SCAN);
+    hipLaunchKernelGGL(k_nleft, gridFor(nA), blk, 0, st, Lc, nA, S, C);
+    Counters hc;
+    if (!ok(hipMemcpy(&hc, C, sizeof(hc), hipMemcpyDeviceToHost), "counters")) return false;
+    stage(S_NLEFT);
+    if (hc.numMedianNew > 0) {
+      // median fallback: sort the ranges (small ones by a wave each, large ones on the host), then partition again
+      hipLaunchKernelGGL(k_median_sort, dim3(nA), dim3(64), 0, st, rA, rB, Lc, nA);
+      if (hc.numMedianBig > 0) {
+        if (!ok(hipMemsetAsync(bigCount, 0, 4, st), "memset")) return false;
+        hipLaunchKernelGGL(k_median_list_big, gridFor(nA), blk, 0, st, Lc, nA, bigList, bigCount);
+        uint32_t m = 0;
+        if (!ok(hipMemcpy(&m, bigCount, 4, hipMemcpyDeviceToHost), "list")) return false;
+        hostList.resize(m);
+        if (m && !ok(hipMemcpy(hostList.data(), bigList, (size_t)m * 4, hipMemcpyDeviceToHost), "list")) return false;
+        for (uint32_t a : hostList) {
+          uint32_t first = 0, count = 0, axis = 0;
+          if (!ok(hipMemcpy(&first, Lc.first + a, 4, hipMemcpyDeviceToHost), "slot") || !ok(hipMemcpy(&count, Lc.count + a, 4, hipMemcpyDeviceToHost), "slot") ||
+              !ok(hipMemcpy(&axis, Lc.maxis + a, 4, hipMemcpyDeviceToHost), "slot"))
+            return false;
+          hostRange.resize(count);
+          if (!ok(hipMemcpy(hostRange.data(), rA + first, (size_t)count * sizeof(BvhBuildRef), hipMemcpyDeviceToHost), "range")) return false;
+          std::sort(hostRange.begin(), hostRange.end(), [axis](const BvhBuildRef& x, const BvhBuildRef& y) {
+            return x.cent[axis] < y.cent[axis] || (x.cent[axis] == y.cent[axis] && x.id < y.id);
+          });
+          if (!ok(hipMemcpy(rA + first, hostRange.data(), (size_t)count * sizeof(BvhBuildRef), hipMemcpyHostToDevice), "range")) return false;
+        }
+        if (m) hipLaunchKernelGGL(k_mark_sorted, gridFor(m), blk, 0, st, Lc, bigList, m);
+      }
+      hipLaunchKernelGGL(k_flags, gridFor(n), blk, 0, st, rA, ofA, n, Lc, F);
+      scan.run(F, n, S, st);
+      hipLaunchKernelGGL(k_nleft, gridFor(nA), blk, 0, st, Lc, nA, S, C);
+    }
+    stage(S_MEDIAN);
+    // children: slots that split, ranked in slot order
+    hipLaunchKernelGGL(k_split_flags, gridFor(nA), blk, 0, st, Lc, nA, G);
+    scan.run(G, nA, R, st);
+    uint32_t numSplit = 0;
+    if (!ok(hipMemcpy(&numSplit, R + nA, 4, hipMemcpyDeviceToHost), "split count")) return false;
+    if ((size_t)numNodes + 2 * (size_t)numSplit > maxNodes || 2 * (size_t)numSplit > cap) {
+      err = "device tree builder: node count out of bounds";
+      return false;
+    }
+    if (numSplit > 0) hipLaunchKernelGGL(k_children, gridFor(nA), blk, 0, st, Lc, nA, R, Ln, T, numNodes);
+    stage(S_CHILDREN);
+    hipLaunchKernelGGL(k_scatter, gridFor(n), blk, 0, st, rA, ofA, n, Lc, F, S, rB, ofB);
+    stage(S_SCATTER);
+    if (stages)
+      std::fprintf(stderr, "[bvh]   device level %2d: %8u slots, %8u split, %.4f s\n", level, nA, numSplit, std::chrono::duration<double>(ts - tLevel).count());
+    std::swap(rA, rB);
+    std::swap(ofA, ofB);
+    numNodes += 2 * numSplit;
+    nA = 2 * numSplit;
+    cur ^= 1;
+    if (!ok(hipGetLastError(), "launch")) return false;
+  }
+  if (!ok(hipDeviceSynchronize(), "synchronise")) return false;
+  lap("levels");
+  if (stages)
+    for (int i = 0; i < S_COUNT; i++) std::fprintf(stderr, "[bvh]   device stage %-10s %.4f s\n", stageName[i], stageTime[i]);
+  // back to the host: the leaf order and the tree, in the host's formats (the boxes of the references are the caller's own)
+  uint32_t* dOrder = F;  // (n + 1 words, free by now)
+  BvhBuildNode* dNodes = nullptr;
+  if (!devAllocT(pool, &dNodes, numNodes, err)) return false;
+  hipLaunchKernelGGL(k_order, gridFor(n), blk, 0, st, rA, n, dOrder);
+  hipLaunchKernelGGL(k_pack_nodes, gridFor(numNodes), blk, 0, st, T, numNodes, dNodes);
+  if (!ok(hipDeviceSynchronize(), "pack")) return false;
+  order.resize(n);
+  nodes.resize(numNodes);
+  if (!downloadStaged(order.data(), dOrder, (size_t)n * 4, err) || !downloadStaged(nodes.data(), dNodes, (size_t)numNodes * sizeof(BvhBuildNode), err)) return false;
+  lap("download");
+  return true;
+}
+
+}  // namespace bdpt

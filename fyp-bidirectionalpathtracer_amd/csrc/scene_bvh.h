@@ -23,6 +23,9 @@ struct SceneBvh {
 
 // threads / budgets as BvhBuildOptions (negative budgets: build defaults); classify = false keeps the reference's
 // per-material opacity (every triangle of an alpha-mode material is tested, nothing is dropped or clipped).
-void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, bool classify, SceneBvh& out);
+// treeBuilder (may be null: host code) builds the binary tree — bdpt_set_scene passes the device implementation; when it
+// fails the tree has no nodes and *error says why.
+void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, bool classify, SceneBvh& out,
+                   BvhTreeBuilder treeBuilder = nullptr, void* treeBuilderUser = nullptr, std::string* error = nullptr);
 
 }  // namespace bdpt

@@ -337,6 +337,11 @@ int bdpt_bvh_build_check(const bdpt_scene_desc* scene, bdpt_bvh_info* out, char*
  * NULL (its `reserved` field returns the default thread count). */
 int bdpt_bvh_build_hash(const bdpt_scene_desc* scene, int threads, uint64_t* out_hash, bdpt_bvh_info* out_info);
 
+/* Test hook: the builder the host-only hooks above and below use for the BINARY TREE stage — device >= 0: the device
+ * implementation bdpt_set_scene uses (csrc/bvh_device.hip) on that device; device < 0: the host code (the default).  The
+ * two build the same tree bit for bit; the GPU tests compare bdpt_bvh_build_hash under both settings. */
+int bdpt_test_tree_builder(int device);
+
 /* Host-only test hooks: the acceleration structure exactly as bdpt_set_scene builds it (traversal flags, alpha
  * classification, spatial pre-splitting; negative budgets = build defaults, classify = 0 keeps the reference's
  * per-material opacity) walked on the CPU with the device's query semantics (bdpt_test_trace), or — brute != 0 —

@@ -8,6 +8,7 @@ every value is finite, and the ray tallies stay within the (D+1)^2 bound.  The a
 stand-ins have their triangle counts, material classes and alpha-masked foliage (host/Atrium.cpp).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,8 @@ import pytest
 from test_gpu_parity import RMSE_TOL, _bands_equal_full, _oracle_frame, _rmse
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RAY_KEYS = ("raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")
 
@@ -359,3 +362,34 @@ def test_execute_at_lower_depth_than_the_context_is_sized_for(pkg, ob):
             orc.close()
         pipe.close()
     scene.close()
+
+
+def test_device_tree_builder_builds_the_host_builders_tree(pkg):
+    """bdpt_set_scene builds the binary tree of the acceleration structure on the device (csrc/bvh_device.hip) — the
+    reference's BLAS / TLAS builds are GPU work too (RtModel.cpp:181-254, RtScene.cpp:220-308).  It has to be the host
+    builder's tree bit for bit: same hash over nodes, leaf-ordered triangles, reference boxes and packed records, same
+    depth / stack / SAH cost — on the bench scene, the heavy-tailed one, the alpha-masked one, tiny inputs (one wave per
+    slot from the root on), and a degenerate pile of identical centroids plus an 18-decade line (median fallback by the
+    wave sort and by the host sort, depth budget)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("device_tree_check", os.path.join(ROOT, "tools", "device_tree_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    lib = pkg.load_library()
+    scenes = [("cornell", pkg.Scene.cornell()), ("atrium", pkg.Scene.atrium(1, 262144)), ("uneven", pkg.Scene.atrium_uneven(1, 262144)),
+              ("courtyard", pkg.Scene.courtyard(1, 200000)), ("soup 3", pkg.Scene.soup(2, 3)), ("soup 1500", pkg.Scene.soup(2, 1500)),
+              ("soup 40000", pkg.Scene.soup(2, 40000)), ("skewed", chk.skewed(pkg, 50000))]
+    try:
+        for name, sc in scenes:
+            got = []
+            for dev in (-1, 0):
+                assert lib.bdpt_test_tree_builder(dev) == 0
+                h = C.c_uint64()
+                info = pkg.abi.BvhInfo()
+                assert lib.bdpt_bvh_build_hash(C.byref(sc.desc), 0, C.byref(h), C.byref(info)) == 0, name
+                got.append((h.value, info.numNodes, info.maxDepth, info.maxStack, info.sahCost, info.numReferences))
+            assert got[0] == got[1], (name, got)
+    finally:
+        lib.bdpt_test_tree_builder(-1)
+        for _, sc in scenes:
+            sc.close()

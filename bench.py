@@ -176,7 +176,7 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, frames=3):
                "stage_ms": {k: round(v, 2) for k, v in agg.items() if v >= 0.05},
                "bvh": {"nodes": info.numNodes, "references": info.numReferences, "triangles": info.numTriangles,
                        "alpha_mode_triangles": info.numAlphaMode, "always_pass": info.numAlwaysPass, "dropped": info.numDropped},
-               "setup_s": round(setup, 2), "device_memory_gb": round((total - free) / 2 ** 30, 1)}
+               "setup_s": round(setup, 2), "setup_breakdown_s": {k: round(v, 2) for k, v in pipe.setup_times.items()}, "device_memory_gb": round((total - free) / 2 ** 30, 1)}
     finally:
         pipe.close()
     return out

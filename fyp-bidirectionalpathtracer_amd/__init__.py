@@ -309,9 +309,13 @@ class FramePipeline:
         self.clamp_upper, self.min_t, self.flags = float(clamp_upper), float(min_t), int(flags)
         self.accum_limit = int(accum_limit)
         self.dev = torch.device("cuda", device)
+        import time
+        t0 = time.time()
         self.ctx = Context(device)
+        t1 = time.time()
         self.scene = scene
         self.ctx.set_scene(scene.desc)
+        t2 = time.time()
         self.cam = scene.camera(self.W / self.H)
         self.ctx.set_camera(self.cam)
         # tile = (y0, y1): a contiguous band; stripes = (stripe_rows, num_owners, owner): interleaved stripes
@@ -327,6 +331,9 @@ class FramePipeline:
                 self.channels[name] = torch.zeros(self.H, self.W, 4, dtype=torch.float16, device=self.dev)
             self.channels[OUTPUT_CHANNEL] = torch.zeros(self.H, self.W, 4, dtype=torch.float32, device=self.dev)
             self.last_frame = torch.zeros(self.H, self.W, 4, dtype=torch.float32, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        # where the set-up time went: the scene (acceleration structure + uploads) and the frame's buffers are separate things
+        self.setup_times = {"context_s": t1 - t0, "set_scene_s": t2 - t1, "buffers_s": time.time() - t2}
         self.gb = GBuffer(*[self.channels[n].data_ptr() for n in GBUFFER_CHANNELS])
         self.gbuffer_frame = 0xdeadbeef
         self.bdpt_frame = 0x1337

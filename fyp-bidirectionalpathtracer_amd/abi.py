@@ -153,6 +153,7 @@ PROTOTYPES = {
     "bdpt_resolve_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdpt_accumulate_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "bdpt_test_tree_builder": (C.c_int, [C.c_int]),
+    "bdpt_bvh_recs_hash": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_uint64), C.POINTER(BvhInfo)]),
     "bdpt_bvh_build_hash": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_uint64), C.POINTER(BvhInfo)]),
     "bdpt_splat_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bdpt_set_splat_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

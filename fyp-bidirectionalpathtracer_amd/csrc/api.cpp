@@ -336,13 +336,18 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   // traversal flags, alpha classification, spatial pre-splitting and the tree itself: scene_bvh.cpp
   SceneBvh sb;
   try {
-    // the binary tree is built on this context's device (bvh_device.hip): the same tree the host code builds, bit for bit
+    // the binary tree is built, and the records are quantised and packed, on this context's device (bvh_device.hip):
+    // the records the host code produces, bit for bit
     std::string treeError;
-    int treeDevice = c->device;
-    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb, buildBinaryTreeOnDevice, &treeDevice, &treeError);
+    struct Build {
+      BvhDeviceBuild* b;
+      ~Build() { bvhDeviceBuildEnd(b); }
+    } build{bvhDeviceBuildBegin(c->device)};
+    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb, buildBinaryTreeOnDevice, build.b, &treeError, packOnDevice);
+    if (sb.bvh.deviceRecs) c->sceneAllocs.push_back(sb.bvh.deviceRecs);  // (the context's from here on)
     if (!treeError.empty()) {
       fail(c, "scene: " + treeError);
-      return BDPT_E_HIP;
+      return treeError.find("2^31") != std::string::npos ? BDPT_E_LIMIT : BDPT_E_HIP;
     }
   } catch (const std::bad_alloc&) {
     fail(c, "scene: out of host memory while building the acceleration structure");
@@ -355,18 +360,18 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     fail(c, "bvh needs a deeper traversal stack than the device provides");
     return BDPT_E_LIMIT;
   }
-  if (bvh.recs.empty()) {
-    fail(c, "bvh does not fit the packed record format (2^31 records)");
-    return BDPT_E_LIMIT;
+  if (!bvh.deviceRecs) {
+    fail(c, "scene: the acceleration structure has no records");
+    return BDPT_E_HIP;
   }
-  c->bvhInfo.numNodes = (uint32_t)bvh.nodes.size();
+  c->bvhInfo.numNodes = bvh.numNodes;
   c->bvhInfo.numTriangles = d->numTriangles;
   c->bvhInfo.maxDepth = bvh.maxDepth;
   c->bvhInfo.nodeBytes = sizeof(BvhRec);
   c->bvhInfo.triBytes = sizeof(BvhTri);
   c->bvhInfo.sahCost = bvh.sahCost;
   c->bvhInfo.maxStack = bvh.maxStack;
-  c->bvhInfo.numReferences = (uint32_t)bvh.tris.size();
+  c->bvhInfo.numReferences = bvh.numRefs;
   c->bvhInfo.numDropped = bvh.numDropped;
   c->bvhInfo.numAlphaMode = sb.numAlphaMode;
   c->bvhInfo.numAlwaysPass = sb.numAlwaysPass;
@@ -398,14 +403,12 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
 
   lap("shading records");
   int rc;
-  const BvhRec* dRecs;
   const float* dShade;
-  if ((rc = devUpload(c, c->sceneAllocs, &dRecs, bvh.recs.data(), bvh.recs.size()))) return rc;
   if ((rc = devUpload(c, c->sceneAllocs, &dShade, shade.data(), shade.size()))) return rc;
-  lap("upload tree+shade");
-  c->S.recs = reinterpret_cast<const uint4*>(dRecs);
+  lap("upload shade");
+  c->S.recs = reinterpret_cast<const uint4*>(bvh.deviceRecs);
   c->S.shade = reinterpret_cast<const float4*>(dShade);
-  c->S.numRecs = (uint32_t)bvh.recs.size();
+  c->S.numRecs = (uint32_t)bvh.deviceNumRecs;
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.indices, d->indices, (size_t)d->numTriangles * 3))) return rc;
   if (d->bitangents) {
     if ((rc = devUpload(c, c->sceneAllocs, &c->S.bitangents, d->bitangents, (size_t)d->numVertices * 3))) return rc;
@@ -1077,16 +1080,78 @@ int bdpt_accumulate_tile(bdpt_ctx* c, float* lastFrame, float* curFrame, uint32_
 // Test hook: which builder the host-only hash / check hooks (bdpt_bvh_build_hash, bdpt_bvh_build_check, bdpt_host_bvh_*)
 // use for the binary tree: device >= 0 the device implementation on that device, < 0 the host code (the default).
 int bdpt_test_tree_builder(int device) {
-  static int sDevice = 0;
-  if (device < 0) {
-    bvhSetDefaultTreeBuilder(nullptr, nullptr);
-    return BDPT_OK;
-  }
+  static BvhDeviceBuild* sBuild = nullptr;
+  bvhSetDefaultTreeBuilder(nullptr, nullptr);
+  if (sBuild) bvhDeviceBuildEnd(sBuild);
+  sBuild = nullptr;
+  if (device < 0) return BDPT_OK;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return BDPT_E_HIP;
-  sDevice = device;
-  bvhSetDefaultTreeBuilder(buildBinaryTreeOnDevice, &sDevice);
+  sBuild = bvhDeviceBuildBegin(device);
+  bvhSetDefaultTreeBuilder(buildBinaryTreeOnDevice, sBuild);
   return BDPT_OK;
+}
+
+// Test hook: FNV-1a over the packed records (every node, every leaf triangle, the pad) and the summary of the
+// acceleration structure of a scene — device < 0: built, quantised and packed by the host code; device >= 0: as
+// bdpt_set_scene does it, tree + quantisation + packing on that device, the records read back.
+int bdpt_bvh_recs_hash(const bdpt_scene_desc* d, int device, uint64_t* out_hash, bdpt_bvh_info* out_info) try {
+  if (!d || !out_hash || !d->positions || !d->indices || !d->materials || !d->triMaterial || !d->numMaterials) return BDPT_E_INVALID;
+  SceneBvh sb;
+  BigVec<BvhRec> fromDevice;
+  const BvhRec* recs = nullptr;
+  size_t numRecs = 0;
+  if (device < 0) {
+    buildSceneBvh(d, 0, -1.0f, -1.0f, true, sb);
+    recs = sb.bvh.recs.data();
+    numRecs = sb.bvh.recs.size();
+  } else {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return BDPT_E_HIP;
+    std::string error;
+    struct Build {
+      BvhDeviceBuild* b;
+      ~Build() { bvhDeviceBuildEnd(b); }
+    } build{bvhDeviceBuildBegin(device)};
+    buildSceneBvh(d, 0, -1.0f, -1.0f, true, sb, buildBinaryTreeOnDevice, build.b, &error, packOnDevice);
+    if (!sb.bvh.deviceRecs) return BDPT_E_HIP;
+    fromDevice.resize(sb.bvh.deviceNumRecs);
+    const hipError_t e = hipMemcpy(fromDevice.data(), sb.bvh.deviceRecs, fromDevice.size() * sizeof(BvhRec), hipMemcpyDeviceToHost);
+    (void)hipFree(sb.bvh.deviceRecs);
+    if (e != hipSuccess || !error.empty()) return BDPT_E_HIP;
+    recs = fromDevice.data();
+    numRecs = fromDevice.size();
+  }
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  mix(recs, numRecs * sizeof(BvhRec));
+  mix(&sb.bvh.maxDepth, sizeof(sb.bvh.maxDepth));
+  mix(&sb.bvh.maxStack, sizeof(sb.bvh.maxStack));
+  mix(&sb.bvh.sahCost, sizeof(sb.bvh.sahCost));
+  *out_hash = h;
+  if (out_info) {
+    *out_info = bdpt_bvh_info{};
+    out_info->numNodes = sb.bvh.numNodes;
+    out_info->numTriangles = d->numTriangles;
+    out_info->maxDepth = sb.bvh.maxDepth;
+    out_info->nodeBytes = sizeof(BvhRec);
+    out_info->triBytes = sizeof(BvhTri);
+    out_info->sahCost = sb.bvh.sahCost;
+    out_info->maxStack = sb.bvh.maxStack;
+    out_info->reserved = (uint32_t)numRecs;
+    out_info->numReferences = sb.bvh.numRefs;
+    out_info->numDropped = sb.bvh.numDropped;
+    out_info->numAlphaMode = sb.numAlphaMode;
+    out_info->numAlwaysPass = sb.numAlwaysPass;
+  }
+  return BDPT_OK;
+} catch (const std::bad_alloc&) {
+  return BDPT_E_NOMEM;
+} catch (...) {
+  return BDPT_E_INVALID;
 }
 
 int bdpt_get_counters(bdpt_ctx* c, bdpt_counters* out) {

@@ -154,6 +154,11 @@ struct Bvh {
   uint32_t maxStack = 0;     // worst-case number of simultaneously stacked references
   float sahCost = 0.0f;
   uint32_t numDropped = 0;   // input triangles with no reference at all (the clipper found nothing that can be hit)
+  uint32_t numNodes = 0;     // four-wide nodes and references (= nodes.size(), tris.size() when the host code packed)
+  uint32_t numRefs = 0;
+  // With BvhBuildOptions::packer: the packed records are built in device memory and nodes / tris / refBox / recs stay empty.
+  void* deviceRecs = nullptr;  // hipMalloc'ed, the caller's to free
+  size_t deviceNumRecs = 0;    // (including the kBvhPadRecs pad records)
 };
 
 // Lets the caller shrink or drop the part of a triangle a reference stands for.  Used for non-opaque triangles
@@ -223,12 +228,43 @@ static_assert(sizeof(BvhBuildNode) == 44, "binary node");
 // of the leaf order the nodes' ranges speak of.  nodes[0] is the root; children come after their parents.  false + err
 // on failure.
 using BvhTreeBuilder = bool (*)(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
-// Test hook: the tree builder buildBvh uses when its options name none (null = the host code).  bdpt_test_tree_builder
-// (api.cpp) points it at the device implementation so that the host-only hash / check hooks can be run over a
-// device-built tree and compared with the host-built one.
+// After the collapse (host): the four-wide nodes as lists of binary nodes, and where each one's index goes in its parent.
+struct BvhWideNode {
+  uint32_t src;      // binary node this wide node covers
+  uint32_t kids[4];  // the binary nodes that became its (up to 4) children
+  int32_t nk;
+  uint32_t depth;
+};
+struct BvhSlot {
+  int32_t node, idx;  // wide node and child slot that refer to this wide node (-1: the root)
+};
+struct Bvh;
+struct BvhPackInput {
+  const BvhTri* triRecs;  // one per input triangle
+  uint32_t numTris;
+  const uint32_t* refTri;  // the triangle of every reference, by reference id
+  uint32_t numRefs;
+  const BvhWideNode* wide;
+  const BvhSlot* slots;
+  size_t numWide;
+  float pad;  // what every child box is padded by before it is quantised
+};
+// Quantises the child boxes and packs nodes and leaf triangles into the device's record array — what the host code does
+// between "collapse" and the upload — from the order and the nodes the BvhTreeBuilder of the same `user` left behind.
+// Fills out.deviceRecs / out.deviceNumRecs (the caller owns the allocation: hipFree) and nothing else.
+using BvhPacker = bool (*)(void* user, const BvhPackInput& in, Bvh& out, std::string& err);
+// Test hook: the tree builder (and packer) buildBvh uses when its options name none (null = the host code).
+// bdpt_test_tree_builder (api.cpp) points it at the device implementation so that the host-only hash / check hooks can be
+// run over a device-built tree and compared with the host-built one.
 void bvhSetDefaultTreeBuilder(BvhTreeBuilder f, void* user);
-// the device implementation (bvh_device.hip); `user` points at the device ordinal (int)
+
+// The device implementation (bvh_device.hip).  One BvhDeviceBuild per build: the stages hand their results to one another
+// in device memory through it (`user` of both functions).
+struct BvhDeviceBuild;
+BvhDeviceBuild* bvhDeviceBuildBegin(int device);
+void bvhDeviceBuildEnd(BvhDeviceBuild* b);
 bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
+bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err);
 
 struct BvhBuildOptions {
   int threads = 0;                // <= 0: bvhBuildThreads()
@@ -238,6 +274,7 @@ struct BvhBuildOptions {
   float splitBudgetAlpha = -1.0f; // < 0: the build default (BDPT_SPLIT_BUDGET_ALPHA)
   const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
   BvhTreeBuilder treeBuilder = nullptr;    // null: the host code builds the binary tree
+  BvhPacker packer = nullptr;              // (with a treeBuilder only) null: the host code quantises and packs; else Bvh::deviceRecs is the result
   void* treeBuilderUser = nullptr;
   std::string* error = nullptr;            // receives the tree builder's message when it fails (the build then has no nodes)
 };

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -611,6 +612,10 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   out.maxDepth = 0;
   out.sahCost = 0.0f;
   out.numDropped = 0;
+  out.numNodes = 0;
+  out.numRefs = 0;
+  out.deviceRecs = nullptr;
+  out.deviceNumRecs = 0;
 
   // Triangle records exactly as the device intersects them: the "actual" triangle is
   // (v0, v0+e1, v0+e2) in fp32, so bounds are taken from those points.
@@ -845,6 +850,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   const BvhTreeBuilder treeBuilder = opt.treeBuilder ? opt.treeBuilder : gDefaultTreeBuilder;
   void* const treeBuilderUser = opt.treeBuilder ? opt.treeBuilderUser : gDefaultTreeBuilderUser;
   const bool plugged = treeBuilder && n > 0;
+  const BvhPacker packer = (plugged && opt.treeBuilder) ? opt.packer : nullptr;
   BigVec<Ref> scratch(plugged ? 0 : n);  // every partition scatters through the node's own range of it
   const BuildData B{refs, scratch};
   lap("records");
@@ -924,10 +930,11 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   }
 
   lap("append");
-  // Leaf-ordered triangle list.
-  out.tris.resize(n);
-  out.refBox.resize((size_t)n * 6);
-  parallelFor(n, threads, [&](size_t a, size_t b, int) {
+  out.numRefs = n;
+  // Leaf-ordered triangle list (a packer gathers it on the device).
+  out.tris.resize(packer ? 0 : n);
+  out.refBox.resize(packer ? 0 : (size_t)n * 6);
+  if (!packer) parallelFor(n, threads, [&](size_t a, size_t b, int) {
     for (size_t i = a; i < b; i++) {
       const Ref& r = plugged ? refs[order[i]] : refs[i];
       out.tris[i] = recs[refTri[r.id]];
@@ -940,12 +947,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
 
   // ---- collapse the binary tree into four-wide nodes and quantise the child boxes ----------------
   auto leafRef = [](uint32_t first, uint32_t count) -> int32_t { return -1 - (int32_t)((first << 3) | (count - 1)); };
-  struct Wide {
-    uint32_t src;            // tmp index of the subtree root this node covers
-    uint32_t kids[4];        // tmp indices of the (up to 4) children
-    int nk;
-    uint32_t depth;
-  };
+  using Wide = BvhWideNode;  // (src: tmp index of the subtree root this node covers; kids: tmp indices of the up to 4 children)
   if (n == 0) {
     BvhNode nd;
     std::memset(&nd, 0, sizeof(nd));
@@ -957,6 +959,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     for (int c = 0; c < 4; c++) nd.child[c] = -1;
     nd.scale[0] = nd.scale[1] = nd.scale[2] = 1.0f;
     out.nodes.push_back(nd);
+    out.numNodes = 1;
     packBvh(out, 1);
     return;
   }
@@ -972,7 +975,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       subtreeNodes[t] = 1 + subtreeNodes[(size_t)tmp[t].left] + subtreeNodes[(size_t)tmp[t].right];
     }
   std::vector<Wide> wide;
-  std::vector<std::pair<int32_t, int32_t>> slots;  // per wide node: where its index must be written
+  std::vector<BvhSlot> slots;  // per wide node: where its index must be written
   uint32_t wDepth = 0, wStack = 0;
   {
     struct Job {
@@ -981,7 +984,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     };
     // One subtree, depth first, appended to (W, SL); `defer` (may be null) receives the jobs of subtrees of at most
     // kCollapseGrain binary nodes instead of descending into them.
-    auto collapse = [&](Job rootJob, std::vector<Wide>& W, std::vector<std::pair<int32_t, int32_t>>& SL, std::vector<Job>* defer, uint32_t& dMax,
+    auto collapse = [&](Job rootJob, std::vector<Wide>& W, std::vector<BvhSlot>& SL, std::vector<Job>* defer, uint32_t& dMax,
                         uint32_t& sMax) {
       std::vector<Job> jobs;
       jobs.push_back(rootJob);
@@ -1021,7 +1024,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         }
         const uint32_t self = (uint32_t)W.size();
         W.push_back(w);
-        SL.push_back({j.slotNode, j.slotIdx});
+        SL.push_back(BvhSlot{j.slotNode, j.slotIdx});
         dMax = std::max(dMax, j.depth);
         const uint32_t need = j.stackAbove + (uint32_t)(w.nk - 1);
         sMax = std::max(sMax, need);
@@ -1042,7 +1045,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     if (!deferred.empty()) {
       struct Local {
         std::vector<Wide> w;
-        std::vector<std::pair<int32_t, int32_t>> sl;
+        std::vector<BvhSlot> sl;
         uint32_t dMax = 0, sMax = 0;
       };
       std::vector<Local> local(deferred.size());
@@ -1054,7 +1057,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         const int32_t parentNode = r.slotNode, parentIdx = r.slotIdx;
         r.slotNode = -2;  // marks the list's root: its slot is a node of the top part
         collapse(r, L.w, L.sl, nullptr, L.dMax, L.sMax);
-        L.sl[0] = {parentNode, parentIdx};
+        L.sl[0] = BvhSlot{parentNode, parentIdx};
       });
       std::vector<size_t> at(deferred.size() + 1);
       at[0] = wide.size();
@@ -1065,7 +1068,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         const Local& L = local[j];
         std::copy(L.w.begin(), L.w.end(), wide.begin() + (long)at[j]);
         slots[at[j]] = L.sl[0];  // (a node of the top part: global index already)
-        for (size_t i = 1; i < L.sl.size(); i++) slots[at[j] + i] = {L.sl[i].first + (int32_t)at[j], L.sl[i].second};
+        for (size_t i = 1; i < L.sl.size(); i++) slots[at[j] + i] = BvhSlot{L.sl[i].node + (int32_t)at[j], L.sl[i].idx};
       });
       for (const Local& L : local) {
         wDepth = std::max(wDepth, L.dMax);
@@ -1076,8 +1079,42 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   lap("collapse");
   out.maxDepth = wDepth;
   out.maxStack = wStack;
-  out.nodes.resize(wide.size());
+  out.numNodes = (uint32_t)wide.size();
   const float rootArea = tmp[0].box.area();
+  auto sahCost = [&] {
+    double cost = 0.0;  // one thread, node order: the sum's rounding does not depend on the thread count
+    if (rootArea > 0)
+      for (size_t wi = 0; wi < wide.size(); wi++)
+        for (int k = 0; k < wide[wi].nk; k++) {
+          const TmpNode& c = tmp[wide[wi].kids[k]];
+          cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
+        }
+    return (float)cost + kCostTraverse;
+  };
+  if (packer) {
+    // quantisation and packing happen where the tree was built; the host keeps only the summary
+    BvhPackInput in;
+    in.triRecs = recs.data();
+    in.numTris = nTris;
+    in.refTri = refTri.data();
+    in.numRefs = n;
+    in.wide = wide.data();
+    in.slots = slots.data();
+    in.numWide = wide.size();
+    in.pad = pad;
+    std::string err;
+    std::future<float> cost = std::async(std::launch::async, sahCost);  // (the host's one job meanwhile)
+    const bool ok = packer(treeBuilderUser, in, out, err);
+    out.sahCost = cost.get();
+    if (!ok) {
+      if (opt.error) *opt.error = err.empty() ? "packer failed" : err;
+      out.deviceRecs = nullptr;
+      out.deviceNumRecs = 0;
+    }
+    lap("device pack");
+    return;
+  }
+  out.nodes.resize(wide.size());
   parallelFor(wide.size(), threads, [&](size_t w0, size_t w1, int) {
   for (size_t wi = w0; wi < w1; wi++) {
     const Wide& w = wide[wi];
@@ -1139,15 +1176,8 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     out.nodes[wi] = nd;
   }
   });
-  double cost = 0.0;  // one thread, node order: the sum's rounding does not depend on the thread count
-  if (rootArea > 0)
-    for (size_t wi = 0; wi < wide.size(); wi++)
-      for (int k = 0; k < wide[wi].nk; k++) {
-        const TmpNode& c = tmp[wide[wi].kids[k]];
-        cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
-      }
-  for (size_t wi = 1; wi < wide.size(); wi++) out.nodes[(size_t)slots[wi].first].child[slots[wi].second] = (int32_t)wi;
-  out.sahCost = (float)cost + kCostTraverse;
+  for (size_t wi = 1; wi < wide.size(); wi++) out.nodes[(size_t)slots[wi].node].child[slots[wi].idx] = (int32_t)wi;
+  out.sahCost = sahCost();
   lap("quantise");
   if (!packBvh(out, threads)) out.recs.clear();  // (leaves of at most 8 triangles always fit: 3 x 8 < 256)
   lap("pack");

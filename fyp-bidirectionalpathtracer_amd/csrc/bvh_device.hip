@@ -33,6 +33,34 @@
 #include "bvh.h"
 
 namespace bdpt {
+
+// What one build's stages hand to one another in device memory.
+struct BvhDeviceBuild {
+  int device = 0;
+  BvhBuildNode* nodes = nullptr;  // the binary tree (buildBinaryTreeOnDevice)
+  uint32_t numNodes = 0;
+  uint32_t* order = nullptr;      // reference id at every position of the leaf order
+  uint32_t numRefs = 0;
+  void release() {
+    if (nodes) (void)hipFree(nodes);
+    if (order) (void)hipFree(order);
+    nodes = nullptr;
+    order = nullptr;
+    numNodes = numRefs = 0;
+  }
+};
+BvhDeviceBuild* bvhDeviceBuildBegin(int device) {
+  BvhDeviceBuild* b = new BvhDeviceBuild();
+  b->device = device;
+  return b;
+}
+void bvhDeviceBuildEnd(BvhDeviceBuild* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  b->release();
+  delete b;
+}
+
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -720,6 +748,111 @@ __global__ void k_pack_nodes(Tree T, uint32_t numNodes, BvhBuildNode* __restrict
   out[i] = nd;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quantise + pack on the device: what bvh_build.cpp does between "collapse" and packBvh, one thread per four-wide node,
+// the same float operations (subtractions, a division by a power of two, floor / ceil, comparisons).
+// ------------------------------------------------------------------------------------------------
+// child boxes -> origin, scale exponents, 8-bit planes, leaf bits, child offsets: everything of the node's record but
+// where it and its child block go; blockSize[i] = records in node i's child block
+__global__ void k_quantise(const BvhWideNode* __restrict__ wide, uint32_t nWide, const BvhBuildNode* __restrict__ nodes, float pad,
+                           BvhRec* __restrict__ recTmp, uint32_t* __restrict__ blockSize) {
+  const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= nWide) return;
+  const BvhWideNode w = wide[wi];
+  float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+  float clo[4][3], chi[4][3];
+  uint32_t leafBits = 0, offs = 0, off = 0;
+  for (int k = 0; k < 4; k++) {
+    if (k >= w.nk) break;
+    const BvhBuildNode c = nodes[w.kids[k]];
+    for (int a = 0; a < 3; a++) {
+      clo[k][a] = c.box.lo[a] - pad;
+      chi[k][a] = c.box.hi[a] + pad;
+      blo[a] = clo[k][a] < blo[a] ? clo[k][a] : blo[a];  // std::min(blo, clo)
+      bhi[a] = bhi[a] < chi[k][a] ? chi[k][a] : bhi[a];  // std::max(bhi, chi)
+    }
+    offs |= off << (8 * k);
+    if (c.left < 0) {
+      leafBits |= 1u << k;
+      off += c.count;
+    } else {
+      off += 1;
+    }
+  }
+  BvhRec rec;
+  for (int i = 0; i < 12; i++) rec.w[i] = 0;
+  uint32_t ex[3];
+  for (int a = 0; a < 3; a++) {
+    rec.w[a] = __float_as_uint(blo[a]);
+    const float d = bhi[a] - blo[a];
+    const float ext = d < 1e-30f ? 1e-30f : d;  // std::max(d, 1e-30f)
+    // frexp(ext / 254): ext / 254 = m 2^e, m in [0.5, 1) — a normal number here, so e = exponent field - 126
+    const int e = (int)((__float_as_uint(ext / 254.0f) >> 23) & 0xffu) - 126;
+    int biased = e + 127;
+    if (biased < 1) biased = 1;
+    if (biased > 254) biased = 254;
+    ex[a] = (uint32_t)biased;
+    const float sc = __uint_as_float((uint32_t)biased << 23);
+    uint32_t lo4 = 0, hi4 = 0;
+    for (int k = 0; k < 4; k++) {
+      if (k >= w.nk) {
+        lo4 |= 255u << (8 * k);
+        continue;
+      }
+      int ql = (int)floorf((clo[k][a] - blo[a]) / sc);
+      ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+      while (ql > 0 && blo[a] + (float)ql * sc > clo[k][a]) ql--;
+      int qh = (int)ceilf((chi[k][a] - blo[a]) / sc);
+      qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+      while (qh < 255 && blo[a] + (float)qh * sc < chi[k][a]) qh++;
+      lo4 |= (uint32_t)ql << (8 * k);
+      hi4 |= (uint32_t)qh << (8 * k);
+    }
+    rec.w[4 + a] = lo4;
+    rec.w[7 + a] = hi4;
+  }
+  rec.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (leafBits << 24);
+  rec.w[11] = offs;
+  recTmp[wi] = rec;
+  blockSize[wi] = off;
+}
+// where every node's record goes: into its parent's child block (the root: record 0)
+__global__ void k_node_pos(const BvhSlot* __restrict__ slots, uint32_t nWide, const BvhRec* __restrict__ recTmp, const uint32_t* __restrict__ baseExcl,
+                           uint32_t* __restrict__ pos) {
+  const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= nWide) return;
+  if (wi == 0) {
+    pos[0] = 0;
+    return;
+  }
+  const BvhSlot s = slots[wi];
+  pos[wi] = 1u + baseExcl[s.node] + ((recTmp[s.node].w[11] >> (8 * s.idx)) & 0xffu);
+}
+__global__ void k_write_recs(const BvhWideNode* __restrict__ wide, uint32_t nWide, const BvhBuildNode* __restrict__ nodes, const BvhRec* __restrict__ recTmp,
+                             const uint32_t* __restrict__ baseExcl, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ order,
+                             const uint32_t* __restrict__ refTri, const BvhTri* __restrict__ triRecs, BvhRec* __restrict__ recs) {
+  const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= nWide) return;
+  const BvhWideNode w = wide[wi];
+  BvhRec rec = recTmp[wi];
+  const uint32_t base = 1u + baseExcl[wi];
+  rec.w[10] = base;
+  recs[pos[wi]] = rec;
+  for (int k = 0; k < 4; k++) {
+    if (k >= w.nk || !((rec.w[3] >> (24 + k)) & 1u)) continue;
+    const uint32_t first = nodes[w.kids[k]].first, count = nodes[w.kids[k]].count;
+    const uint32_t at = base + ((rec.w[11] >> (8 * k)) & 0xffu);
+    for (uint32_t j = 0; j < count; j++) {
+      BvhTri t = triRecs[refTri[order[first + j]]];
+      if (j + 1 == count) t.flags |= kTriLastOfLeaf;
+      BvhRec out;
+      static_assert(sizeof(BvhTri) == sizeof(BvhRec), "one record per triangle");
+      __builtin_memcpy(&out, &t, sizeof(out));
+      recs[at + j] = out;
+    }
+  }
+}
+
 // Device -> pageable host memory through pinned staging buffers, the host-side copies shared among a few threads (a
 // plain hipMemcpy into pageable memory runs at ~3 GB/s here; the node list of a 10 M-triangle scene is 1 GB).
 bool downloadStaged(void* dst, const void* src, size_t bytes, std::string& err) {
@@ -806,9 +939,14 @@ bool allocLevel(std::vector<void*>& pool, Level& L, size_t cap, std::string& err
 
 }  // namespace
 
-// The BvhTreeBuilder bdpt_set_scene plugs into buildBvh; `user` points at the device ordinal (int).
+// The BvhTreeBuilder bdpt_set_scene plugs into buildBvh; `user` is the build's BvhDeviceBuild.
 bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err) {
-  const int device = user ? *static_cast<const int*>(user) : 0;
+  BvhDeviceBuild* const build = static_cast<BvhDeviceBuild*>(user);
+  if (!build) {
+    err = "device tree builder: no build object";
+    return false;
+  }
+  const int device = build->device;
   if (n == 0) return false;
   if (hipSetDevice(device) != hipSuccess) {
     err = "device tree builder: no such device";
@@ -967,9 +1105,22 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   if (stages)
     for (int i = 0; i < S_COUNT; i++) std::fprintf(stderr, "[bvh]   device stage %-10s %.4f s\n", stageName[i], stageTime[i]);
   // back to the host: the leaf order and the tree, in the host's formats (the boxes of the references are the caller's own)
-  uint32_t* dOrder = F;  // (n + 1 words, free by now)
-  BvhBuildNode* dNodes = nullptr;
-  if (!devAllocT(pool, &dNodes, numNodes, err)) return false;
+  // (both stay in device memory for the packer: the build object owns them from here on)
+  build->release();
+  {
+    void *q0 = nullptr, *q1 = nullptr;
+    if (hipMalloc(&q0, (size_t)n * 4) != hipSuccess || hipMalloc(&q1, (size_t)numNodes * sizeof(BvhBuildNode)) != hipSuccess) {
+      if (q0) (void)hipFree(q0);
+      err = "device tree builder: out of device memory";
+      return false;
+    }
+    build->order = static_cast<uint32_t*>(q0);
+    build->nodes = static_cast<BvhBuildNode*>(q1);
+    build->numRefs = n;
+    build->numNodes = numNodes;
+  }
+  uint32_t* const dOrder = build->order;
+  BvhBuildNode* const dNodes = build->nodes;
   hipLaunchKernelGGL(k_order, gridFor(n), blk, 0, st, rA, n, dOrder);
   hipLaunchKernelGGL(k_pack_nodes, gridFor(numNodes), blk, 0, st, T, numNodes, dNodes);
   if (!ok(hipDeviceSynchronize(), "pack")) return false;
@@ -977,6 +1128,92 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   nodes.resize(numNodes);
   if (!downloadStaged(order.data(), dOrder, (size_t)n * 4, err) || !downloadStaged(nodes.data(), dNodes, (size_t)numNodes * sizeof(BvhBuildNode), err)) return false;
   lap("download");
+  return true;
+}
+
+// The BvhPacker bdpt_set_scene plugs into buildBvh (after buildBinaryTreeOnDevice of the same build).
+bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err) {
+  BvhDeviceBuild* const build = static_cast<BvhDeviceBuild*>(user);
+  if (!build || !build->nodes || !build->order || build->numRefs != in.numRefs || in.numWide == 0 || in.numWide > 0x7fffffffull) {
+    err = "device packer: no tree of this build in device memory";
+    return false;
+  }
+  if (hipSetDevice(build->device) != hipSuccess) {
+    err = "device packer: no such device";
+    return false;
+  }
+  const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bvh]   device %-10s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
+  std::vector<void*> pool;
+  struct Free {
+    std::vector<void*>& p;
+    ~Free() {
+      for (void* q : p) (void)hipFree(q);
+    }
+  } freeAll{pool};
+  auto ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err = std::string("device packer: ") + what + ": " + hipGetErrorString(e);
+    return false;
+  };
+  const uint32_t nWide = (uint32_t)in.numWide;
+  BvhTri* dTri = nullptr;
+  uint32_t *dRefTri = nullptr, *dBlock = nullptr, *dBase = nullptr, *dPos = nullptr;
+  BvhWideNode* dWide = nullptr;
+  BvhSlot* dSlots = nullptr;
+  BvhRec* dTmp = nullptr;
+  Scan scan;
+  if (!devAllocT(pool, &dTri, in.numTris, err) || !devAllocT(pool, &dRefTri, in.numRefs, err) || !devAllocT(pool, &dWide, nWide, err) ||
+      !devAllocT(pool, &dSlots, nWide, err) || !devAllocT(pool, &dTmp, nWide, err) || !devAllocT(pool, &dBlock, (size_t)nWide + 1, err) ||
+      !devAllocT(pool, &dBase, (size_t)nWide + 1, err) || !devAllocT(pool, &dPos, nWide, err))
+    return false;
+  scan.capTiles = (nWide + kScanTile - 1) / kScanTile + 1;
+  if (!devAllocT(pool, &scan.sums, scan.capTiles, err) || !devAllocT(pool, &scan.total, 1, err)) return false;
+  if (!ok(hipMemcpy(dTri, in.triRecs, (size_t)in.numTris * sizeof(BvhTri), hipMemcpyHostToDevice), "upload") ||
+      !ok(hipMemcpy(dRefTri, in.refTri, (size_t)in.numRefs * 4, hipMemcpyHostToDevice), "upload") ||
+      !ok(hipMemcpy(dWide, in.wide, (size_t)nWide * sizeof(BvhWideNode), hipMemcpyHostToDevice), "upload") ||
+      !ok(hipMemcpy(dSlots, in.slots, (size_t)nWide * sizeof(BvhSlot), hipMemcpyHostToDevice), "upload"))
+    return false;
+  lap("pack upload");
+  hipStream_t st = nullptr;
+  const dim3 blk(256), grid((nWide + 255) / 256);
+  hipLaunchKernelGGL(k_quantise, grid, blk, 0, st, dWide, nWide, build->nodes, in.pad, dTmp, dBlock);
+  scan.run(dBlock, nWide, dBase, st);
+  uint32_t total = 0;
+  if (!ok(hipMemcpy(&total, dBase + nWide, 4, hipMemcpyDeviceToHost), "block sizes")) return false;
+  const uint64_t next = 1ull + total;
+  if (next >= 0x7fffffffull || total < nWide - 1) {  // (the 32-bit sum wrapped, or the format's 2^31 records are not enough)
+    err = "bvh does not fit the packed record format (2^31 records)";
+    return false;
+  }
+  void* q = nullptr;
+  const size_t numRecs = (size_t)next + kBvhPadRecs;
+  if (hipMalloc(&q, numRecs * sizeof(BvhRec)) != hipSuccess) {
+    err = "device packer: out of device memory";
+    return false;
+  }
+  BvhRec* const dRecs = static_cast<BvhRec*>(q);
+  bool good = ok(hipMemsetAsync(dRecs + next, 0, kBvhPadRecs * sizeof(BvhRec), st), "memset");
+  if (good) {
+    hipLaunchKernelGGL(k_node_pos, grid, blk, 0, st, dSlots, nWide, dTmp, dBase, dPos);
+    hipLaunchKernelGGL(k_write_recs, grid, blk, 0, st, dWide, nWide, build->nodes, dTmp, dBase, dPos, build->order, dRefTri, dTri, dRecs);
+    good = ok(hipGetLastError(), "launch") && ok(hipDeviceSynchronize(), "synchronise");
+  }
+  if (!good) {
+    (void)hipFree(dRecs);
+    return false;
+  }
+  lap("pack");
+  build->release();
+  out.deviceRecs = dRecs;
+  out.deviceNumRecs = numRecs;
   return true;
 }
 

@@ -90,9 +90,17 @@ def main():
             rc = lib.bdpt_bvh_build_hash(C.byref(sc.desc), 0, C.byref(h), C.byref(info))
             res.append((rc, h.value, info.numNodes, info.maxDepth, info.maxStack, info.sahCost, time.time() - t0))
         lib.bdpt_test_tree_builder(-1)
-        same = res[0][:6] == res[1][:6]
+        # the whole device pipeline (tree + quantise + pack) against the host's packed records
+        rh = []
+        for dev in ((0, 0) if only else (-1, 0)):
+            h = C.c_uint64()
+            info = pkg.abi.BvhInfo()
+            t0 = time.time()
+            rc = lib.bdpt_bvh_recs_hash(C.byref(sc.desc), dev, C.byref(h), C.byref(info))
+            rh.append((rc, h.value, info.numNodes, info.maxDepth, info.maxStack, info.sahCost, info.reserved, time.time() - t0))
+        same = res[0][:6] == res[1][:6] and rh[0][:7] == rh[1][:7] and rh[0][0] == 0
         bad += 0 if same else 1
-        print(f"{name:16s} host {res[0][1]:#018x} {res[0][2]:9d} nodes {res[0][6]:7.3f} s | device {res[1][1]:#018x} {res[1][2]:9d} nodes {res[1][6]:7.3f} s | {'SAME' if same else 'DIFFERENT'}", flush=True)
+        print(f"{name:16s} host {res[0][1]:#018x} {res[0][2]:9d} nodes {res[0][6]:7.3f} s | device {res[1][1]:#018x} {res[1][2]:9d} nodes {res[1][6]:7.3f} s | records {rh[0][1]:#018x} {rh[0][7]:6.3f} s / {rh[1][1]:#018x} {rh[1][7]:6.3f} s | {'SAME' if same else 'DIFFERENT'}", flush=True)
         sc.close()
     return 1 if bad else 0
 

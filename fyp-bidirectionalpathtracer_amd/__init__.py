@@ -313,11 +313,9 @@ class FramePipeline:
         t0 = time.time()
         self.ctx = Context(device)
         t1 = time.time()
-        self.scene = scene
-        self.ctx.set_scene(scene.desc)
-        t2 = time.time()
-        self.cam = scene.camera(self.W / self.H)
-        self.ctx.set_camera(self.cam)
+        # The frame's buffers first, the scene second: building the acceleration structure of a large scene takes and
+        # frees tens of GB of device scratch, and the driver wipes freed VRAM before it hands it out again — a 94 GB
+        # bdpt_resize issued right after such a bdpt_set_scene was measured waiting 1-1.7 s for that (0.01 s otherwise).
         # tile = (y0, y1): a contiguous band; stripes = (stripe_rows, num_owners, owner): interleaved stripes
         self.stripes = stripes
         if stripes is None:
@@ -325,6 +323,13 @@ class FramePipeline:
         else:
             self.ctx.resize_stripes(self.W, self.H, int(stripes[0]), int(stripes[1]), int(stripes[2]), self.max_depth)
         self.rows = self.ctx.row_ranges()
+        torch.cuda.synchronize(self.dev)
+        t2 = time.time()
+        self.scene = scene
+        self.ctx.set_scene(scene.desc)
+        self.cam = scene.camera(self.W / self.H)
+        self.ctx.set_camera(self.cam)
+        t3 = time.time()
         with torch.cuda.device(self.dev):
             self.channels = {"WorldPosition": torch.zeros(self.H, self.W, 4, dtype=torch.float32, device=self.dev)}
             for name in GBUFFER_CHANNELS[1:]:
@@ -333,7 +338,7 @@ class FramePipeline:
             self.last_frame = torch.zeros(self.H, self.W, 4, dtype=torch.float32, device=self.dev)
         torch.cuda.synchronize(self.dev)
         # where the set-up time went: the scene (acceleration structure + uploads) and the frame's buffers are separate things
-        self.setup_times = {"context_s": t1 - t0, "set_scene_s": t2 - t1, "buffers_s": time.time() - t2}
+        self.setup_times = {"context_s": t1 - t0, "resize_s": t2 - t1, "set_scene_s": t3 - t2, "channels_s": time.time() - t3}
         self.gb = GBuffer(*[self.channels[n].data_ptr() for n in GBUFFER_CHANNELS])
         self.gbuffer_frame = 0xdeadbeef
         self.bdpt_frame = 0x1337

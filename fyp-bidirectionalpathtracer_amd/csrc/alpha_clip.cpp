@@ -248,6 +248,23 @@ bool AlphaClipper::clip(uint32_t tri, double (*poly)[2], int& n) const {
   return n >= 3;
 }
 
+bool AlphaClipper::tables(BvhClipTables& out) const {
+  out.triMaterial = d_->triMaterial;
+  out.indices = d_->indices;
+  out.texcoords = d_->texcoords;
+  out.numTriangles = d_->numTriangles;
+  out.numVertices = d_->numVertices;
+  out.matMask.clear();
+  out.matVerdict.clear();
+  for (const MatInfo& m : mats_) {
+    out.matMask.push_back(m.mask);
+    out.matVerdict.push_back(m.verdict);
+  }
+  out.masks.clear();
+  for (const Mask& m : masks_) out.masks.push_back(BvhClipTables::Mask{m.w, m.h, m.mayPass.data()});
+  return true;
+}
+
 bool AlphaClipper::testFails(uint32_t tri, float bu, float bv) const {
   const bdpt_material& mm = d_->materials[d_->triMaterial[tri]];
   const uint32_t type = BDPT_FLAG_DIFFUSE_TYPE(mm.flags);

@@ -23,6 +23,7 @@ class AlphaClipper : public BvhRefClipper {
   // 0: both outcomes occur (or could not be decided), 1: the test always passes, 2: it always fails
   int classify(uint32_t tri) const;
   bool clip(uint32_t tri, double (*poly)[2], int& n) const override;
+  bool tables(BvhClipTables& out) const override;
   // the device's alpha test in the same fp32 arithmetic (device_scene.hpp alphaTestFails), for the host-side trace hook
   bool testFails(uint32_t tri, float bu, float bv) const;
 

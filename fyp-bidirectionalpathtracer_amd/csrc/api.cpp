@@ -343,7 +343,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
       BvhDeviceBuild* b;
       ~Build() { bvhDeviceBuildEnd(b); }
     } build{bvhDeviceBuildBegin(c->device)};
-    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb, buildBinaryTreeOnDevice, build.b, &treeError, packOnDevice);
+    buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb, buildBinaryTreeOnDevice, build.b, &treeError, packOnDevice, makeReferencesOnDevice);
     if (sb.bvh.deviceRecs) c->sceneAllocs.push_back(sb.bvh.deviceRecs);  // (the context's from here on)
     if (!treeError.empty()) {
       fail(c, "scene: " + treeError);
@@ -359,6 +359,12 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   if (bvh.maxStack > (uint32_t)kBvhMaxStack) {
     fail(c, "bvh needs a deeper traversal stack than the device provides");
     return BDPT_E_LIMIT;
+  }
+  if (!bvh.deviceRecs && !bvh.recs.empty()) {  // nothing to build a tree over (no triangle can be hit): the host's one empty node
+    const BvhRec* dRecs = nullptr;
+    if (int rc0 = devUpload(c, c->sceneAllocs, &dRecs, bvh.recs.data(), bvh.recs.size())) return rc0;
+    bvh.deviceRecs = const_cast<BvhRec*>(dRecs);
+    bvh.deviceNumRecs = bvh.recs.size();
   }
   if (!bvh.deviceRecs) {
     fail(c, "scene: the acceleration structure has no records");
@@ -1113,7 +1119,11 @@ int bdpt_bvh_recs_hash(const bdpt_scene_desc* d, int device, uint64_t* out_hash,
       BvhDeviceBuild* b;
       ~Build() { bvhDeviceBuildEnd(b); }
     } build{bvhDeviceBuildBegin(device)};
-    buildSceneBvh(d, 0, -1.0f, -1.0f, true, sb, buildBinaryTreeOnDevice, build.b, &error, packOnDevice);
+    buildSceneBvh(d, 0, -1.0f, -1.0f, true, sb, buildBinaryTreeOnDevice, build.b, &error, packOnDevice, makeReferencesOnDevice);
+    if (!sb.bvh.deviceRecs && !sb.bvh.recs.empty() && error.empty()) {  // (nothing to build a tree over: the host's one empty node)
+      recs = sb.bvh.recs.data();
+      numRecs = sb.bvh.recs.size();
+    } else {
     if (!sb.bvh.deviceRecs) return BDPT_E_HIP;
     fromDevice.resize(sb.bvh.deviceNumRecs);
     const hipError_t e = hipMemcpy(fromDevice.data(), sb.bvh.deviceRecs, fromDevice.size() * sizeof(BvhRec), hipMemcpyDeviceToHost);
@@ -1121,6 +1131,7 @@ int bdpt_bvh_recs_hash(const bdpt_scene_desc* d, int device, uint64_t* out_hash,
     if (e != hipSuccess || !error.empty()) return BDPT_E_HIP;
     recs = fromDevice.data();
     numRecs = fromDevice.size();
+    }
   }
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](const void* p, size_t n) {

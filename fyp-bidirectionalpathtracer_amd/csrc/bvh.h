@@ -167,9 +167,25 @@ struct Bvh {
 // piece where the test can pass.  `poly` is a convex polygon in the triangle's barycentric plane, vertex k =
 // (bu, bv) with P = v0 + bu e1 + bv e2, at most kBvhPolyMax vertices.  Returns false when nothing is left.
 constexpr int kBvhPolyMax = 24;
+// What a clipper decides with, as plain tables — for an implementation of the same decisions somewhere else (the device:
+// bvh_device.hip runs alpha_clip.cpp's clip() from these).  All pointers stay the clipper's / the scene's.
+struct BvhClipTables {
+  const uint32_t* triMaterial = nullptr;  // per triangle
+  const uint32_t* indices = nullptr;      // 3 per triangle
+  const float* texcoords = nullptr;       // 3 floats per vertex, or null
+  uint32_t numTriangles = 0, numVertices = 0;
+  std::vector<int32_t> matMask;     // per material: index into masks, -1: no texture decides
+  std::vector<int32_t> matVerdict;  // for matMask < 0: 1 the test always passes, 2 it always fails
+  struct Mask {
+    int32_t w, h;
+    const uint32_t* mayPass;  // summed-area table, (w + 1) x (h + 1): cells a sample may pass in
+  };
+  std::vector<Mask> masks;
+};
 struct BvhRefClipper {
   virtual ~BvhRefClipper() {}
   virtual bool clip(uint32_t tri, double (*poly)[2], int& n) const = 0;
+  virtual bool tables(BvhClipTables&) const { return false; }  // false: this clipper's decisions exist as code only
 };
 
 // ---- what the binary-tree stage of the builder works on (bvh_build.cpp on the host, bvh_device.hip on the device) ----
@@ -242,13 +258,26 @@ struct Bvh;
 struct BvhPackInput {
   const BvhTri* triRecs;  // one per input triangle
   uint32_t numTris;
-  const uint32_t* refTri;  // the triangle of every reference, by reference id
+  const uint32_t* refTri;  // the triangle of every reference, by reference id (null: the BvhRefMaker of this build kept it, and triRecs)
   uint32_t numRefs;
   const BvhWideNode* wide;
   const BvhSlot* slots;
   size_t numWide;
   float pad;  // what every child box is padded by before it is quantised
 };
+// Makes the references (bvh_build.cpp "References": every triangle's whole piece, shrunk by the clipper, split `splits`
+// times, every piece clipped again) somewhere else, in the host code's order, and keeps them there for the
+// BvhTreeBuilder of the same `user` (which is then called with refs = null) and the BvhPacker.
+struct BvhRefInput {
+  const BvhTri* triRecs;   // one per input triangle
+  const BvhBox* triBox;
+  const uint32_t* splits;  // split count per triangle
+  const uint8_t* state;    // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
+  uint32_t numTris;
+  double gridLo[3], gridExt[3];      // the scene box: the split planes are its spatial medians
+  const BvhRefClipper* clipper;      // for the non-opaque triangles; may be null
+};
+using BvhRefMaker = bool (*)(void* user, const BvhRefInput& in, uint32_t& numRefs, std::string& err);
 // Quantises the child boxes and packs nodes and leaf triangles into the device's record array — what the host code does
 // between "collapse" and the upload — from the order and the nodes the BvhTreeBuilder of the same `user` left behind.
 // Fills out.deviceRecs / out.deviceNumRecs (the caller owns the allocation: hipFree) and nothing else.
@@ -265,6 +294,7 @@ BvhDeviceBuild* bvhDeviceBuildBegin(int device);
 void bvhDeviceBuildEnd(BvhDeviceBuild* b);
 bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
 bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err);
+bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs, std::string& err);
 
 struct BvhBuildOptions {
   int threads = 0;                // <= 0: bvhBuildThreads()
@@ -274,6 +304,7 @@ struct BvhBuildOptions {
   float splitBudgetAlpha = -1.0f; // < 0: the build default (BDPT_SPLIT_BUDGET_ALPHA)
   const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
   BvhTreeBuilder treeBuilder = nullptr;    // null: the host code builds the binary tree
+  BvhRefMaker refMaker = nullptr;          // (with a treeBuilder and a packer only) null: the host code makes the references
   BvhPacker packer = nullptr;              // (with a treeBuilder only) null: the host code quantises and packs; else Bvh::deviceRecs is the result
   void* treeBuilderUser = nullptr;
   std::string* error = nullptr;            // receives the tree builder's message when it fails (the build then has no nodes)

@@ -792,7 +792,27 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   // 40-byte records the tree is built over (box, centre, reference index) + the triangle every reference belongs to
   BigVec<Ref> refs;
   BigVec<uint32_t> refTri;
-  {
+  // (a plugged-in reference maker — bdpt_set_scene: the device — makes the same references in the same order and keeps them)
+  const BvhRefMaker refMaker = (opt.treeBuilder && opt.packer) ? opt.refMaker : nullptr;
+  uint32_t madeElsewhere = 0;
+  if (refMaker) {
+    BvhRefInput in;
+    in.triRecs = recs.data();
+    in.triBox = triBox.data();
+    in.splits = splits.data();
+    in.state = state.data();
+    in.numTris = nTris;
+    for (int a = 0; a < 3; a++) {
+      in.gridLo[a] = G.lo[a];
+      in.gridExt[a] = G.ext[a];
+    }
+    in.clipper = opt.clipper;
+    std::string err;
+    if (!refMaker(opt.treeBuilderUser, in, madeElsewhere, err)) {
+      if (opt.error) *opt.error = err.empty() ? "reference maker failed" : err;
+      return;
+    }
+  } else {
     std::vector<RefOut> part((nTris + kRefChunk - 1) / kRefChunk);  // one per chunk, appended in chunk order below
     parallelChunks(nTris, threads, kRefChunk, [&](size_t ci, size_t t0, size_t t1) {
       RefOut& o = part[ci];
@@ -843,7 +863,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     for (uint32_t t = 0; t < nTris; t++) dropped += state[t] == 2 ? 1u : 0u;
     out.numDropped = dropped;
   }
-  const uint32_t n = (uint32_t)refs.size();  // references from here on
+  const uint32_t n = refMaker ? madeElsewhere : (uint32_t)refs.size();  // references from here on
   if (verbose) std::fprintf(stderr, "[bvh] %u triangles -> %u references (%u dropped)\n", nTris, n, out.numDropped);
   BigVec<TmpNode> tmp;
   BigVec<uint32_t> order;  // filled by a plugged-in tree builder: the leaf order as reference ids (the host code permutes `refs` itself)
@@ -858,7 +878,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     // the binary tree is built elsewhere (bdpt_set_scene: on the device, bvh_device.hip) — the same decisions, the same
     // order of the references, the same tree as the host code below; children come after their parents there too
     std::string err;
-    if (!treeBuilder(treeBuilderUser, refs.data(), n, order, tmp, err) || tmp.empty() || order.size() != n) {
+    if (!treeBuilder(treeBuilderUser, refMaker ? nullptr : refs.data(), n, order, tmp, err) || tmp.empty() || (!refMaker && order.size() != n)) {
       if (opt.error) *opt.error = err.empty() ? "tree builder failed" : err;
       out.nodes.clear();
       out.tris.clear();
@@ -1096,7 +1116,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     BvhPackInput in;
     in.triRecs = recs.data();
     in.numTris = nTris;
-    in.refTri = refTri.data();
+    in.refTri = refMaker ? nullptr : refTri.data();
     in.numRefs = n;
     in.wide = wide.data();
     in.slots = slots.data();

@@ -41,12 +41,27 @@ struct BvhDeviceBuild {
   uint32_t numNodes = 0;
   uint32_t* order = nullptr;      // reference id at every position of the leaf order
   uint32_t numRefs = 0;
-  void release() {
+  BvhBuildRef* refs = nullptr;    // makeReferencesOnDevice: the references (until the tree builder takes them) ...
+  uint32_t numMadeRefs = 0;
+  uint32_t* refTri = nullptr;     // ... the triangle of each, and the triangle records (for the packer)
+  BvhTri* triRecs = nullptr;
+  uint32_t numTris = 0;
+  void releaseTree() {
     if (nodes) (void)hipFree(nodes);
     if (order) (void)hipFree(order);
     nodes = nullptr;
     order = nullptr;
     numNodes = numRefs = 0;
+  }
+  void release() {
+    releaseTree();
+    if (refs) (void)hipFree(refs);
+    if (refTri) (void)hipFree(refTri);
+    if (triRecs) (void)hipFree(triRecs);
+    refs = nullptr;
+    refTri = nullptr;
+    triRecs = nullptr;
+    numMadeRefs = numTris = 0;
   }
 };
 BvhDeviceBuild* bvhDeviceBuildBegin(int device) {
@@ -853,6 +868,400 @@ __global__ void k_write_recs(const BvhWideNode* __restrict__ wide, uint32_t nWid
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// References on the device: bvh_build.cpp's wholePiece + splitTriangle and alpha_clip.cpp's clip(), one thread per
+// triangle — the same double-precision operations in the same order (no contraction: the Makefile's -ffp-contract=off),
+// so the same pieces, the same boxes, in the same order.
+// ------------------------------------------------------------------------------------------------
+struct DevPiece {
+  double b[kBvhPolyMax][2];
+  int n;
+  uint32_t splits;
+  float lo[3], hi[3];
+};
+struct DevMask {
+  int32_t w, h;
+  const uint32_t* mayPass;
+};
+struct RefArgs {
+  const BvhTri* triRecs;
+  const BvhBox* triBox;
+  const uint32_t* splits;
+  const uint8_t* state;
+  uint32_t numTris;
+  double gridLo[3], gridExt[3];
+  int haveClipper;
+  const uint32_t* triMaterial;
+  const uint32_t* indices;
+  const float* texcoords;  // may be null
+  const int32_t* matMask;
+  const int32_t* matVerdict;
+  const DevMask* masks;
+};
+
+BDV float floatDownD(double x) {
+  float f = (float)x;
+  if ((double)f > x) {  // nextafterf(f, -inf)
+    const uint32_t u = __float_as_uint(f);
+    f = (f == 0.0f) ? -__uint_as_float(1u) : __uint_as_float((u & 0x80000000u) ? u + 1u : u - 1u);
+  }
+  return f;
+}
+BDV float floatUpD(double x) {
+  float f = (float)x;
+  if ((double)f < x) {  // nextafterf(f, +inf)
+    const uint32_t u = __float_as_uint(f);
+    f = (f == 0.0f) ? __uint_as_float(1u) : __uint_as_float((u & 0x80000000u) ? u - 1u : u + 1u);
+  }
+  return f;
+}
+BDV double dmin(double a, double b) { return b < a ? b : a; }  // std::min(a, b)
+BDV double dmax(double a, double b) { return a < b ? b : a; }  // std::max(a, b)
+
+// Sutherland-Hodgman against the closed half-plane A + B bu + C bv <= 0 (clipHalfPlane)
+__device__ int devClipHalfPlane(const double (*in)[2], int n, double A, double B, double C, double (*out)[2]) {
+  int m = 0;
+  for (int k = 0; k < n; k++) {
+    const double* p = in[k];
+    const double* q = in[(k + 1) % n];
+    const double fp = A + B * p[0] + C * p[1], fq = A + B * q[0] + C * q[1];
+    if (fp <= 0.0 && m < kBvhPolyMax) {
+      out[m][0] = p[0];
+      out[m][1] = p[1];
+      m++;
+    }
+    if (((fp < 0.0 && fq > 0.0) || (fp > 0.0 && fq < 0.0)) && m < kBvhPolyMax) {
+      const double t = fp / (fp - fq);
+      out[m][0] = p[0] + t * (q[0] - p[0]);
+      out[m][1] = p[1] + t * (q[1] - p[1]);
+      m++;
+    }
+  }
+  return m;
+}
+__device__ int devClipInPlace(double (*poly)[2], int n, double A, double B, double C) {
+  double out[kBvhPolyMax][2];
+  const int m = devClipHalfPlane(poly, n, A, B, C, out);
+  for (int k = 0; k < m; k++) {
+    poly[k][0] = out[k][0];
+    poly[k][1] = out[k][1];
+  }
+  return m;
+}
+__device__ double devPolyArea2(const double (*b)[2], int n) {
+  double s = 0;
+  for (int k = 0; k < n; k++) {
+    const double* p = b[k];
+    const double* q = b[(k + 1) % n];
+    s += p[0] * q[1] - q[0] * p[1];
+  }
+  return fabs(s);
+}
+// intersectBox(polyBox(r, b, n), outer)
+__device__ void devPolyBoxIn(const BvhTri& r, const double (*b)[2], int n, const float* outerLo, const float* outerHi, float* lo, float* hi) {
+  double dlo[3] = {1e300, 1e300, 1e300}, dhi[3] = {-1e300, -1e300, -1e300};
+  for (int k = 0; k < n; k++)
+    for (int a = 0; a < 3; a++) {
+      const double p = (double)r.v0[a] + b[k][0] * (double)r.e1[a] + b[k][1] * (double)r.e2[a];
+      dlo[a] = dmin(dlo[a], p);
+      dhi[a] = dmax(dhi[a], p);
+    }
+  for (int a = 0; a < 3; a++) {
+    const float pl = floatDownD(dlo[a]), ph = floatUpD(dhi[a]);
+    lo[a] = pl < outerLo[a] ? outerLo[a] : pl;  // std::max(a.lo, b.lo)
+    hi[a] = outerHi[a] < ph ? outerHi[a] : ph;  // std::min(a.hi, b.hi)
+    if (hi[a] < lo[a]) hi[a] = lo[a];
+  }
+}
+// SplitGrid::plane
+__device__ int devPlane(const RefArgs& A, int axis, float a, float b, double& coord) {
+  if (!(A.gridExt[axis] > 0.0) || !(b > a)) return -1;
+  const double s = 1073741824.0 / A.gridExt[axis];
+  double ua = floor(((double)a - A.gridLo[axis]) * s), ub = floor(((double)b - A.gridLo[axis]) * s);
+  ua = dmin(dmax(ua, 0.0), 1073741823.0);
+  ub = dmin(dmax(ub, 0.0), 1073741823.0);
+  const uint32_t ia = (uint32_t)ua, ib = (uint32_t)ub;
+  if (ia == ib) return -1;
+  const uint32_t diff = ia ^ ib;
+  const int h = 31 - __clz((int)diff);
+  const uint32_t pl = (ib >> h) << h;
+  coord = A.gridLo[axis] + (double)pl / s;
+  if (!(coord > (double)a && coord < (double)b)) return -1;
+  return h;
+}
+__device__ int devDominant(const RefArgs& A, const float* lo, const float* hi, int& axis, double& coord) {
+  int best = -1;
+  float bestExt = -1.0f;
+  for (int a = 0; a < 3; a++) {
+    double c = 0.0;
+    const int h = devPlane(A, a, lo[a], hi[a], c);
+    const float e = hi[a] - lo[a];
+    if (h > best || (h == best && h >= 0 && e > bestExt)) {
+      best = h;
+      bestExt = e;
+      axis = a;
+      coord = c;
+    }
+  }
+  return best;
+}
+BDV long long devFloorDiv(long long a, long long n) {
+  long long q = a / n;
+  if ((a % n) != 0 && ((a < 0) != (n < 0))) q--;
+  return q;
+}
+// AlphaClipper::Mask::count over mayPass
+__device__ uint32_t devCount(const DevMask& m, long long x0, long long x1, long long y0, long long y1) {
+  if (x1 < x0 || y1 < y0) return 0;
+  const size_t W1 = (size_t)m.w + 1;
+  const uint32_t* sat = m.mayPass;
+  long long xs[2][2], ys[2][2];
+  int nx = 0, ny = 0;
+  {
+    const long long s = devFloorDiv(x0, m.w) * m.w, a = x0 - s, b = x1 - s;
+    if (b < m.w) {
+      xs[nx][0] = a, xs[nx][1] = b, nx++;
+    } else {
+      xs[nx][0] = a, xs[nx][1] = m.w - 1, nx++;
+      xs[nx][0] = 0, xs[nx][1] = (b - m.w) < (long long)(m.w - 1) ? (b - m.w) : (long long)(m.w - 1), nx++;
+    }
+  }
+  {
+    const long long s = devFloorDiv(y0, m.h) * m.h, a = y0 - s, b = y1 - s;
+    if (b < m.h) {
+      ys[ny][0] = a, ys[ny][1] = b, ny++;
+    } else {
+      ys[ny][0] = a, ys[ny][1] = m.h - 1, ny++;
+      ys[ny][0] = 0, ys[ny][1] = (b - m.h) < (long long)(m.h - 1) ? (b - m.h) : (long long)(m.h - 1), ny++;
+    }
+  }
+  uint32_t c = 0;
+  for (int i = 0; i < nx; i++)
+    for (int j = 0; j < ny; j++) {
+      const long long xa = xs[i][0], xb = xs[i][1], ya = ys[j][0], yb = ys[j][1];
+      c += sat[((size_t)yb + 1) * W1 + (size_t)xb + 1] - sat[(size_t)ya * W1 + (size_t)xb + 1] - sat[((size_t)yb + 1) * W1 + (size_t)xa] +
+           sat[(size_t)ya * W1 + (size_t)xa];
+    }
+  return c;
+}
+// AlphaClipper::clip
+__device__ bool devClip(const RefArgs& A, uint32_t tri, double (*poly)[2], int& n) {
+  const uint32_t mat = A.triMaterial[tri];
+  const int32_t mask = A.matMask[mat];
+  if (mask < 0) return A.matVerdict[mat] != 2;
+  // cellRect
+  if (!A.texcoords) return true;
+  const DevMask m = A.masks[mask];
+  double uv[3][2], big = 0.0;
+  for (int k = 0; k < 3; k++) {
+    const uint32_t vi = A.indices[(size_t)tri * 3 + (size_t)k];
+    uv[k][0] = (double)A.texcoords[(size_t)vi * 3];
+    uv[k][1] = (double)A.texcoords[(size_t)vi * 3 + 1];
+    if (!isfinite(uv[k][0]) || !isfinite(uv[k][1])) return true;
+    big = dmax(big, dmax(fabs(uv[k][0]), fabs(uv[k][1])));
+  }
+  if (big > 4096.0) return true;
+  const double margin = 0.5 + 1e-5 * (big + 1.0) * (double)(m.w < m.h ? m.h : m.w);
+  double xa = 1e300, xb = -1e300, ya = 1e300, yb = -1e300;
+  for (int k = 0; k < n; k++) {
+    const double b0 = 1.0 - poly[k][0] - poly[k][1];
+    const double u = uv[0][0] * b0 + uv[1][0] * poly[k][0] + uv[2][0] * poly[k][1];
+    const double v = uv[0][1] * b0 + uv[1][1] * poly[k][0] + uv[2][1] * poly[k][1];
+    const double x = u * (double)m.w - 0.5, y = v * (double)m.h - 0.5;
+    xa = dmin(xa, x);
+    xb = dmax(xb, x);
+    ya = dmin(ya, y);
+    yb = dmax(yb, y);
+  }
+  long long x0 = (long long)floor(xa - margin), x1 = (long long)floor(xb + margin);
+  long long y0 = (long long)floor(ya - margin), y1 = (long long)floor(yb + margin);
+  const bool fullX = x1 - x0 + 1 >= m.w, fullY = y1 - y0 + 1 >= m.h;
+  if (fullX) x0 = 0, x1 = m.w - 1;
+  if (fullY) y0 = 0, y1 = m.h - 1;
+  if (devCount(m, x0, x1, y0, y1) == 0) return false;
+  const double du1 = uv[1][0] - uv[0][0], du2 = uv[2][0] - uv[0][0], dv1 = uv[1][1] - uv[0][1], dv2 = uv[2][1] - uv[0][1];
+  if (!fullX) {
+    long long a = x0, b = x1;  // firstCol
+    while (a < b) {
+      const long long mid = a + (b - a) / 2;
+      if (devCount(m, x0, mid, y0, y1) > 0)
+        b = mid;
+      else
+        a = mid + 1;
+    }
+    const long long c0 = a;
+    a = x0, b = x1;  // lastCol
+    while (a < b) {
+      const long long mid = a + (b - a + 1) / 2;
+      if (devCount(m, mid, x1, y0, y1) > 0)
+        a = mid;
+      else
+        b = mid - 1;
+    }
+    const long long c1 = a;
+    const double uLo = ((double)c0 + 0.5 - margin) / (double)m.w, uHi = ((double)c1 + 1.5 + margin) / (double)m.w;
+    if (c0 > x0) n = devClipInPlace(poly, n, uLo - uv[0][0], -du1, -du2);
+    if (n >= 3 && c1 < x1) n = devClipInPlace(poly, n, uv[0][0] - uHi, du1, du2);
+  }
+  if (n >= 3 && !fullY) {
+    long long a = y0, b = y1;  // firstRow
+    while (a < b) {
+      const long long mid = a + (b - a) / 2;
+      if (devCount(m, x0, x1, y0, mid) > 0)
+        b = mid;
+      else
+        a = mid + 1;
+    }
+    const long long r0 = a;
+    a = y0, b = y1;  // lastRow
+    while (a < b) {
+      const long long mid = a + (b - a + 1) / 2;
+      if (devCount(m, x0, x1, mid, y1) > 0)
+        a = mid;
+      else
+        b = mid - 1;
+    }
+    const long long r1 = a;
+    const double vLo = ((double)r0 + 0.5 - margin) / (double)m.h, vHi = ((double)r1 + 1.5 + margin) / (double)m.h;
+    if (r0 > y0) n = devClipInPlace(poly, n, vLo - uv[0][1], -dv1, -dv2);
+    if (n >= 3 && r1 < y1) n = devClipInPlace(poly, n, uv[0][1] - vHi, dv1, dv2);
+  }
+  return n >= 3;
+}
+
+// upper bounds: a triangle makes at most splits + 1 references and stacks at most `splits` pieces
+__global__ void k_ref_caps(RefArgs A, uint32_t* __restrict__ capRefs, uint32_t* __restrict__ capStack) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.numTris) return;
+  const bool dropped = A.state[t] == 2;
+  capRefs[t] = dropped ? 0u : A.splits[t] + 1u;
+  capStack[t] = dropped ? 0u : A.splits[t];
+}
+// pass 2 of bvh_build.cpp for triangle t: its references' boxes into boxes[slotAt[t] ...], their number into made[t]
+__global__ __launch_bounds__(64) void k_make_refs(RefArgs A, const uint32_t* __restrict__ slotAt, const uint32_t* __restrict__ stackAt,
+                                                  DevPiece* __restrict__ stacks, BvhBox* __restrict__ boxes, uint32_t* __restrict__ made) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.numTris) return;
+  const uint32_t st = A.state[t];
+  if (st == 2) {
+    made[t] = 0;
+    return;
+  }
+  BvhBox* const out = boxes + slotAt[t];
+  const uint32_t nSplits = A.splits[t];
+  const BvhBox tb = A.triBox[t];
+  if (nSplits == 0 && st == 0) {
+    out[0] = tb;
+    made[t] = 1;
+    return;
+  }
+  const BvhTri r = A.triRecs[t];
+  const bool alpha = (r.flags & kTriNonOpaque) != 0 && A.haveClipper;
+  // wholePiece
+  DevPiece pc;
+  pc.n = 3;
+  pc.b[0][0] = 0.0;
+  pc.b[0][1] = 0.0;
+  pc.b[1][0] = 1.0;
+  pc.b[1][1] = 0.0;
+  pc.b[2][0] = 0.0;
+  pc.b[2][1] = 1.0;
+  for (int a = 0; a < 3; a++) {
+    pc.lo[a] = tb.lo[a];
+    pc.hi[a] = tb.hi[a];
+  }
+  if (alpha) {
+    if (!devClip(A, t, pc.b, pc.n) || pc.n < 3) {  // (cannot happen: pass 1 kept it)
+      made[t] = 0;
+      return;
+    }
+    const bool shrunk =
+        !(pc.n == 3 && pc.b[0][0] == 0.0 && pc.b[0][1] == 0.0 && pc.b[1][0] == 1.0 && pc.b[1][1] == 0.0 && pc.b[2][0] == 0.0 && pc.b[2][1] == 1.0);
+    if (shrunk) devPolyBoxIn(r, pc.b, pc.n, tb.lo, tb.hi, pc.lo, pc.hi);
+  }
+  uint32_t m = 0;
+  auto emit = [&](const DevPiece& p) {
+    BvhBox bx;
+    for (int a = 0; a < 3; a++) {
+      bx.lo[a] = p.lo[a];
+      bx.hi[a] = p.hi[a];
+    }
+    out[m++] = bx;
+  };
+  if (nSplits == 0) {
+    emit(pc);
+    made[t] = m;
+    return;
+  }
+  pc.splits = nSplits;
+  // splitTriangle
+  DevPiece* const stack = stacks + stackAt[t];
+  uint32_t sp = 0;
+  for (;;) {
+    for (int guard = 0;; guard++) {
+      int axis = 0;
+      double c = 0;
+      if (pc.splits == 0 || guard > 96 || pc.n + 2 > kBvhPolyMax || devDominant(A, pc.lo, pc.hi, axis, c) < 0) {
+        emit(pc);
+        break;
+      }
+      const double PA = (double)r.v0[axis] - c, PB = (double)r.e1[axis], PC = (double)r.e2[axis];
+      DevPiece lo, hi;
+      lo.n = devClipHalfPlane(pc.b, pc.n, PA, PB, PC, lo.b);
+      hi.n = devClipHalfPlane(pc.b, pc.n, -PA, -PB, -PC, hi.b);
+      bool haveLo = lo.n >= 3 && devPolyArea2(lo.b, lo.n) > 0.0, haveHi = hi.n >= 3 && devPolyArea2(hi.b, hi.n) > 0.0;
+      if (alpha) {
+        if (haveLo) haveLo = devClip(A, t, lo.b, lo.n) && lo.n >= 3;
+        if (haveHi) haveHi = devClip(A, t, hi.b, hi.n) && hi.n >= 3;
+      }
+      if (haveLo) devPolyBoxIn(r, lo.b, lo.n, pc.lo, pc.hi, lo.lo, lo.hi);
+      if (haveHi) devPolyBoxIn(r, hi.b, hi.n, pc.lo, pc.hi, hi.lo, hi.hi);
+      if (!haveLo && !haveHi) {
+        if (!alpha) emit(pc);  // (a sliver the clip lost to rounding: keep the piece as it was)
+        break;
+      }
+      if (!haveLo || !haveHi) {
+        const uint32_t s = pc.splits;
+        pc = haveLo ? lo : hi;
+        pc.splits = s;
+        continue;
+      }
+      const uint32_t rest = pc.splits - 1;
+      const double wl = ((double)lo.hi[0] - lo.lo[0]) + ((double)lo.hi[1] - lo.lo[1]) + ((double)lo.hi[2] - lo.lo[2]);
+      const double wh = ((double)hi.hi[0] - hi.lo[0]) + ((double)hi.hi[1] - hi.lo[1]) + ((double)hi.hi[2] - hi.lo[2]);
+      uint32_t sl = (wl + wh > 0.0) ? (uint32_t)floor((double)rest * wl / (wl + wh) + 0.5) : rest / 2;
+      if (sl > rest) sl = rest;
+      lo.splits = sl;
+      hi.splits = rest - sl;
+      stack[sp++] = hi;
+      pc = lo;
+      guard = 0;
+    }
+    if (sp == 0) break;
+    pc = stack[--sp];
+  }
+  made[t] = m;
+}
+// the references in triangle order: box (-0 -> +0), centre, id = index; and the triangle of each
+__global__ void k_compact_refs(uint32_t numTris, const uint32_t* __restrict__ slotAt, const uint32_t* __restrict__ made, const uint32_t* __restrict__ refAt,
+                               const BvhBox* __restrict__ boxes, BvhBuildRef* __restrict__ refs, uint32_t* __restrict__ refTri) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= numTris) return;
+  const uint32_t m = made[t], at = refAt[t];
+  for (uint32_t j = 0; j < m; j++) {
+    const BvhBox bx = boxes[slotAt[t] + j];
+    BvhBuildRef r;
+    for (int k = 0; k < 3; k++) {
+      r.box.lo[k] = bx.lo[k] + 0.0f;
+      r.box.hi[k] = bx.hi[k] + 0.0f;
+      r.cent[k] = 0.5f * (r.box.lo[k] + r.box.hi[k]) + 0.0f;
+    }
+    r.id = at + j;
+    refs[at + j] = r;
+    refTri[at + j] = t;
+  }
+}
+
 // Device -> pageable host memory through pinned staging buffers, the host-side copies shared among a few threads (a
 // plain hipMemcpy into pageable memory runs at ~3 GB/s here; the node list of a 10 M-triangle scene is 1 GB).
 bool downloadStaged(void* dst, const void* src, size_t bytes, std::string& err) {
@@ -996,7 +1405,16 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   Tree T;
   Scan scan;
   const size_t binWords = ((size_t)n / (kSmall + 1) + 1) * 3 * kBvhBins * kBinWords;  // (binsOf)
-  if (!devAllocT(pool, &rA, n, err) || !devAllocT(pool, &rB, n, err) || !devAllocT(pool, &ofA, n, err) || !devAllocT(pool, &ofB, n, err) ||
+  if (!refs) {  // the references of makeReferencesOnDevice: this function's from here on
+    if (!build->refs || build->numMadeRefs != n) {
+      err = "device tree builder: no references of this build in device memory";
+      return false;
+    }
+    rA = build->refs;
+    pool.push_back(rA);
+    build->refs = nullptr;
+  }
+  if ((refs && !devAllocT(pool, &rA, n, err)) || !devAllocT(pool, &rB, n, err) || !devAllocT(pool, &ofA, n, err) || !devAllocT(pool, &ofB, n, err) ||
       !devAllocT(pool, &F, (size_t)n + 1, err) || !devAllocT(pool, &S, (size_t)n + 1, err) || !devAllocT(pool, &G, cap + 1, err) ||
       !devAllocT(pool, &R, cap + 1, err) || !devAllocT(pool, &bins, binWords, err) || !devAllocT(pool, &bigList, cap, err) ||
       !devAllocT(pool, &bigCount, 1, err) || !devAllocT(pool, &C, 1, err) || !allocLevel(pool, L[0], cap, err) || !allocLevel(pool, L[1], cap, err) ||
@@ -1006,7 +1424,7 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   scan.capTiles = (uint32_t)((std::max<size_t>(n, cap) + kScanTile - 1) / kScanTile) + 1;
   if (!devAllocT(pool, &scan.sums, scan.capTiles, err) || !devAllocT(pool, &scan.total, 1, err)) return false;
   lap("alloc");
-  if (!ok(hipMemcpy(rA, refs, (size_t)n * sizeof(BvhBuildRef), hipMemcpyHostToDevice), "upload")) return false;
+  if (refs && !ok(hipMemcpy(rA, refs, (size_t)n * sizeof(BvhBuildRef), hipMemcpyHostToDevice), "upload")) return false;
   lap("upload");
 
   const dim3 blk(256);
@@ -1106,7 +1524,7 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
     for (int i = 0; i < S_COUNT; i++) std::fprintf(stderr, "[bvh]   device stage %-10s %.4f s\n", stageName[i], stageTime[i]);
   // back to the host: the leaf order and the tree, in the host's formats (the boxes of the references are the caller's own)
   // (both stay in device memory for the packer: the build object owns them from here on)
-  build->release();
+  build->releaseTree();
   {
     void *q0 = nullptr, *q1 = nullptr;
     if (hipMalloc(&q0, (size_t)n * 4) != hipSuccess || hipMalloc(&q1, (size_t)numNodes * sizeof(BvhBuildNode)) != hipSuccess) {
@@ -1124,9 +1542,10 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   hipLaunchKernelGGL(k_order, gridFor(n), blk, 0, st, rA, n, dOrder);
   hipLaunchKernelGGL(k_pack_nodes, gridFor(numNodes), blk, 0, st, T, numNodes, dNodes);
   if (!ok(hipDeviceSynchronize(), "pack")) return false;
-  order.resize(n);
+  order.resize(refs ? n : 0);  // (references that never left the device: the packer reads the order there)
   nodes.resize(numNodes);
-  if (!downloadStaged(order.data(), dOrder, (size_t)n * 4, err) || !downloadStaged(nodes.data(), dNodes, (size_t)numNodes * sizeof(BvhBuildNode), err)) return false;
+  if ((refs && !downloadStaged(order.data(), dOrder, (size_t)n * 4, err)) || !downloadStaged(nodes.data(), dNodes, (size_t)numNodes * sizeof(BvhBuildNode), err))
+    return false;
   lap("download");
   return true;
 }
@@ -1170,14 +1589,23 @@ bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err
   BvhSlot* dSlots = nullptr;
   BvhRec* dTmp = nullptr;
   Scan scan;
-  if (!devAllocT(pool, &dTri, in.numTris, err) || !devAllocT(pool, &dRefTri, in.numRefs, err) || !devAllocT(pool, &dWide, nWide, err) ||
+  const bool kept = in.refTri == nullptr;  // the reference maker of this build kept refTri and the triangle records
+  if (kept && (!build->refTri || !build->triRecs || build->numMadeRefs != in.numRefs || build->numTris != in.numTris)) {
+    err = "device packer: no references of this build in device memory";
+    return false;
+  }
+  if (kept) {
+    dTri = build->triRecs;
+    dRefTri = build->refTri;
+  }
+  if ((!kept && (!devAllocT(pool, &dTri, in.numTris, err) || !devAllocT(pool, &dRefTri, in.numRefs, err))) || !devAllocT(pool, &dWide, nWide, err) ||
       !devAllocT(pool, &dSlots, nWide, err) || !devAllocT(pool, &dTmp, nWide, err) || !devAllocT(pool, &dBlock, (size_t)nWide + 1, err) ||
       !devAllocT(pool, &dBase, (size_t)nWide + 1, err) || !devAllocT(pool, &dPos, nWide, err))
     return false;
   scan.capTiles = (nWide + kScanTile - 1) / kScanTile + 1;
   if (!devAllocT(pool, &scan.sums, scan.capTiles, err) || !devAllocT(pool, &scan.total, 1, err)) return false;
-  if (!ok(hipMemcpy(dTri, in.triRecs, (size_t)in.numTris * sizeof(BvhTri), hipMemcpyHostToDevice), "upload") ||
-      !ok(hipMemcpy(dRefTri, in.refTri, (size_t)in.numRefs * 4, hipMemcpyHostToDevice), "upload") ||
+  if ((!kept && (!ok(hipMemcpy(dTri, in.triRecs, (size_t)in.numTris * sizeof(BvhTri), hipMemcpyHostToDevice), "upload") ||
+                 !ok(hipMemcpy(dRefTri, in.refTri, (size_t)in.numRefs * 4, hipMemcpyHostToDevice), "upload"))) ||
       !ok(hipMemcpy(dWide, in.wide, (size_t)nWide * sizeof(BvhWideNode), hipMemcpyHostToDevice), "upload") ||
       !ok(hipMemcpy(dSlots, in.slots, (size_t)nWide * sizeof(BvhSlot), hipMemcpyHostToDevice), "upload"))
     return false;
@@ -1214,6 +1642,149 @@ bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err
   build->release();
   out.deviceRecs = dRecs;
   out.deviceNumRecs = numRecs;
+  return true;
+}
+
+// The BvhRefMaker bdpt_set_scene plugs into buildBvh: the references stay in device memory (in the build object) for
+// buildBinaryTreeOnDevice and packOnDevice.
+bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs, std::string& err) {
+  BvhDeviceBuild* const build = static_cast<BvhDeviceBuild*>(user);
+  if (!build) {
+    err = "device reference maker: no build object";
+    return false;
+  }
+  if (hipSetDevice(build->device) != hipSuccess) {
+    err = "device reference maker: no such device";
+    return false;
+  }
+  build->release();
+  numRefs = 0;
+  if (in.numTris == 0) return true;
+  const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bvh]   device %-10s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
+  std::vector<void*> pool;
+  struct Free {
+    std::vector<void*>& p;
+    ~Free() {
+      for (void* q : p) (void)hipFree(q);
+    }
+  } freeAll{pool};
+  auto ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err = std::string("device reference maker: ") + what + ": " + hipGetErrorString(e);
+    return false;
+  };
+  auto upload = [&](auto** dst, const auto* src, size_t count) {
+    if (!devAllocT(pool, dst, count, err)) return false;
+    return count == 0 || ok(hipMemcpy(*dst, src, count * sizeof(**dst), hipMemcpyHostToDevice), "upload");
+  };
+  const uint32_t nT = in.numTris;
+  RefArgs A{};
+  {  // the triangle records stay for the packer
+    void* q = nullptr;
+    if (hipMalloc(&q, (size_t)nT * sizeof(BvhTri)) != hipSuccess) {
+      err = "device reference maker: out of device memory";
+      return false;
+    }
+    build->triRecs = static_cast<BvhTri*>(q);
+    build->numTris = nT;
+    if (!ok(hipMemcpy(build->triRecs, in.triRecs, (size_t)nT * sizeof(BvhTri), hipMemcpyHostToDevice), "upload")) return false;
+  }
+  A.triRecs = build->triRecs;
+  BvhBox* dTriBox = nullptr;
+  uint32_t* dSplits = nullptr;
+  uint8_t* dState = nullptr;
+  if (!upload(&dTriBox, in.triBox, nT) || !upload(&dSplits, in.splits, nT) || !upload(&dState, in.state, nT)) return false;
+  A.triBox = dTriBox;
+  A.splits = dSplits;
+  A.state = dState;
+  A.numTris = nT;
+  for (int a = 0; a < 3; a++) {
+    A.gridLo[a] = in.gridLo[a];
+    A.gridExt[a] = in.gridExt[a];
+  }
+  if (in.clipper) {
+    BvhClipTables tb;
+    if (!in.clipper->tables(tb) || tb.numTriangles != nT) {
+      err = "device reference maker: the clipper's decisions are not available as tables";
+      return false;
+    }
+    uint32_t *dMat = nullptr, *dIdx = nullptr;
+    float* dTex = nullptr;
+    int32_t *dMask = nullptr, *dVerdict = nullptr;
+    DevMask* dMasks = nullptr;
+    if (!upload(&dMat, tb.triMaterial, nT) || !upload(&dIdx, tb.indices, (size_t)nT * 3) || !upload(&dMask, tb.matMask.data(), tb.matMask.size()) ||
+        !upload(&dVerdict, tb.matVerdict.data(), tb.matVerdict.size()))
+      return false;
+    if (tb.texcoords && !upload(&dTex, tb.texcoords, (size_t)tb.numVertices * 3)) return false;
+    std::vector<DevMask> masks;
+    for (const BvhClipTables::Mask& m : tb.masks) {
+      uint32_t* dSat = nullptr;
+      if (!upload(&dSat, m.mayPass, ((size_t)m.w + 1) * ((size_t)m.h + 1))) return false;
+      masks.push_back(DevMask{m.w, m.h, dSat});
+    }
+    if (!upload(&dMasks, masks.data(), masks.size())) return false;
+    A.haveClipper = 1;
+    A.triMaterial = dMat;
+    A.indices = dIdx;
+    A.texcoords = dTex;
+    A.matMask = dMask;
+    A.matVerdict = dVerdict;
+    A.masks = dMasks;
+  }
+  lap("refs upload");
+  hipStream_t st = nullptr;
+  const dim3 blk(256), grid((nT + 255) / 256);
+  uint32_t *capRefs = nullptr, *capStack = nullptr, *slotAt = nullptr, *stackAt = nullptr, *made = nullptr, *refAt = nullptr;
+  Scan scan;
+  scan.capTiles = (nT + kScanTile - 1) / kScanTile + 1;
+  if (!devAllocT(pool, &capRefs, nT, err) || !devAllocT(pool, &capStack, nT, err) || !devAllocT(pool, &slotAt, (size_t)nT + 1, err) ||
+      !devAllocT(pool, &stackAt, (size_t)nT + 1, err) || !devAllocT(pool, &made, nT, err) || !devAllocT(pool, &refAt, (size_t)nT + 1, err) ||
+      !devAllocT(pool, &scan.sums, scan.capTiles, err) || !devAllocT(pool, &scan.total, 1, err))
+    return false;
+  hipLaunchKernelGGL(k_ref_caps, grid, blk, 0, st, A, capRefs, capStack);
+  scan.run(capRefs, nT, slotAt, st);
+  scan.run(capStack, nT, stackAt, st);
+  uint32_t totalSlots = 0, totalStack = 0;
+  if (!ok(hipMemcpy(&totalSlots, slotAt + nT, 4, hipMemcpyDeviceToHost), "caps") || !ok(hipMemcpy(&totalStack, stackAt + nT, 4, hipMemcpyDeviceToHost), "caps")) return false;
+  {  // (the scans are 32-bit: make sure they did not wrap)
+    uint64_t s = 0;
+    for (uint32_t t = 0; t < nT; t++) s += in.state[t] == 2 ? 0u : (uint64_t)in.splits[t] + 1u;
+    if (s != totalSlots || s >= 0x7fffffffull) {
+      err = "bvh does not fit the packed record format (2^31 records)";
+      return false;
+    }
+  }
+  BvhBox* boxes = nullptr;
+  DevPiece* stacks = nullptr;
+  if (!devAllocT(pool, &boxes, totalSlots, err) || !devAllocT(pool, &stacks, totalStack, err)) return false;
+  hipLaunchKernelGGL(k_make_refs, dim3((nT + 63) / 64), dim3(64), 0, st, A, slotAt, stackAt, stacks, boxes, made);
+  scan.run(made, nT, refAt, st);
+  uint32_t total = 0;
+  if (!ok(hipMemcpy(&total, refAt + nT, 4, hipMemcpyDeviceToHost), "count")) return false;
+  lap("refs make");
+  if (total > 0) {
+    void *q0 = nullptr, *q1 = nullptr;
+    if (hipMalloc(&q0, (size_t)total * sizeof(BvhBuildRef)) != hipSuccess || hipMalloc(&q1, (size_t)total * 4) != hipSuccess) {
+      if (q0) (void)hipFree(q0);
+      err = "device reference maker: out of device memory";
+      return false;
+    }
+    build->refs = static_cast<BvhBuildRef*>(q0);
+    build->refTri = static_cast<uint32_t*>(q1);
+    hipLaunchKernelGGL(k_compact_refs, grid, blk, 0, st, nT, slotAt, made, refAt, boxes, build->refs, build->refTri);
+  }
+  if (!ok(hipGetLastError(), "launch") || !ok(hipDeviceSynchronize(), "synchronise")) return false;
+  build->numMadeRefs = total;
+  numRefs = total;
+  lap("refs compact");
   return true;
 }
 

@@ -23,9 +23,10 @@ struct SceneBvh {
 
 // threads / budgets as BvhBuildOptions (negative budgets: build defaults); classify = false keeps the reference's
 // per-material opacity (every triangle of an alpha-mode material is tested, nothing is dropped or clipped).
-// treeBuilder / packer (may be null: host code) build the binary tree and pack the records — bdpt_set_scene passes the
+// refMaker / treeBuilder / packer (may be null: host code) make the references, build the binary tree and pack the records — bdpt_set_scene passes the
 // device implementations; when one fails *error says why (no nodes / no device records then).
 void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, bool classify, SceneBvh& out,
-                   BvhTreeBuilder treeBuilder = nullptr, void* treeBuilderUser = nullptr, std::string* error = nullptr, BvhPacker packer = nullptr);
+                   BvhTreeBuilder treeBuilder = nullptr, void* treeBuilderUser = nullptr, std::string* error = nullptr, BvhPacker packer = nullptr,
+                   BvhRefMaker refMaker = nullptr);
 
 }  // namespace bdpt

@@ -364,32 +364,50 @@ def test_execute_at_lower_depth_than_the_context_is_sized_for(pkg, ob):
     scene.close()
 
 
-def test_device_tree_builder_builds_the_host_builders_tree(pkg):
-    """bdpt_set_scene builds the binary tree of the acceleration structure on the device (csrc/bvh_device.hip) — the
-    reference's BLAS / TLAS builds are GPU work too (RtModel.cpp:181-254, RtScene.cpp:220-308).  It has to be the host
-    builder's tree bit for bit: same hash over nodes, leaf-ordered triangles, reference boxes and packed records, same
-    depth / stack / SAH cost — on the bench scene, the heavy-tailed one, the alpha-masked one, tiny inputs (one wave per
-    slot from the root on), and a degenerate pile of identical centroids plus an 18-decade line (median fallback by the
-    wave sort and by the host sort, depth budget)."""
+def test_device_builder_builds_what_the_host_builder_builds(pkg, monkeypatch):
+    """bdpt_set_scene builds the acceleration structure on the device (csrc/bvh_device.hip) — the reference's BLAS / TLAS
+    builds are GPU work too (RtModel.cpp:181-254, RtScene.cpp:220-308): the references (alpha-clipped, pre-split), the
+    binned-SAH binary tree, and the quantised, packed records; the host keeps the split priorities and the four-wide
+    collapse.  Every stage has to produce the host builder's result bit for bit:
+      * bdpt_bvh_build_hash with the device tree builder plugged in (bdpt_test_tree_builder) = with the host one: nodes,
+        leaf-ordered triangles, reference boxes, packed records, depth / stack / SAH cost;
+      * bdpt_bvh_recs_hash of the whole device pipeline = of the host pipeline: every packed record.
+    Scenes: the bench scene, the heavy-tailed one, the alpha-masked one, tiny inputs (one wave per slot from the root on), a
+    degenerate pile of identical centroids plus an 18-decade line (median fallback by the wave sort and by the host sort,
+    depth budget), and builds with other split budgets (opaque outliers split too; eight splits per alpha card)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("device_tree_check", os.path.join(ROOT, "tools", "device_tree_check.py"))
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
     lib = pkg.load_library()
-    scenes = [("cornell", pkg.Scene.cornell()), ("atrium", pkg.Scene.atrium(1, 262144)), ("uneven", pkg.Scene.atrium_uneven(1, 262144)),
-              ("courtyard", pkg.Scene.courtyard(1, 200000)), ("soup 3", pkg.Scene.soup(2, 3)), ("soup 1500", pkg.Scene.soup(2, 1500)),
-              ("soup 40000", pkg.Scene.soup(2, 40000)), ("skewed", chk.skewed(pkg, 50000))]
+    scenes = [("cornell", pkg.Scene.cornell(), {}), ("atrium", pkg.Scene.atrium(1, 262144), {}), ("uneven", pkg.Scene.atrium_uneven(1, 262144), {}),
+              ("courtyard", pkg.Scene.courtyard(1, 200000), {}), ("soup 3", pkg.Scene.soup(2, 3), {}), ("soup 1500", pkg.Scene.soup(2, 1500), {}),
+              ("soup 40000", pkg.Scene.soup(2, 40000), {}), ("skewed", chk.skewed(pkg, 50000), {}),
+              ("uneven +split", pkg.Scene.atrium_uneven(1, 262144), {"BDPT_SPLIT_BUDGET": "1"}),
+              ("courtyard +8", pkg.Scene.courtyard(3, 100000, 0.7), {"BDPT_SPLIT_BUDGET": "0.5", "BDPT_SPLIT_BUDGET_ALPHA": "8"})]
     try:
-        for name, sc in scenes:
-            got = []
+        for name, sc, env in scenes:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got, recs = [], []
             for dev in (-1, 0):
                 assert lib.bdpt_test_tree_builder(dev) == 0
                 h = C.c_uint64()
                 info = pkg.abi.BvhInfo()
                 assert lib.bdpt_bvh_build_hash(C.byref(sc.desc), 0, C.byref(h), C.byref(info)) == 0, name
                 got.append((h.value, info.numNodes, info.maxDepth, info.maxStack, info.sahCost, info.numReferences))
+            lib.bdpt_test_tree_builder(-1)
+            for dev in (-1, 0):
+                h = C.c_uint64()
+                info = pkg.abi.BvhInfo()
+                assert lib.bdpt_bvh_recs_hash(C.byref(sc.desc), dev, C.byref(h), C.byref(info)) == 0, name
+                recs.append((h.value, info.numNodes, info.maxDepth, info.maxStack, info.sahCost, info.numReferences, info.numDropped, info.reserved))
             assert got[0] == got[1], (name, got)
+            assert recs[0] == recs[1], (name, recs)
+            assert recs[0][1] == got[0][1] and recs[0][5] == got[0][5], name
+            for k in env:
+                monkeypatch.delenv(k)
     finally:
         lib.bdpt_test_tree_builder(-1)
-        for _, sc in scenes:
+        for _, sc, _ in scenes:
             sc.close()

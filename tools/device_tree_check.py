@@ -1,5 +1,7 @@
-"""The device tree builder (csrc/bvh_device.hip) against the host one: bdpt_bvh_build_hash under both settings of
-bdpt_test_tree_builder, scene by scene, with build times.  `python tools/device_tree_check.py [big]`."""
+"""The device builder (csrc/bvh_device.hip) against the host one, scene by scene, with build times: bdpt_bvh_build_hash
+under both settings of bdpt_test_tree_builder (the binary-tree stage alone), and bdpt_bvh_recs_hash of the whole device
+pipeline (references, tree, quantise + pack) against the host pipeline's packed records.
+`python tools/device_tree_check.py [big]`; DEVTREE_ONLY=<scene name> runs one scene on the device only (for profiles)."""
 import ctypes as C
 import os
 import sys
@@ -68,7 +70,10 @@ def main():
     scenes = [("cornell", lambda: pkg.Scene.cornell()), ("atrium 262144", lambda: pkg.Scene.atrium(1, 262144)),
               ("atrium uneven", lambda: pkg.Scene.atrium_uneven(1, 262144)), ("courtyard", lambda: pkg.Scene.courtyard(1, 200000)),
               ("soup 3", lambda: pkg.Scene.soup(2, 3)), ("soup 40000", lambda: pkg.Scene.soup(2, 40000)),
-              ("skewed 50000", lambda: skewed(pkg, 50000))]
+              ("skewed 50000", lambda: skewed(pkg, 50000)),
+              # opaque outliers split too (BDPT_SPLIT_BUDGET, read by every build), more splits per alpha card
+              ("uneven +split", lambda: pkg.Scene.atrium_uneven(1, 262144), {"BDPT_SPLIT_BUDGET": "1"}),
+              ("courtyard +8", lambda: pkg.Scene.courtyard(3, 100000, 0.7), {"BDPT_SPLIT_BUDGET": "0.5", "BDPT_SPLIT_BUDGET_ALPHA": "8"})]
     if big:
         scenes += [("atrium 2.8M", lambda: pkg.Scene.atrium(1, 2800000)), ("atrium 10M", lambda: pkg.Scene.atrium(1, 10000000)),
                    ("courtyard 10M", lambda: pkg.Scene.courtyard(1, 10000000))]
@@ -76,7 +81,10 @@ def main():
     if only:
         scenes = [x for x in scenes if x[0] == only]
     bad = 0
-    for name, make in scenes:
+    for entry in scenes:
+        name, make = entry[0], entry[1]
+        env = entry[2] if len(entry) > 2 else {}
+        os.environ.update(env)
         sc = make()
         if sc is None:
             print(name, "skipped")
@@ -102,6 +110,8 @@ def main():
         bad += 0 if same else 1
         print(f"{name:16s} host {res[0][1]:#018x} {res[0][2]:9d} nodes {res[0][6]:7.3f} s | device {res[1][1]:#018x} {res[1][2]:9d} nodes {res[1][6]:7.3f} s | records {rh[0][1]:#018x} {rh[0][7]:6.3f} s / {rh[1][1]:#018x} {rh[1][7]:6.3f} s | {'SAME' if same else 'DIFFERENT'}", flush=True)
         sc.close()
+        for k in env:
+            del os.environ[k]
     return 1 if bad else 0
 
 

@@ -1,24 +1,27 @@
-// bvh_device.hip — the binary-tree stage of the acceleration-structure build ON THE DEVICE.
+// bvh_device.hip — the acceleration-structure build ON THE DEVICE.
 //
 // Replaces what the reference leaves to the DXR driver on the GPU as well — BLAS / TLAS builds issued by
-// Falcor/Framework/Source/Raytracing/RtModel.cpp:181-254 and RtScene.cpp:220-308 — for the part of this build that is
-// data-parallel over the references: the binned-SAH binary tree.  (The references themselves — alpha classification,
-// pre-splitting, clipping — and the four-wide collapse / quantisation / packing stay on the host: bvh_build.cpp.)
+// Falcor/Framework/Source/Raytracing/RtModel.cpp:181-254 and RtScene.cpp:220-308.  Three stages of buildBvh
+// (bvh_build.cpp) are plugged in from here by bdpt_set_scene, each producing the host code's result bit for bit (the host
+// code stays as what the CPU tests run and as the definition; tests/test_gpu_configs.py compares the two):
+//   makeReferencesOnDevice   the references: whole piece, clipped by the alpha clipper, split, every piece clipped again
+//   buildBinaryTreeOnDevice  the binned-SAH binary tree over them
+//   packOnDevice             child boxes quantised, nodes + leaf triangles packed into the record array the kernels traverse
+// (on the host between them: split priorities before, the four-wide collapse after the tree).
 //
-// Level-synchronous: every level of the tree is a handful of flat launches over all n references —
-//   bounds   node box + centroid box per active node            (ordered-uint atomics, wave-aggregated)
-//   prepare  leaf / forced-median / split candidate; bin grid   (one thread per node)
-//   bin      3 x 16 bins per candidate: box + count             (atomics)
-//   decide   the SAH sweep of bvh_build.cpp splitNode           (one thread per node, the same float operations in the same order)
-//   flags -> exclusive scan -> stable partition scatter         (lefts in their order, then rights in theirs)
-//   children two nodes per split node, in slot order
+// The tree is level-synchronous: every level is a handful of launches —
+//   bounds   node box + centroid box per active node ("slot")   (ordered-uint atomics; a block first reduces the
+//   bin      3 x 16 bins per split candidate: box + count        references of its dominant slot in registers / LDS)
+//   prepare  leaf / forced-median / split candidate; bin grid    (one thread per slot)
+//   decide   the SAH sweep of bvh_build.cpp splitNode            (one thread per slot, the same float operations in the same order)
+//   small    all of the above for a slot of <= kSmall references (one wave per slot, bins in LDS, no atomics on memory)
+//   flags -> exclusive scan -> stable partition scatter          (lefts in their order, then rights in theirs)
+//   children two nodes per split slot, in slot order
 // — and produces, bit for bit, the permutation of the references and the tree the host code produces (one partition
-// rule there too: bvh_build.cpp), so everything downstream, the packed records and the statistics of every query are
-// the same; tests/test_gpu_configs.py compares the two builders' hashes.  Median fallback (no useful SAH split, or the
-// depth budget): the node's range is sorted by (centroid, reference id) — by one wave for up to kMedianWave
-// references, on the host beyond that (it happens on degenerate inputs only).
-// Float min / max through atomics on an order-preserving uint encoding: exact, order-independent.  The host turns -0
-// into +0 when it makes the references, so no box component depends on the order in which equal zeros met.
+// rule there too).  Median fallback (no useful SAH split, or the depth budget): the slot's range is sorted by
+// (centroid, reference id) — by one wave for up to kMedianWave references, on the host beyond that (degenerate inputs only).
+// Float min / max through atomics on an order-preserving uint encoding: exact, order-independent.  -0 is turned into +0
+// when the references are made, so no box component depends on the order in which equal zeros met.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -137,10 +137,14 @@ def timed_frames(R, pkg, K):
     return dt, rays
 
 
-def other_config(pkg, torch, name, scene, W, H, D, mat, frames=3):
-    """One more BASELINE shape on this GPU, one frame in flight: ms per frame, Mrays/s, visits per ray, stage times."""
+def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
+    """One more BASELINE shape on this GPU, one frame in flight: ms per frame, Mrays/s, visits per ray, stage times.
+    The pipeline is left open (appended to `keep`): the driver wipes freed VRAM before it hands it out again, and the
+    next shape's set-up would be charged the wait for this one's tens of GB (measured: 0.9-1.2 s per shape)."""
+    free0 = torch.cuda.mem_get_info()[0]
     t0 = time.time()
     pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, accum_limit=1 << 30)
+    keep.append(pipe)
     try:
         torch.cuda.synchronize()
         setup = time.time() - t0
@@ -176,9 +180,11 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, frames=3):
                "stage_ms": {k: round(v, 2) for k, v in agg.items() if v >= 0.05},
                "bvh": {"nodes": info.numNodes, "references": info.numReferences, "triangles": info.numTriangles,
                        "alpha_mode_triangles": info.numAlphaMode, "always_pass": info.numAlwaysPass, "dropped": info.numDropped},
-               "setup_s": round(setup, 2), "setup_breakdown_s": {k: round(v, 2) for k, v in pipe.setup_times.items()}, "device_memory_gb": round((total - free) / 2 ** 30, 1)}
-    finally:
+               "setup_s": round(setup, 2), "setup_breakdown_s": {k: round(v, 2) for k, v in pipe.setup_times.items()}, "device_memory_gb": round((free0 - free) / 2 ** 30, 1)}
+    except Exception:
+        keep.remove(pipe)
         pipe.close()
+        raise
     return out
 
 
@@ -564,7 +570,7 @@ def main():
                 out["cpu_baseline"] = base
                 out.update(parity)
             guarded("cpu_baseline", cpu)
-    R.close()
+    keep = []  # the other shapes' pipelines, closed together with the bench's own at the end (see other_config)
     if rank == 0 and world == 1 and dist is None and args.other_configs and scene_name == "atrium" and (W, H, D) == (1920, 1080, 8):
         others = []
 
@@ -572,7 +578,7 @@ def main():
             def run():
                 sc = make()
                 try:
-                    others.append(other_config(pkg, torch, name, sc, w, h, d, m))
+                    others.append(other_config(pkg, torch, name, sc, w, h, d, m, keep))
                 finally:
                     sc.close()
             guarded(name.split(":")[0], run)
@@ -596,6 +602,9 @@ def main():
         other("BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "
               "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", lambda: pkg.Scene.courtyard(2, 10000000, 0.5), 3840, 2160, 16, 0)
         out["config"]["other_configs"] = others
+    for p in keep:
+        p.close()
+    R.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -271,3 +271,28 @@ def test_an_exception_on_a_builder_worker_thread_comes_back_as_an_error_code(pkg
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]  # (an uncaught exception on a std::thread would have aborted: rc -6)
     assert "codes -4 -4 0 80000" in r.stdout, r.stdout
+
+
+def test_recs_hash_hook_on_the_host_pipeline_and_device_hooks_without_a_gpu(pkg):
+    """bdpt_bvh_recs_hash (device < 0: everything by the host code) is what the GPU suite compares the device build with:
+    it has to be deterministic, to see a change of the scene, and to report the record count; without a GPU the
+    device-side settings of the test hooks fail with BDPT_E_HIP instead of falling back to the host code."""
+    import torch
+    lib = pkg.load_library()
+    a, b = pkg.Scene.courtyard(1, 20000), pkg.Scene.courtyard(2, 20000)
+    got = []
+    for sc in (a, a, b):
+        h = C.c_uint64()
+        info = pkg.abi.BvhInfo()
+        assert lib.bdpt_bvh_recs_hash(C.byref(sc.desc), -1, C.byref(h), C.byref(info)) == 0
+        got.append((h.value, info.numNodes, info.numReferences, info.reserved))
+    assert got[0] == got[1] and got[0][0] != got[2][0]
+    # records = one per node + one per reference + the pad records
+    assert got[0][3] == got[0][1] + got[0][2] + 4
+    if not torch.cuda.is_available():
+        h = C.c_uint64()
+        assert lib.bdpt_bvh_recs_hash(C.byref(a.desc), 0, C.byref(h), None) == -3  # BDPT_E_HIP
+        assert lib.bdpt_test_tree_builder(0) == -3
+    assert lib.bdpt_test_tree_builder(-1) == 0
+    a.close()
+    b.close()

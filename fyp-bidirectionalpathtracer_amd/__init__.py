@@ -314,8 +314,9 @@ class FramePipeline:
         self.ctx = Context(device)
         t1 = time.time()
         # The frame's buffers first, the scene second: building the acceleration structure of a large scene takes and
-        # frees tens of GB of device scratch, and the driver wipes freed VRAM before it hands it out again — a 94 GB
-        # bdpt_resize issued right after such a bdpt_set_scene was measured waiting 1-1.7 s for that (0.01 s otherwise).
+        # frees some 15 GB of device scratch, and the driver clears VRAM that has been used before when it hands it out
+        # again (~35 GB/s) — a 94 GB bdpt_resize issued right after such a bdpt_set_scene was measured 1-1.7 s slower
+        # (0.01-0.03 s on untouched memory).
         # tile = (y0, y1): a contiguous band; stripes = (stripe_rows, num_owners, owner): interleaved stripes
         self.stripes = stripes
         if stripes is None:

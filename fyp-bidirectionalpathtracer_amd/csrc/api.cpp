@@ -483,6 +483,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     if ((rc = devUpload(c, c->sceneAllocs, &dAlpha, alphaRecs.data(), alphaRecs.size()))) return rc;
     c->S.alphaRecs = reinterpret_cast<const float4*>(dAlpha);
   }
+  lap("indices, textures, alpha");
   SceneConst sc;
   std::memset(&sc, 0, sizeof(sc));
   std::memcpy(sc.lights, d->lights, sizeof(bdpt_light) * d->numLights);

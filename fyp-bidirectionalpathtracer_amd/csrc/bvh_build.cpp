@@ -1102,13 +1102,22 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   out.numNodes = (uint32_t)wide.size();
   const float rootArea = tmp[0].box.area();
   auto sahCost = [&] {
-    double cost = 0.0;  // one thread, node order: the sum's rounding does not depend on the thread count
+    // blocks of kCostBlock nodes summed in node order side by side, the block sums added in block order: the rounding
+    // depends on neither the thread count nor on who builds the tree
+    constexpr size_t kCostBlock = (size_t)1 << 16;
+    std::vector<double> part((wide.size() + kCostBlock - 1) / kCostBlock, 0.0);
     if (rootArea > 0)
-      for (size_t wi = 0; wi < wide.size(); wi++)
-        for (int k = 0; k < wide[wi].nk; k++) {
-          const TmpNode& c = tmp[wide[wi].kids[k]];
-          cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
-        }
+      parallelChunks(wide.size(), threads, kCostBlock, [&](size_t ci, size_t w0, size_t w1) {
+        double cost = 0.0;
+        for (size_t wi = w0; wi < w1; wi++)
+          for (int k = 0; k < wide[wi].nk; k++) {
+            const TmpNode& c = tmp[wide[wi].kids[k]];
+            cost += (c.left < 0 ? kCostTri * c.count : kCostTraverse) * c.box.area() / rootArea;
+          }
+        part[ci] = cost;
+      });
+    double cost = 0.0;
+    for (double v : part) cost += v;
     return (float)cost + kCostTraverse;
   };
   if (packer) {

@@ -137,10 +137,20 @@ def timed_frames(R, pkg, K):
     return dt, rays
 
 
+_CLOSE_LAST = []  # renderers of the side measurements: nothing is freed on the device before the last shape has been set up
+
+
 def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
     """One more BASELINE shape on this GPU, one frame in flight: ms per frame, Mrays/s, visits per ray, stage times.
     The pipeline is left open (appended to `keep`): the driver wipes freed VRAM before it hands it out again, and the
     next shape's set-up would be charged the wait for this one's tens of GB (measured: 0.9-1.2 s per shape)."""
+    # (unless the device is short of memory: path state grows with pixels x depth^2, the build takes scratch on top)
+    need = W * H * (650 * D + 13 * D * D) + scene.desc.numTriangles * 3000 + (4 << 30)  # measured: 8.5 / 62 / 93 GB of path state at depth 8 / 12 / 16
+    if torch.cuda.mem_get_info()[0] < need:
+        for q in keep + _CLOSE_LAST:
+            q.close()
+        del keep[:], _CLOSE_LAST[:]
+        torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     t0 = time.time()
     pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, accum_limit=1 << 30)
@@ -567,7 +577,7 @@ def main():
                         "frames_in_flight": 1, "value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 3),
                         "note": "same frames, one context, no host synchronisation either; informational (the kernels' solo durations of the roofline block add up to this loop)"}
                 finally:
-                    R1.close()
+                    _CLOSE_LAST.append(R1)  # (closed at the end: see other_config)
             guarded("single_frame_in_flight", single)
         if not args.no_cpu_baseline:  # rank 0 at N=1 only
             def cpu():
@@ -607,7 +617,7 @@ def main():
         other("BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "
               "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", lambda: pkg.Scene.courtyard(2, 10000000, 0.5), 3840, 2160, 16, 0)
         out["config"]["other_configs"] = others
-    for p in keep:
+    for p in keep + _CLOSE_LAST:
         p.close()
     R.close()
     if rank == 0:
@@ -698,7 +708,7 @@ def cpu_baseline(pkg, scene, pipe, W, H, D, mat, budget_s, frame):
     tp.render_frame()
     torch.cuda.synchronize(tp.dev)
     gpu = tp.output[ya:yb].cpu().numpy()
-    tp.close()
+    _CLOSE_LAST.append(tp)  # (closed at the end: see other_config)
     d = gpu[..., :3].astype(np.float64) - img[..., :3].astype(np.float64)
     parity = {"rmse": float(np.sqrt(np.mean(d * d))),
               "bit_exact_frac": float((gpu.view(np.uint32) == img.view(np.uint32)).all(axis=-1).mean()),

@@ -347,7 +347,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     if (sb.bvh.deviceRecs) c->sceneAllocs.push_back(sb.bvh.deviceRecs);  // (the context's from here on)
     if (!treeError.empty()) {
       fail(c, "scene: " + treeError);
-      return treeError.find("2^31") != std::string::npos ? BDPT_E_LIMIT : BDPT_E_HIP;
+      return treeError.find("2^31") != std::string::npos ? BDPT_E_LIMIT : (treeError.find("out of device memory") != std::string::npos ? BDPT_E_NOMEM : BDPT_E_HIP);
     }
   } catch (const std::bad_alloc&) {
     fail(c, "scene: out of host memory while building the acceleration structure");

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,10 @@ struct BvhDeviceArena {
   std::vector<Chunk> chunks;
   static constexpr size_t kMinChunk = (size_t)1 << 30;
   void* alloc(size_t bytes) {
+    // test hook: BDPT_TEST_FAIL_DEVICE_ALLOC=<n> makes the n-th request of the process fail (tests/test_gpu_configs.py)
+    static const long failAt = std::getenv("BDPT_TEST_FAIL_DEVICE_ALLOC") ? std::atol(std::getenv("BDPT_TEST_FAIL_DEVICE_ALLOC")) : -1;
+    static std::atomic<long> requests{0};
+    if (failAt >= 0 && ++requests == failAt) return nullptr;
     bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
     for (Chunk& c : chunks)
       if (c.used + bytes <= c.size) {

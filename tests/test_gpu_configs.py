@@ -411,3 +411,32 @@ def test_device_builder_builds_what_the_host_builder_builds(pkg, monkeypatch):
         lib.bdpt_test_tree_builder(-1)
         for _, sc, _ in scenes:
             sc.close()
+
+
+def test_a_failed_allocation_in_the_device_build_comes_back_as_an_error_code():
+    """Every stage of the device build (references, tree, pack) takes its scratch from the build's arena; a request that
+    fails must end bdpt_set_scene with BDPT_E_NOMEM and a message — no fault, no partial scene — and the next call in
+    the same context must work.  (The hook counts requests per process, so every case runs in a child process.)"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+import torch
+import __graft_entry__ as ge
+pkg = ge.load_package(); lib = pkg.load_library()
+sc = pkg.Scene.courtyard(1, 30000)
+ctx = pkg.Context(0)
+rc = lib.bdpt_set_scene(ctx._h, C.byref(sc.desc))
+msg = lib.bdpt_last_error(ctx._h).decode()
+rc2 = lib.bdpt_set_scene(ctx._h, C.byref(sc.desc))
+info = ctx.bvh_info()
+print("RESULT", rc, rc2, info.numNodes > 0, "|", msg)
+''' % ROOT
+    for n in (1, 9, 30, 60, 75):  # requests in the reference stage, the tree stage (level arrays) and the pack stage
+        env = dict(os.environ, BDPT_TEST_FAIL_DEVICE_ALLOC=str(n))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, (n, out.stdout[-500:], out.stderr[-500:])
+        _, rc, rc2, ok, _, msg = line[0].split(" ", 5)
+        assert (int(rc), int(rc2), ok) == (-4, 0, "True") and "out of device memory" in msg, (n, line[0])  # BDPT_E_NOMEM

@@ -440,3 +440,116 @@ print("RESULT", rc, rc2, info.numNodes > 0, "|", msg)
         assert line, (n, out.stdout[-500:], out.stderr[-500:])
         _, rc, rc2, ok, _, msg = line[0].split(" ", 5)
         assert (int(rc), int(rc2), ok) == (-4, 0, "True") and "out of device memory" in msg, (n, line[0])  # BDPT_E_NOMEM
+
+
+def _many_cards_scene(pkg, n_cards, tex, uv_scale, rng, threshold=0.5, jitter=0.3):
+    """n_cards alpha-masked unit cards (two triangles each, one shared texture) scattered and rotated in a box, plus an opaque
+    floor: a small stand-in for foliage whose texture and uv tiling the caller chooses."""
+    a = pkg.abi
+    quad = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    pos, uv, idx, tri_mat = [], [], [], []
+    for k in range(n_cards):
+        ang = rng.uniform(0, 2 * np.pi, 3)
+        cx, sx, cy, sy = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1])
+        R = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float32) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], np.float32)
+        p = (quad * rng.uniform(0.2, 1.5)) @ R.T + rng.uniform(-3, 3, 3).astype(np.float32)
+        base = len(pos)
+        pos.extend(p.astype(np.float32))
+        off = rng.uniform(-jitter, jitter, 2)
+        uv.extend(np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32) * uv_scale + np.array([off[0], off[1], 0], np.float32))
+        idx.extend([base, base + 1, base + 2, base, base + 2, base + 3])
+        tri_mat.extend([0, 0])
+    base = len(pos)
+    pos.extend(np.array([[-6, -6, -4], [6, -6, -4], [6, 6, -4], [-6, 6, -4]], np.float32))
+    uv.extend(np.zeros((4, 3), np.float32))
+    idx.extend([base, base + 1, base + 2, base, base + 2, base + 3])
+    tri_mat.extend([1, 1])
+    pos, uv = np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(uv, np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(pos), 1))
+    idx, tri_mat = np.asarray(idx, np.uint32), np.asarray(tri_mat, np.uint32)
+    mats = (a.Material * 2)()
+    for m, alpha_mode, tex_id in ((mats[0], 1, 0), (mats[1], 0, -1)):
+        for k in range(4):
+            m.baseColor[k] = 1.0
+        m.alphaThreshold = threshold
+        m.IoR = 1.5
+        m.flags = (0 | ((2 if tex_id >= 0 else 1) << 3) | (1 << 6) | (alpha_mode << 17) | (1 << 19))
+        m.texBaseColor, m.texSpecular, m.texEmissive, m.texNormal = tex_id, -1, -1, -1
+    texs = (a.Texture * 1)()
+    texs[0].rgba8 = tex.ctypes.data_as(C.POINTER(C.c_uint8))
+    texs[0].width, texs[0].height, texs[0].srgb = tex.shape[1], tex.shape[0], 1
+    lights = (a.Light * 1)()
+    lights[0].posW[2] = 3.0
+    lights[0].intensity[0] = lights[0].intensity[1] = lights[0].intensity[2] = 1.0
+    d = a.SceneDesc()
+    d.numVertices, d.numTriangles, d.numMaterials, d.numTextures, d.numLights = len(pos), len(tri_mat), 2, 1, 1
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    d.positions, d.normals, d.texcoords = fp(pos), fp(nrm), fp(uv)
+    d.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.triMaterial = tri_mat.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.materials, d.textures, d.lights = mats, texs, lights
+    return d, [tex, pos, nrm, uv, idx, tri_mat, mats, texs, lights]
+
+
+def test_device_builder_on_adversarial_inputs(pkg, monkeypatch):
+    """The device build against the host build (packed records + summary, bdpt_bvh_recs_hash) where the code paths fork:
+    reference counts on either side of the one-wave-per-node bound (1024) and of the wave sort's bound (2048), every
+    triangle identical (median fallback through the host sort), geometry on a line and in a plane (one or two centroid
+    axes without extent), coordinates over 24 decades, and alpha-masked cards — random blobs, a checkerboard, one opaque
+    texel, tiled and shifted texture coordinates, up to 64 splits per card."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("device_tree_check", os.path.join(ROOT, "tools", "device_tree_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    lib = pkg.load_library()
+    rng = np.random.default_rng(11)
+
+    def soup(n, make_centres, size=0.01):
+        c = make_centres(n).astype(np.float32)
+        d = rng.normal(0, size, (n, 3, 3)).astype(np.float32)
+        pos = (c[:, None, :] + d).reshape(-1, 3)
+        return chk.RawScene(pkg, pos, np.arange(n * 3, dtype=np.uint32).reshape(n, 3))
+
+    cases = []
+    for n in (1, 2, 3, 1023, 1024, 1025, 2047, 2048, 2049, 4097):
+        cases.append(("uniform %d" % n, soup(n, lambda m: rng.uniform(-1, 1, (m, 3))), {}))
+    same = np.tile(np.array([[0.1, 0.2, 0.3], [0.4, 0.2, 0.3], [0.1, 0.6, 0.3]], np.float32), (5000, 1))
+    cases.append(("identical 5000", chk.RawScene(pkg, same, np.arange(15000, dtype=np.uint32).reshape(5000, 3)), {}))
+    cases.append(("line 3000", soup(3000, lambda m: np.stack([rng.uniform(-5, 5, m), np.zeros(m), np.zeros(m)], 1), size=0.0), {}))
+    cases.append(("plane 3000", soup(3000, lambda m: np.stack([rng.uniform(-5, 5, m), rng.uniform(-5, 5, m), np.full(m, 2.0)], 1), size=0.0), {}))
+    cases.append(("24 decades", soup(6000, lambda m: np.exp(rng.uniform(-27, 27, (m, 3))) * rng.choice([-1.0, 1.0], (m, 3)), size=1e-3), {}))
+    blobs = np.zeros((64, 64, 4), np.uint8)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for _ in range(12):
+        cx, cy, r = rng.uniform(0, 64, 3)
+        blobs[..., 3] = np.maximum(blobs[..., 3], np.where((xx - cx) ** 2 + (yy - cy) ** 2 < (4 + r / 8) ** 2, 255, 0))
+    checker = np.zeros((16, 16, 4), np.uint8)
+    checker[..., 3] = np.where((xx[:16, :16] + yy[:16, :16]) % 2 == 0, 255, 0)
+    dot = np.zeros((32, 32, 4), np.uint8)
+    dot[17, 5, 3] = 255
+    keepalive = []
+    for name, tex, uv_scale, env in (("cards blobs", blobs, 1.0, {}), ("cards blobs x3.7", blobs, 3.7, {"BDPT_SPLIT_BUDGET_ALPHA": "16"}),
+                                     ("cards checker", checker, 1.0, {"BDPT_SPLIT_BUDGET_ALPHA": "64"}), ("cards dot", dot, 1.0, {}),
+                                     ("cards dot x0.5", dot, 0.5, {"BDPT_SPLIT_BUDGET": "2", "BDPT_SPLIT_BUDGET_ALPHA": "8"})):
+        d, keep = _many_cards_scene(pkg, 400, tex, uv_scale, rng)
+        keepalive.append(keep)
+
+        class Holder:
+            pass
+        hsc = Holder()
+        hsc.desc = d
+        hsc.close = lambda: None
+        cases.append((name, hsc, env))
+    for name, sc, env in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = []
+        for dev in (-1, 0):
+            h = C.c_uint64()
+            info = pkg.abi.BvhInfo()
+            assert lib.bdpt_bvh_recs_hash(C.byref(sc.desc), dev, C.byref(h), C.byref(info)) == 0, name
+            got.append((h.value, info.numNodes, info.maxDepth, info.maxStack, info.sahCost, info.numReferences, info.numDropped, info.reserved))
+        assert got[0] == got[1], (name, got)
+        for k in env:
+            monkeypatch.delenv(k)
+        sc.close()

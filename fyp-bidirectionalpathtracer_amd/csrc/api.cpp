@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <functional>
 #include <atomic>
 #include <chrono>
@@ -333,6 +334,68 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     tLap = t;
   };
   lap("validate");
+  // Beside the build, on a thread of its own: the per-primitive shading records (3 x (position, normal, uv) + material id,
+  // 112 B) and the uploads that depend on nothing the build produces — while the build's device stages run the host is
+  // idle, and while its host stages run the copy engine is.
+  struct SideUploads {
+    std::vector<void*> pool;
+    const float* shade = nullptr;
+    const uint32_t* indices = nullptr;
+    const float* bitangents = nullptr;
+    hipError_t err = hipSuccess;
+  };
+  // (BDPT_SET_SCENE_SERIAL: measurement knob — the same work at the point where its results are needed, on this thread)
+  std::future<SideUploads> side = std::async(std::getenv("BDPT_SET_SCENE_SERIAL") ? std::launch::deferred : std::launch::async, [c, d]() {
+    SideUploads u;
+    BigVec<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4);  // (sized, not zeroed: the loop writes every float)
+    hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
+      for (size_t t = t0; t < t1; t++) {
+        float* r = &shade[t * kShadeRecF4 * 4];
+        for (int k = 0; k < 3; k++) {
+          const uint32_t vi = d->indices[t * 3 + (size_t)k];
+          const float* p = d->positions + (size_t)vi * 3;
+          const float* nn = d->normals + (size_t)vi * 3;
+          float* q = r + k * 8;
+          q[0] = p[0];
+          q[1] = p[1];
+          q[2] = p[2];
+          q[3] = nn[0];
+          q[4] = nn[1];
+          q[5] = nn[2];
+          q[6] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
+          q[7] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
+        }
+        uint32_t mid = d->triMaterial[t];
+        std::memcpy(r + 24, &mid, 4);
+        for (int k = 25; k < kShadeRecF4 * 4; k++) r[k] = 0.0f;
+      }
+    });
+    auto up = [&](auto** dst, const auto* host, size_t count) {
+      if (u.err != hipSuccess) return;
+      void* q = nullptr;
+      u.err = hipMalloc(&q, std::max<size_t>(count * sizeof(**dst), 16));
+      if (u.err != hipSuccess) return;
+      u.pool.push_back(q);
+      if (count) u.err = hipMemcpy(q, host, count * sizeof(**dst), hipMemcpyHostToDevice);
+      *dst = static_cast<std::remove_reference_t<decltype(*dst)>>(q);
+    };
+    u.err = hipSetDevice(c->device);
+    up(&u.shade, shade.data(), shade.size());
+    up(&u.indices, d->indices, (size_t)d->numTriangles * 3);
+    if (d->bitangents) up(&u.bitangents, d->bitangents, (size_t)d->numVertices * 3);
+    return u;
+  });
+  struct SideJoin {  // whatever way this function is left, the thread is joined and what it allocated has an owner
+    std::future<SideUploads>& f;
+    ~SideJoin() {
+      if (!f.valid()) return;
+      try {
+        SideUploads u = f.get();
+        for (void* q : u.pool) (void)hipFree(q);
+      } catch (...) {
+      }
+    }
+  } sideJoin{side};
   // traversal flags, alpha classification, spatial pre-splitting and the tree itself: scene_bvh.cpp
   SceneBvh sb;
   try {
@@ -382,44 +445,24 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   c->bvhInfo.numAlphaMode = sb.numAlphaMode;
   c->bvhInfo.numAlwaysPass = sb.numAlwaysPass;
 
-  // per-primitive shading records: 3 x (position, normal, uv) + material id, 112 B
-  BigVec<float> shade((size_t)d->numTriangles * kShadeRecF4 * 4);  // (sized, not zeroed: the loop writes every float)
-  hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
-    for (size_t t = t0; t < t1; t++) {
-      float* r = &shade[t * kShadeRecF4 * 4];
-      for (int k = 0; k < 3; k++) {
-        const uint32_t vi = d->indices[t * 3 + (size_t)k];
-        const float* p = d->positions + (size_t)vi * 3;
-        const float* nn = d->normals + (size_t)vi * 3;
-        float* q = r + k * 8;
-        q[0] = p[0];
-        q[1] = p[1];
-        q[2] = p[2];
-        q[3] = nn[0];
-        q[4] = nn[1];
-        q[5] = nn[2];
-        q[6] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
-        q[7] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
-      }
-      uint32_t mid = d->triMaterial[t];
-      std::memcpy(r + 24, &mid, 4);
-      for (int k = 25; k < kShadeRecF4 * 4; k++) r[k] = 0.0f;
-    }
-  });
-
-  lap("shading records");
   int rc;
-  const float* dShade;
-  if ((rc = devUpload(c, c->sceneAllocs, &dShade, shade.data(), shade.size()))) return rc;
-  lap("upload shade");
-  c->S.recs = reinterpret_cast<const uint4*>(bvh.deviceRecs);
-  c->S.shade = reinterpret_cast<const float4*>(dShade);
-  c->S.numRecs = (uint32_t)bvh.deviceNumRecs;
-  if ((rc = devUpload(c, c->sceneAllocs, &c->S.indices, d->indices, (size_t)d->numTriangles * 3))) return rc;
-  if (d->bitangents) {
-    if ((rc = devUpload(c, c->sceneAllocs, &c->S.bitangents, d->bitangents, (size_t)d->numVertices * 3))) return rc;
-    c->S.hasBitangents = 1;
+  {
+    SideUploads u = side.get();  // (a std::bad_alloc of that thread is rethrown here: bdpt_set_scene's catch)
+    c->sceneAllocs.insert(c->sceneAllocs.end(), u.pool.begin(), u.pool.end());
+    if (u.err != hipSuccess) {
+      fail(c, std::string("scene upload: ") + hipGetErrorString(u.err));
+      return u.err == hipErrorOutOfMemory ? BDPT_E_NOMEM : BDPT_E_HIP;
+    }
+    c->S.shade = reinterpret_cast<const float4*>(u.shade);
+    c->S.indices = u.indices;
+    if (d->bitangents) {
+      c->S.bitangents = u.bitangents;
+      c->S.hasBitangents = 1;
+    }
   }
+  lap("shading records + uploads (joined)");
+  c->S.recs = reinterpret_cast<const uint4*>(bvh.deviceRecs);
+  c->S.numRecs = (uint32_t)bvh.deviceNumRecs;
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.materials, d->materials, d->numMaterials))) return rc;
   std::vector<TexDev> texs(d->numTextures);
   for (uint32_t i = 0; i < d->numTextures; i++) {

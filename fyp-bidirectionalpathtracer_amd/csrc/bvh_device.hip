@@ -1295,6 +1295,15 @@ __global__ __launch_bounds__(64) void k_make_refs(RefArgs A, const uint32_t* __r
   }
   made[t] = m;
 }
+// no triangle is split or shrunk (a scene without alpha-mode materials, built without opaque splits): one reference per
+// triangle that was not dropped, its box the triangle's — without k_make_refs and the scratch its private arrays need
+__global__ void k_plain_refs(RefArgs A, const uint32_t* __restrict__ slotAt, BvhBox* __restrict__ boxes, uint32_t* __restrict__ made) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.numTris) return;
+  const bool keep = A.state[t] != 2;
+  if (keep) boxes[slotAt[t]] = A.triBox[t];
+  made[t] = keep ? 1u : 0u;
+}
 // the references in triangle order: box (-0 -> +0), centre, id = index; and the triangle of each
 __global__ void k_compact_refs(uint32_t numTris, const uint32_t* __restrict__ slotAt, const uint32_t* __restrict__ made, const uint32_t* __restrict__ refAt,
                                const BvhBox* __restrict__ boxes, BvhBuildRef* __restrict__ refs, uint32_t* __restrict__ refTri) {
@@ -1797,9 +1806,13 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
   scan.run(capStack, nT, stackAt, st);
   uint32_t totalSlots = 0, totalStack = 0;
   if (!ok(hipMemcpy(&totalSlots, slotAt + nT, 4, hipMemcpyDeviceToHost), "caps") || !ok(hipMemcpy(&totalStack, stackAt + nT, 4, hipMemcpyDeviceToHost), "caps")) return false;
+  bool plain = true;  // nothing to split, nothing shrunk
   {  // (the scans are 32-bit: make sure they did not wrap)
     uint64_t s = 0;
-    for (uint32_t t = 0; t < nT; t++) s += in.state[t] == 2 ? 0u : (uint64_t)in.splits[t] + 1u;
+    for (uint32_t t = 0; t < nT; t++) {
+      s += in.state[t] == 2 ? 0u : (uint64_t)in.splits[t] + 1u;
+      plain = plain && (in.state[t] == 2 || (in.splits[t] == 0 && in.state[t] == 0));
+    }
     if (s != totalSlots || s >= 0x7fffffffull) {
       err = "bvh does not fit the packed record format (2^31 records)";
       return false;
@@ -1808,7 +1821,10 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
   BvhBox* boxes = nullptr;
   DevPiece* stacks = nullptr;
   if (!devAllocT(pool, &boxes, totalSlots, err) || !devAllocT(pool, &stacks, totalStack, err)) return false;
-  hipLaunchKernelGGL(k_make_refs, dim3((nT + 63) / 64), dim3(64), 0, st, A, slotAt, stackAt, stacks, boxes, made);
+  if (plain)
+    hipLaunchKernelGGL(k_plain_refs, grid, blk, 0, st, A, slotAt, boxes, made);
+  else
+    hipLaunchKernelGGL(k_make_refs, dim3((nT + 63) / 64), dim3(64), 0, st, A, slotAt, stackAt, stacks, boxes, made);
   scan.run(made, nT, refAt, st);
   uint32_t total = 0;
   if (!ok(hipMemcpy(&total, refAt + nT, 4, hipMemcpyDeviceToHost), "count")) return false;

@@ -290,14 +290,26 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     return BDPT_E_LIMIT;
   }
   {
-    std::atomic<int> bad{0};  // 1 = material id, 2 = vertex index
+    std::atomic<int> bad{0};  // 1 = material id, 2 = vertex index, 3 = vertex position
     hostParallelFor(d->numTriangles, [&](size_t t0, size_t t1) {
       for (size_t t = t0; t < t1; t++) {
         if (d->triMaterial[t] >= d->numMaterials) bad.store(1);
-        for (int k = 0; k < 3; k++)
-          if (d->indices[t * 3 + (size_t)k] >= d->numVertices) bad.store(2);
+        for (int k = 0; k < 3; k++) {
+          const uint32_t vi = d->indices[t * 3 + (size_t)k];
+          if (vi >= d->numVertices) {
+            bad.store(2);
+            continue;
+          }
+          // (a box with a NaN or an infinity in it has no place in a tree built by comparing and sorting boxes)
+          const float* p = d->positions + (size_t)vi * 3;
+          if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) && bad.load() == 0) bad.store(3);
+        }
       }
     });
+    if (bad.load() == 3) {
+      fail(c, "scene: a triangle has a vertex position that is not finite");
+      return BDPT_E_INVALID;
+    }
     if (bad.load() == 1) {
       fail(c, "scene: triMaterial out of range");
       return BDPT_E_INVALID;

@@ -317,6 +317,10 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx);
 void bdpt_destroy(bdpt_ctx* ctx);
 const char* bdpt_last_error(const bdpt_ctx* ctx);
 
+/* Copies the scene and builds its acceleration structure on the context's device (what the reference leaves to the DXR
+ * driver: Falcor RtModel.cpp:181-254, RtScene.cpp:220-308).  The caller keeps its arrays.  BDPT_E_INVALID for indices or
+ * material ids out of range and for a triangle with a vertex position that is not finite; BDPT_E_NOMEM when host or
+ * device memory runs out during the build; BDPT_E_LIMIT past 2^28 triangles / 2^31 records. */
 int bdpt_set_scene(bdpt_ctx* ctx, const bdpt_scene_desc* scene);
 int bdpt_get_bvh_info(const bdpt_ctx* ctx, bdpt_bvh_info* out);
 int bdpt_set_camera(bdpt_ctx* ctx, const bdpt_camera* cam);

@@ -607,6 +607,20 @@ def test_error_conventions(pkg, gpu_ctx):
     bad = pkg.abi.SceneDesc()
     with pytest.raises(pkg.BdptError):
         ctx.set_scene(bad)
+    # a vertex position that is not finite (of a triangle; unreferenced vertices are nobody's business) is refused before the
+    # acceleration structure is built by comparing and sorting boxes; the context keeps working afterwards
+    import ctypes
+    n = scene.desc.numVertices * 3
+    pos = np.ctypeslib.as_array(scene.desc.positions, shape=(n,)).copy()
+    broken = pkg.abi.SceneDesc()
+    ctypes.memmove(ctypes.byref(broken), ctypes.byref(scene.desc), ctypes.sizeof(broken))
+    for value in (np.nan, np.inf):
+        pos2 = pos.copy()
+        pos2[3 * int(np.ctypeslib.as_array(scene.desc.indices, shape=(3,))[1]) + 2] = value
+        broken.positions = pos2.ctypes.data_as(C.POINTER(C.c_float))
+        with pytest.raises(pkg.BdptError, match="not finite"):
+            ctx.set_scene(broken)
+    ctx.set_scene(scene.desc)
     ctx.close()
 
 

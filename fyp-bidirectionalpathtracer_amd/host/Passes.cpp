@@ -519,6 +519,9 @@ void BDPTPass::initScene(RenderContext*, Scene::SharedPtr pScene) {
   mpScene = pScene;
   if (mpRays) mpRays->setScene(mpScene);
 }
+void BDPTPass::resize(uint32_t width, uint32_t height) {
+  if (mpRays && width && height) (void)mpRays->ensureSize(width, height);
+}
 void BDPTPass::renderGui(Gui* pGui) {
   int dirty = 0;
   dirty |= (int)pGui->addIntVar("Max Ray Depth", mUserSpecifiedRayDepth, 0, mMaxPossibleRayDepth);

@@ -95,6 +95,9 @@ class BDPTPass : public RenderPass {
   void initScene(RenderContext* pRenderContext, Scene::SharedPtr pScene) override;
   void execute(RenderContext* pRenderContext) override;
   void renderGui(Gui* pGui) override;
+  // The frame's path state is sized as soon as the frame size is known — before initScene builds the acceleration
+  // structure, whose freed scratch the driver would otherwise have to clear again under these allocations
+  void resize(uint32_t width, uint32_t height) override;
   bool requiresScene() override { return true; }
   bool usesRayTracing() override { return true; }
 

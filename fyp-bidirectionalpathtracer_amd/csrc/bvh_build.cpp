@@ -255,23 +255,17 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
       }
     }
   }
-  uint32_t mid = 0;
-  if (bestAxis >= 0) {
-    const float lo = cb.lo[bestAxis], ext = cb.hi[bestAxis] - cb.lo[bestAxis];
-    const float scale = (float)kBins / ext;
-    auto goesLeft = [&](const Ref& r) {
-      int b = (int)((r.cent[bestAxis] - lo) * scale);
-      b = std::min(std::max(b, 0), kBins - 1);
-      return b <= bestSplit;
-    };
+  // A STABLE partition of the node's range — lefts in their order, then rights in theirs — is the one way references
+  // move, whatever decides who goes left.  Large nodes (the top of the tree: a few dozen nodes that together touch every
+  // reference several times) do it in three parallel passes: count the lefts of every chunk, scatter the records into
+  // the scratch array at offsets from those counts, copy back.  The chunks are fixed-size, not per-thread, and the rule is
+  // chosen by the node's SIZE, so the permutation — and with it the tree — does not depend on the thread count; small
+  // nodes do the same by one thread.  One rule for every node size: a builder that partitions in parallel — the passes
+  // here, or a device (bvh_device.hip: flags, scan, scatter) — produces the very same permutation.
+  auto partitionStable = [&](auto&& goesLeft) -> uint32_t {
+    Ref* const tmp = B.scratch.data() + first;
     if (count >= kStablePartitionMin) {
-      // Large nodes (the top of the tree: a few dozen nodes that together touch every reference several times): a STABLE
-      // partition — lefts in their order, then rights in theirs — in three parallel passes: count the lefts of every
-      // chunk, scatter the records into the scratch array at offsets from those counts, copy back.  The chunks are
-      // fixed-size, not per-thread, and the rule is chosen by the node's SIZE, so the permutation — and with it the
-      // tree — does not depend on the thread count.
       const size_t nChunks = ((size_t)count + kPartitionChunk - 1) / kPartitionChunk;
-      Ref* const tmp = B.scratch.data() + first;
       std::vector<uint32_t> lefts(nChunks + 1, 0);
       parallelChunks(count, threads, kPartitionChunk, [&](size_t ci, size_t a, size_t b) {
         uint32_t n = 0;
@@ -290,34 +284,42 @@ uint32_t splitNode(const BuildData& B, uint32_t first, uint32_t count, uint32_t 
         }
       });
       parallelChunks(count, threads, kPartitionChunk, [&](size_t, size_t a, size_t b) { std::memcpy(base + a, tmp + a, (b - a) * sizeof(Ref)); });
-      mid = nLeft;
-    } else {
-      // Small nodes: the same stable partition by one thread, through the scratch array (the range is the node's own).
-      // One rule for every node size: a builder that partitions in parallel — the passes above, or a device — produces
-      // the very same permutation.
-      Ref* const tmp = B.scratch.data() + first;
-      uint32_t l = 0, r = 0;
-      for (uint32_t k = 0; k < count; k++) {
-        if (goesLeft(base[k]))
-          base[l++] = base[k];  // (l <= k: never overwrites an element not yet read)
-        else
-          tmp[r++] = base[k];
-      }
-      std::memcpy(base + l, tmp, (size_t)r * sizeof(Ref));
-      mid = l;
+      return nLeft;
     }
+    uint32_t l = 0, r = 0;
+    for (uint32_t k = 0; k < count; k++) {
+      if (goesLeft(base[k]))
+        base[l++] = base[k];  // (l <= k: never overwrites an element not yet read)
+      else
+        tmp[r++] = base[k];
+    }
+    std::memcpy(base + l, tmp, (size_t)r * sizeof(Ref));
+    return l;
+  };
+  uint32_t mid = 0;
+  if (bestAxis >= 0) {
+    const float lo = cb.lo[bestAxis], ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+    const float scale = (float)kBins / ext;
+    mid = partitionStable([&](const Ref& r) {
+      int b = (int)((r.cent[bestAxis] - lo) * scale);
+      b = std::min(std::max(b, 0), kBins - 1);
+      return b <= bestSplit;
+    });
   }
   if (mid == 0 || mid == count) {
-    // median split on the widest centroid axis (also the degenerate all-equal case)
+    // Median split on the widest centroid axis (also the degenerate all-equal case): the count / 2 references that come
+    // first by (centroid, reference id) go left — found by SELECTING the pivot, not by sorting — and the same stable
+    // partition moves them: no order inside the halves has to be defined beyond the one they already have, and a device
+    // does it with a radix select and the partition machinery it has anyway.
     int axis = 0;
     const float e0 = cb.hi[0] - cb.lo[0], e1 = cb.hi[1] - cb.lo[1], e2 = cb.hi[2] - cb.lo[2];
     if (e1 > e0 && e1 >= e2) axis = 1;
     if (e2 > e0 && e2 > e1) axis = 2;
-    mid = count / 2;
-    // (a full sort, not nth_element: the order inside the halves is then defined, and with it the whole permutation)
-    std::sort(base, base + count, [&](const Ref& a, const Ref& b) {
-      return a.cent[axis] < b.cent[axis] || (a.cent[axis] == b.cent[axis] && a.id < b.id);
-    });
+    std::vector<std::pair<float, uint32_t>> keys(count);
+    for (uint32_t k = 0; k < count; k++) keys[k] = {base[k].cent[axis], base[k].id};
+    std::nth_element(keys.begin(), keys.begin() + count / 2, keys.end());
+    const std::pair<float, uint32_t> pivot = keys[count / 2];
+    mid = partitionStable([&](const Ref& r) { return std::pair<float, uint32_t>(r.cent[axis], r.id) < pivot; });
   }
   return mid;
 }

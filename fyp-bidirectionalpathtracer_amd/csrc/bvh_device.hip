@@ -18,8 +18,9 @@
 //   flags -> exclusive scan -> stable partition scatter          (lefts in their order, then rights in theirs)
 //   children two nodes per split slot, in slot order
 // — and produces, bit for bit, the permutation of the references and the tree the host code produces (one partition
-// rule there too).  Median fallback (no useful SAH split, or the depth budget): the slot's range is sorted by
-// (centroid, reference id) — by one wave for up to kMedianWave references, on the host beyond that (degenerate inputs only).
+// rule there too).  Median fallback (no useful SAH split, or the depth budget): the count / 2 references that come first by
+// (centroid, reference id) go left — the pivot found by one wave's ranking for up to kMedianWave references, by a radix
+// select over the 64-bit key beyond that — through the same stable partition.
 // Float min / max through atomics on an order-preserving uint encoding: exact, order-independent.  -0 is turned into +0
 // when the references are made, so no box component depends on the order in which equal zeros met.
 #include <hip/hip_runtime.h>
@@ -136,7 +137,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 // on memory); larger ones by the flat launches over the references.  The slot number a reference carries has
 // kSmallBit set when its slot is a small one (kNone has it too: "nothing here for the flat launches").
 constexpr uint32_t kSmall = 1024, kSmallBit = 0x80000000u;
-constexpr uint32_t kMedianWave = 2048;  // median-fallback nodes up to this many references are sorted by one wave
+constexpr uint32_t kMedianWave = 2048;  // median-fallback slots up to this many references find their pivot by one wave's ranking, larger ones by a radix select
 enum : uint32_t { ST_LEAF = 0u, ST_SPLIT = 1u, ST_MEDIAN = 2u };
 constexpr int kBinWords = 7;  // lo3 hi3 (encoded) + count
 
@@ -174,7 +175,9 @@ struct Level {
   uint32_t* maxis;   // the median fallback's axis: the widest centroid axis
   uint32_t* split;   // SPLIT: last bin of the left side
   uint32_t* nLeft;
-  uint32_t* sorted;  // MEDIAN: range already sorted
+  uint32_t* sel;     // MEDIAN slot of more than kMedianWave references: its row in the radix select's tables (else kNone)
+  uint32_t* pivotHi;  // MEDIAN: the pivot key — (encoded centroid on maxis, reference id) of the reference that comes
+  uint32_t* pivotLo;  //         count / 2-th in that order: the keys below it go left
   uint32_t* child;   // slot of the left child in the next level (right = +1)
 };
 
@@ -189,8 +192,8 @@ struct Tree {  // node arrays (struct of arrays), capacity 2n
 
 struct Counters {
   uint32_t numSplit;       // slots that get two children this level
-  uint32_t numMedianNew;   // MEDIAN slots whose range is not sorted yet
-  uint32_t numMedianBig;   // of those: too large for the wave sort
+  uint32_t numMedianNew;   // MEDIAN slots of this level
+  uint32_t numMedianBig;   // of those: too large for the one-wave ranking
   uint32_t pad;
 };
 
@@ -296,7 +299,7 @@ __global__ void k_prepare(Level L, Tree T, uint32_t nA, Counters* C, uint32_t* _
   }
   const uint32_t node = L.node[a], count = L.count[a], depth = L.depth[a];
   for (int j = 0; j < 6; j++) T.box[(size_t)node * 6 + j] = nb[j];
-  L.sorted[a] = 0;
+  L.sel[a] = kNone;
   L.nLeft[a] = 0;
   L.child[a] = kNone;
   if (count <= kBvhLeafMax) {
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(64) void k_small(const BvhBuildRef* __restrict__ re
   const uint32_t node = L.node[a], depth = L.depth[a];
   if (lane == 0) {
     for (int j = 0; j < 6; j++) T.box[(size_t)node * 6 + j] = v[j];
-    L.sorted[a] = 0;
+    L.sel[a] = kNone;
     L.nLeft[a] = 0;
     L.child[a] = kNone;
   }
@@ -622,7 +625,9 @@ __global__ __launch_bounds__(256) void k_flags(const BvhBuildRef* __restrict__ r
       b = b < 0 ? 0 : (b > kBvhBins - 1 ? kBvhBins - 1 : b);
       f = b <= (int)L.split[a] ? 1u : 0u;
     } else if (st == ST_MEDIAN) {
-      f = (k - L.first[a]) < L.count[a] / 2 ? 1u : 0u;  // (the range is sorted by then)
+      const BvhBuildRef r = refs[k];
+      const uint32_t hi = enc(r.cent[L.maxis[a]]), pHi = L.pivotHi[a];
+      f = (hi < pHi || (hi == pHi && r.id < L.pivotLo[a])) ? 1u : 0u;  // (the pivot is known by the time this matters)
     }
   }
   F[k] = f;
@@ -710,36 +715,84 @@ __global__ void k_nleft(Level L, uint32_t nA, const uint32_t* __restrict__ S, Co
   }
 }
 
-// MEDIAN slots of at most kMedianWave references: one wave sorts the range by (centroid on the slot's axis, id) — each
-// lane ranks its elements against all the others — into `tmp`, then copies it back.
-__global__ __launch_bounds__(64) void k_median_sort(BvhBuildRef* refs, BvhBuildRef* tmp, Level L, uint32_t nA) {
+// The median fallback's pivot: the reference that comes count / 2-th by (centroid on the slot's axis, reference id).
+// Slots of at most kMedianWave references: one wave ranks every reference against all the others.
+__global__ __launch_bounds__(64) void k_median_pivot_small(const BvhBuildRef* __restrict__ refs, Level L, uint32_t nA) {
   const uint32_t a = blockIdx.x;
-  if (a >= nA || L.state[a] != ST_MEDIAN || L.sorted[a] != 0 || L.count[a] > kMedianWave) return;
-  const uint32_t first = L.first[a], count = L.count[a], axis = L.maxis[a];
+  if (a >= nA || L.state[a] != ST_MEDIAN || L.count[a] > kMedianWave) return;
+  const uint32_t first = L.first[a], count = L.count[a], axis = L.maxis[a], mid = count / 2;
   for (uint32_t i = threadIdx.x; i < count; i += 64) {
-    const BvhBuildRef r = refs[first + i];
-    const float ki = r.cent[axis];
+    const float ki = refs[first + i].cent[axis];
+    const uint32_t idi = refs[first + i].id;
     uint32_t rank = 0;
     for (uint32_t j = 0; j < count; j++) {
       const float kj = refs[first + j].cent[axis];
       const uint32_t idj = refs[first + j].id;
-      rank += (kj < ki || (kj == ki && idj < r.id)) ? 1u : 0u;
+      rank += (kj < ki || (kj == ki && idj < idi)) ? 1u : 0u;
     }
-    tmp[first + rank] = r;
+    if (rank == mid) {
+      L.pivotHi[a] = enc(ki);
+      L.pivotLo[a] = idi;
+    }
   }
-  __syncthreads();
-  __threadfence_block();
-  for (uint32_t i = threadIdx.x; i < count; i += 64) refs[first + i] = tmp[first + i];
-  if (threadIdx.x == 0) L.sorted[a] = 1;
 }
-__global__ void k_median_list_big(Level L, uint32_t nA, uint32_t* list, uint32_t* listCount) {  // slots the host has to sort
+// Larger slots: a radix select over the 64-bit key, most significant byte first — per pass a histogram of the byte
+// among the keys that match the prefix found so far (k_sel_hist), then the bin the wanted rank falls in (k_sel_pick).
+__global__ void k_median_list_big(Level L, uint32_t nA, uint32_t* list, uint32_t* listCount, uint32_t* selHi, uint32_t* selLo, uint32_t* selK) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= nA || L.state[a] != ST_MEDIAN || L.sorted[a] != 0 || L.count[a] <= kMedianWave) return;
-  list[atomicAdd(listCount, 1u)] = a;
+  if (a >= nA || L.state[a] != ST_MEDIAN || L.count[a] <= kMedianWave) return;
+  const uint32_t j = atomicAdd(listCount, 1u);
+  list[j] = a;
+  L.sel[a] = j;
+  selHi[j] = 0;
+  selLo[j] = 0;
+  selK[j] = L.count[a] / 2;
 }
-__global__ void k_mark_sorted(Level L, const uint32_t* list, uint32_t m) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) L.sorted[list[i]] = 1;
+__global__ __launch_bounds__(256) void k_sel_hist(const BvhBuildRef* __restrict__ refs, const uint32_t* __restrict__ nodeOf, uint32_t n, Level L, int pass,
+                                                  const uint32_t* __restrict__ selHi, const uint32_t* __restrict__ selLo, uint32_t* __restrict__ hist) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t a = nodeOf[k];
+  if (a == kNone) return;
+  a &= ~kSmallBit;
+  if (L.state[a] != ST_MEDIAN) return;
+  const uint32_t j = L.sel[a];
+  if (j == kNone) return;
+  const BvhBuildRef r = refs[k];
+  const uint32_t hi = enc(r.cent[L.maxis[a]]), lo = r.id;
+  // the bytes above byte `pass` must be the prefix found so far
+  bool match;
+  uint32_t digit;
+  if (pass >= 4) {
+    const int sh = 8 * (pass - 4);
+    match = sh == 24 || (hi >> (sh + 8)) == (selHi[j] >> (sh + 8));
+    digit = (hi >> sh) & 255u;
+  } else {
+    const int sh = 8 * pass;
+    match = hi == selHi[j] && (sh == 24 || (lo >> (sh + 8)) == (selLo[j] >> (sh + 8)));
+    digit = (lo >> sh) & 255u;
+  }
+  if (match) atomicAdd(&hist[(size_t)j * 256 + digit], 1u);
+}
+__global__ void k_sel_pick(uint32_t m, int pass, uint32_t* selHi, uint32_t* selLo, uint32_t* selK, uint32_t* hist, Level L, const uint32_t* __restrict__ list) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t* h = hist + (size_t)j * 256;
+  uint32_t kk = selK[j], d = 0;
+  for (; d < 255; d++) {
+    if (kk < h[d]) break;
+    kk -= h[d];
+  }
+  for (uint32_t i = 0; i < 256; i++) h[i] = 0;
+  selK[j] = kk;
+  if (pass >= 4)
+    selHi[j] |= d << (8 * (pass - 4));
+  else
+    selLo[j] |= d << (8 * pass);
+  if (pass == 0) {
+    L.pivotHi[list[j]] = selHi[j];
+    L.pivotLo[list[j]] = selLo[j];
+  }
 }
 
 // slots that split: G[a] = 1 (scanned into the children's slots)
@@ -1403,7 +1456,8 @@ bool allocLevel(BvhDeviceArena& pool, Level& L, size_t cap, std::string& err) {
   return devAllocT(pool, &L.node, cap, err) && devAllocT(pool, &L.first, cap, err) && devAllocT(pool, &L.count, cap, err) &&
          devAllocT(pool, &L.depth, cap, err) && devAllocT(pool, &L.state, cap, err) && devAllocT(pool, &L.bnd, cap * 12, err) &&
          devAllocT(pool, &L.lo, cap * 3, err) && devAllocT(pool, &L.scale, cap * 3, err) && devAllocT(pool, &L.axis, cap, err) && devAllocT(pool, &L.maxis, cap, err) &&
-         devAllocT(pool, &L.split, cap, err) && devAllocT(pool, &L.nLeft, cap, err) && devAllocT(pool, &L.sorted, cap, err) &&
+         devAllocT(pool, &L.split, cap, err) && devAllocT(pool, &L.nLeft, cap, err) && devAllocT(pool, &L.sel, cap, err) &&
+         devAllocT(pool, &L.pivotHi, cap, err) && devAllocT(pool, &L.pivotLo, cap, err) &&
          devAllocT(pool, &L.child, cap, err);
 }
 
@@ -1496,8 +1550,7 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, st, L[0], T, n);
   uint32_t nA = 1, numNodes = 1;
   int cur = 0;
-  std::vector<uint32_t> hostList;
-  std::vector<BvhBuildRef> hostRange;
+  uint32_t *selHist = nullptr, *selHi = nullptr, *selLo = nullptr, *selK = nullptr;  // (allocated when a level first needs them)
   for (int level = 0; nA > 0; level++) {
     if (level > kBvhBinaryMaxDepth + 2) {
       err = "device tree builder: depth budget exceeded";
@@ -1530,28 +1583,21 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
     if (!ok(hipMemcpy(&hc, C, sizeof(hc), hipMemcpyDeviceToHost), "counters")) return false;
     stage(S_NLEFT);
     if (hc.numMedianNew > 0) {
-      // median fallback: sort the ranges (small ones by a wave each, large ones on the host), then partition again
-      hipLaunchKernelGGL(k_median_sort, dim3(nA), dim3(64), 0, st, rA, rB, Lc, nA);
+      // median fallback: every such slot's pivot (by one wave's ranking, or by a radix select), then the flags again
+      hipLaunchKernelGGL(k_median_pivot_small, dim3(nA), dim3(64), 0, st, rA, Lc, nA);
       if (hc.numMedianBig > 0) {
-        if (!ok(hipMemsetAsync(bigCount, 0, 4, st), "memset")) return false;
-        hipLaunchKernelGGL(k_median_list_big, gridFor(nA), blk, 0, st, Lc, nA, bigList, bigCount);
+        const uint32_t capBig = n / (kMedianWave + 1) + 1;  // (disjoint ranges of more than kMedianWave references)
+        if (!selHist && (!devAllocT(pool, &selHist, (size_t)capBig * 256, err) || !devAllocT(pool, &selHi, capBig, err) || !devAllocT(pool, &selLo, capBig, err) ||
+                         !devAllocT(pool, &selK, capBig, err)))
+          return false;
+        if (!ok(hipMemsetAsync(bigCount, 0, 4, st), "memset") || !ok(hipMemsetAsync(selHist, 0, (size_t)capBig * 256 * 4, st), "memset")) return false;
+        hipLaunchKernelGGL(k_median_list_big, gridFor(nA), blk, 0, st, Lc, nA, bigList, bigCount, selHi, selLo, selK);
         uint32_t m = 0;
         if (!ok(hipMemcpy(&m, bigCount, 4, hipMemcpyDeviceToHost), "list")) return false;
-        hostList.resize(m);
-        if (m && !ok(hipMemcpy(hostList.data(), bigList, (size_t)m * 4, hipMemcpyDeviceToHost), "list")) return false;
-        for (uint32_t a : hostList) {
-          uint32_t first = 0, count = 0, axis = 0;
-          if (!ok(hipMemcpy(&first, Lc.first + a, 4, hipMemcpyDeviceToHost), "slot") || !ok(hipMemcpy(&count, Lc.count + a, 4, hipMemcpyDeviceToHost), "slot") ||
-              !ok(hipMemcpy(&axis, Lc.maxis + a, 4, hipMemcpyDeviceToHost), "slot"))
-            return false;
-          hostRange.resize(count);
-          if (!ok(hipMemcpy(hostRange.data(), rA + first, (size_t)count * sizeof(BvhBuildRef), hipMemcpyDeviceToHost), "range")) return false;
-          std::sort(hostRange.begin(), hostRange.end(), [axis](const BvhBuildRef& x, const BvhBuildRef& y) {
-            return x.cent[axis] < y.cent[axis] || (x.cent[axis] == y.cent[axis] && x.id < y.id);
-          });
-          if (!ok(hipMemcpy(rA + first, hostRange.data(), (size_t)count * sizeof(BvhBuildRef), hipMemcpyHostToDevice), "range")) return false;
+        for (int pass = 7; pass >= 0 && m > 0; pass--) {
+          hipLaunchKernelGGL(k_sel_hist, gridFor(n), blk, 0, st, rA, ofA, n, Lc, pass, selHi, selLo, selHist);
+          hipLaunchKernelGGL(k_sel_pick, gridFor(m), blk, 0, st, m, pass, selHi, selLo, selK, selHist, Lc, bigList);
         }
-        if (m) hipLaunchKernelGGL(k_mark_sorted, gridFor(m), blk, 0, st, Lc, bigList, m);
       }
       hipLaunchKernelGGL(k_flags, gridFor(n), blk, 0, st, rA, ofA, n, Lc, F);
       scan.run(F, n, S, st);

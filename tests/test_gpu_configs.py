@@ -373,7 +373,7 @@ def test_device_builder_builds_what_the_host_builder_builds(pkg, monkeypatch):
         leaf-ordered triangles, reference boxes, packed records, depth / stack / SAH cost;
       * bdpt_bvh_recs_hash of the whole device pipeline = of the host pipeline: every packed record.
     Scenes: the bench scene, the heavy-tailed one, the alpha-masked one, tiny inputs (one wave per slot from the root on), a
-    degenerate pile of identical centroids plus an 18-decade line (median fallback by the wave sort and by the host sort,
+    degenerate pile of identical centroids plus an 18-decade line (median fallback: pivot by one wave's ranking and by the radix select,
     depth budget), and builds with other split budgets (opaque outliers split too; eight splits per alpha card)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("device_tree_check", os.path.join(ROOT, "tools", "device_tree_check.py"))
@@ -494,7 +494,7 @@ def _many_cards_scene(pkg, n_cards, tex, uv_scale, rng, threshold=0.5, jitter=0.
 def test_device_builder_on_adversarial_inputs(pkg, monkeypatch):
     """The device build against the host build (packed records + summary, bdpt_bvh_recs_hash) where the code paths fork:
     reference counts on either side of the one-wave-per-node bound (1024) and of the wave sort's bound (2048), every
-    triangle identical (median fallback through the host sort), geometry on a line and in a plane (one or two centroid
+    triangle identical (median fallback through the radix select), geometry on a line and in a plane (one or two centroid
     axes without extent), coordinates over 24 decades, and alpha-masked cards — random blobs, a checkerboard, one opaque
     texel, tiled and shifted texture coordinates, up to 64 splits per card."""
     import importlib.util

@@ -146,11 +146,15 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
     next shape's set-up would be charged the wait for this one's tens of GB (measured: 0.9-1.2 s per shape)."""
     # (unless the device is short of memory: path state grows with pixels x depth^2, the build takes scratch on top)
     need = W * H * (650 * D + 13 * D * D) + scene.desc.numTriangles * 3000 + (4 << 30)  # measured: 8.5 / 62 / 93 GB of path state at depth 8 / 12 / 16
-    if torch.cuda.mem_get_info()[0] < need:
+    free_before = torch.cuda.mem_get_info()[0]
+    if free_before < need:
         for q in keep + _CLOSE_LAST:
             q.close()
         del keep[:], _CLOSE_LAST[:]
         torch.cuda.synchronize()
+        # ... and then the wipe of what was just freed (~30 GB/s, tools/vram_wipe_probe.py) is the bench's housekeeping, not
+        # this shape's set-up: wait it out before the clock starts
+        time.sleep(1.0 + max(0, torch.cuda.mem_get_info()[0] - free_before) / 25e9)
     free0 = torch.cuda.mem_get_info()[0]
     t0 = time.time()
     pipe = pkg.FramePipeline(scene, W, H, max_depth=D, mat_index=mat, accum_limit=1 << 30)

@@ -145,7 +145,7 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
     The pipeline is left open (appended to `keep`): the driver wipes freed VRAM before it hands it out again, and the
     next shape's set-up would be charged the wait for this one's tens of GB (measured: 0.9-1.2 s per shape)."""
     # (unless the device is short of memory: path state grows with pixels x depth^2, the build takes scratch on top)
-    need = W * H * (650 * D + 13 * D * D) + scene.desc.numTriangles * 3000 + (4 << 30)  # measured: 8.5 / 62 / 93 GB of path state at depth 8 / 12 / 16
+    need = W * H * (580 * D + 12 * D * D) + scene.desc.numTriangles * 2000 + (2 << 30)  # measured: 8.5 / 62 / 93 GiB of path state at depth 8 / 12 / 16, 18 GiB of scene + build scratch at 10 M triangles
     free_before = torch.cuda.mem_get_info()[0]
     if free_before < need:
         for q in keep + _CLOSE_LAST:

@@ -260,8 +260,8 @@ struct BvhPackInput {
   uint32_t numTris;
   const uint32_t* refTri;  // the triangle of every reference, by reference id (null: the BvhRefMaker of this build kept it, and triRecs)
   uint32_t numRefs;
-  const BvhWideNode* wide;
-  const BvhSlot* slots;
+  const BvhWideNode* wide;  // null: the collapse has not happened — the packer does it from the tree of this build and fills
+  const BvhSlot* slots;     // out.numNodes / maxDepth / maxStack / sahCost as well
   size_t numWide;
   float pad;  // what every child box is padded by before it is quantised
 };
@@ -290,7 +290,7 @@ void bvhSetDefaultTreeBuilder(BvhTreeBuilder f, void* user);
 // The device implementation (bvh_device.hip).  One BvhDeviceBuild per build: the stages hand their results to one another
 // in device memory through it (`user` of both functions).
 struct BvhDeviceBuild;
-BvhDeviceBuild* bvhDeviceBuildBegin(int device);
+BvhDeviceBuild* bvhDeviceBuildBegin(int device, bool collapseOnDevice = false);
 void bvhDeviceBuildEnd(BvhDeviceBuild* b);
 bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
 bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err);
@@ -305,6 +305,7 @@ struct BvhBuildOptions {
   const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
   BvhTreeBuilder treeBuilder = nullptr;    // null: the host code builds the binary tree
   BvhRefMaker refMaker = nullptr;          // (with a treeBuilder and a packer only) null: the host code makes the references
+  bool collapseInPacker = false;           // (with refMaker, treeBuilder and packer) the packer also does the four-wide collapse (in.wide = null) and fills the summary
   BvhPacker packer = nullptr;              // (with a treeBuilder only) null: the host code quantises and packs; else Bvh::deviceRecs is the result
   void* treeBuilderUser = nullptr;
   std::string* error = nullptr;            // receives the tree builder's message when it fails (the build then has no nodes)

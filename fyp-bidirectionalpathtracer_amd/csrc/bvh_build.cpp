@@ -953,6 +953,26 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
 
   lap("append");
   out.numRefs = n;
+  if (packer && refMaker && opt.collapseInPacker) {
+    // everything from here on — collapse, quantisation, packing, the summary — happens where the tree is (bvh_device.hip)
+    BvhPackInput in;
+    in.triRecs = recs.data();
+    in.numTris = nTris;
+    in.refTri = nullptr;
+    in.numRefs = n;
+    in.wide = nullptr;
+    in.slots = nullptr;
+    in.numWide = 0;
+    in.pad = pad;
+    std::string err;
+    if (!packer(treeBuilderUser, in, out, err)) {
+      if (opt.error) *opt.error = err.empty() ? "packer failed" : err;
+      out.deviceRecs = nullptr;
+      out.deviceNumRecs = 0;
+    }
+    lap("device collapse + pack");
+    return;
+  }
   // Leaf-ordered triangle list (a packer gathers it on the device).
   out.tris.resize(packer ? 0 : n);
   out.refBox.resize(packer ? 0 : (size_t)n * 6);

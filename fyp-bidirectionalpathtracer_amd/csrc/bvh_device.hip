@@ -99,6 +99,8 @@ struct BvhDeviceBuild {
   uint32_t* refTri = nullptr;     // ... the triangle of each, and the triangle records (for the packer)
   BvhTri* triRecs = nullptr;
   uint32_t numTris = 0;
+  bool collapseHere = false;          // the four-wide collapse happens on the device too: the tree is not read back
+  std::vector<uint32_t> levelStart;   // first node of every level of the binary tree, then numNodes (for the collapse)
   void releaseTree() {
     if (nodes) (void)hipFree(nodes);
     if (order) (void)hipFree(order);
@@ -118,9 +120,10 @@ struct BvhDeviceBuild {
     arena.release();
   }
 };
-BvhDeviceBuild* bvhDeviceBuildBegin(int device) {
+BvhDeviceBuild* bvhDeviceBuildBegin(int device, bool collapseOnDevice) {
   BvhDeviceBuild* b = new BvhDeviceBuild();
   b->device = device;
+  b->collapseHere = collapseOnDevice;
   return b;
 }
 void bvhDeviceBuildEnd(BvhDeviceBuild* b) {
@@ -1377,6 +1380,221 @@ __global__ void k_compact_refs(uint32_t numTris, const uint32_t* __restrict__ sl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The four-wide collapse on the device: bvh_build.cpp's `collapse` — the same greedy widening under the stack budget, the
+// same node ORDER (the top of the tree depth first; then, in the order the top met them, the subtrees of at most
+// kCollapseGrain binary nodes, each depth first) — computed level by level instead of by a walk:
+//   metrics   binary height and subtree size, bottom-up over the tree's levels
+//   expand    the wide nodes breadth first: a level's jobs choose their children; a scan places the next level's jobs
+//   sizes     wide-subtree sizes bottom-up (all nodes / top nodes only), deferred children per top node
+//   number    the final index of every wide node, top-down: top part, deferred roots (by the top's order), the rest
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kCollapseGrainDev = 1u << 15;  // (bvh_build.cpp kCollapseGrain)
+enum : uint32_t { WF_TOP = 1u, WF_DEFROOT = 2u };
+struct WideTmp {  // breadth-first arrays, one entry per wide node
+  uint32_t* src;
+  uint32_t* kids;    // 4 per node
+  int32_t* nk;
+  uint32_t* depth;
+  uint32_t* above;   // stack entries above this node's own (the parent's `need`)
+  uint32_t* need;
+  int32_t* parent;   // breadth-first index of the parent (-1: the root)
+  int32_t* kIdx;
+  uint32_t* flags;
+  int32_t* child;    // 4 per node: breadth-first index of the wide node under kid k (-1: a leaf)
+  uint32_t* nInterior;
+  uint32_t* sizeAll;
+  uint32_t* sizeTop;
+  uint32_t* defCount;
+  uint32_t* idx;     // final index
+};
+__global__ void k_tree_metrics(const BvhBuildNode* __restrict__ nodes, uint32_t start, uint32_t end, uint16_t* __restrict__ hgt, uint32_t* __restrict__ sub) {
+  const uint32_t t = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= end) return;
+  const BvhBuildNode nd = nodes[t];
+  if (nd.left >= 0) {
+    const uint16_t hl = hgt[nd.left], hr = hgt[nd.right];
+    hgt[t] = (uint16_t)(1 + (hl > hr ? hl : hr));
+    sub[t] = 1u + sub[nd.left] + sub[nd.right];
+  } else {
+    hgt[t] = 0;
+    sub[t] = 1;
+  }
+}
+BDV float nodeArea(const BvhBuildNode& n) { return areaOf(n.box.lo, n.box.hi); }
+// one job = one wide node: its children (the collapse's inner loop), how much stack it needs, how many of them are interior
+__global__ void k_wide_expand(WideTmp W, uint32_t start, uint32_t end, const BvhBuildNode* __restrict__ nodes, const uint16_t* __restrict__ hgt,
+                              uint32_t* __restrict__ maxDepth, uint32_t* __restrict__ maxStack) {
+  const uint32_t b = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= end) return;
+  const uint32_t src = W.src[b], above = W.above[b];
+  uint32_t kids[4] = {0, 0, 0, 0};
+  int nk = 0;
+  if (nodes[src].left < 0) {  // the root is a single leaf
+    kids[nk++] = src;
+  } else {
+    kids[nk++] = (uint32_t)nodes[src].left;
+    kids[nk++] = (uint32_t)nodes[src].right;
+    while (nk < 4) {
+      int best = -1;
+      float bestArea = -1.0f;
+      for (int k = 0; k < nk; k++)
+        if (nodes[kids[k]].left >= 0) {
+          const float ar = nodeArea(nodes[kids[k]]);
+          if (ar > bestArea) {
+            bestArea = ar;
+            best = k;
+          }
+        }
+      if (best < 0) break;
+      const uint32_t t = kids[best];
+      uint32_t tallest = hgt[nodes[t].left] > hgt[nodes[t].right] ? hgt[nodes[t].left] : hgt[nodes[t].right];
+      for (int k = 0; k < nk; k++)
+        if (k != best) tallest = tallest > hgt[kids[k]] ? tallest : (uint32_t)hgt[kids[k]];
+      if (above + (uint32_t)nk + tallest > (uint32_t)kBvhMaxStack) break;
+      kids[best] = (uint32_t)nodes[t].left;
+      kids[nk++] = (uint32_t)nodes[t].right;
+    }
+  }
+  const uint32_t need = above + (uint32_t)(nk - 1);
+  uint32_t nInt = 0;
+  for (int k = 0; k < 4; k++) {
+    W.kids[(size_t)b * 4 + k] = k < nk ? kids[k] : 0u;
+    W.child[(size_t)b * 4 + k] = -1;
+    if (k < nk && nodes[kids[k]].left >= 0) nInt++;
+  }
+  W.nk[b] = nk;
+  W.need[b] = need;
+  W.nInterior[b] = nInt;
+  atomicMax(maxDepth, W.depth[b]);
+  atomicMax(maxStack, need);
+}
+// the jobs of the next level: the interior kids of this level's nodes, in (node, k) order
+__global__ void k_wide_children(WideTmp W, uint32_t start, uint32_t end, const uint32_t* __restrict__ at, const BvhBuildNode* __restrict__ nodes,
+                                const uint32_t* __restrict__ sub, int deferral) {
+  const uint32_t b = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= end) return;
+  uint32_t c = end + at[b - start];
+  const uint32_t pf = W.flags[b];
+  const int nk = W.nk[b];
+  for (int k = 0; k < nk; k++) {
+    const uint32_t kid = W.kids[(size_t)b * 4 + k];
+    if (nodes[kid].left < 0) continue;
+    W.child[(size_t)b * 4 + k] = (int32_t)c;
+    W.src[c] = kid;
+    W.depth[c] = W.depth[b] + 1;
+    W.above[c] = W.need[b];
+    W.parent[c] = (int32_t)b;
+    W.kIdx[c] = k;
+    const bool parentTop = (pf & WF_TOP) != 0;
+    const bool def = parentTop && deferral && sub[kid] <= kCollapseGrainDev;
+    W.flags[c] = def ? WF_DEFROOT : (parentTop ? WF_TOP : 0u);
+    c++;
+  }
+}
+__global__ void k_wide_sizes(WideTmp W, uint32_t start, uint32_t end) {
+  const uint32_t b = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= end) return;
+  uint32_t all = 1, top = 1, def = 0;
+  for (int k = 0; k < 4; k++) {
+    const int32_t c = W.child[(size_t)b * 4 + k];
+    if (c < 0) continue;
+    all += W.sizeAll[c];
+    if (W.flags[c] & WF_TOP) top += W.sizeTop[c];
+    if (W.flags[c] & WF_DEFROOT) def++;
+  }
+  W.sizeAll[b] = all;
+  W.sizeTop[b] = (W.flags[b] & WF_TOP) ? top : 0u;
+  W.defCount[b] = (W.flags[b] & WF_TOP) ? def : 0u;
+}
+// pass 1: the top part, depth first (children in k order, top children only)
+__global__ void k_wide_number_top(WideTmp W, uint32_t start, uint32_t end, uint32_t* __restrict__ defCountByIdx) {
+  const uint32_t b = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= end || !(W.flags[b] & WF_TOP)) return;
+  if (W.parent[b] < 0) W.idx[b] = 0;
+  const uint32_t me = W.idx[b];
+  defCountByIdx[me] = W.defCount[b];
+  uint32_t next = me + 1;
+  for (int k = 0; k < 4; k++) {
+    const int32_t c = W.child[(size_t)b * 4 + k];
+    if (c < 0 || !(W.flags[c] & WF_TOP)) continue;
+    W.idx[c] = next;
+    next += W.sizeTop[c];
+  }
+}
+// pass 2: the deferred roots, in the order the top's walk met them (by parent index; within a parent by DEcreasing k)
+__global__ void k_wide_def_rank(WideTmp W, uint32_t nWide, const uint32_t* __restrict__ defBaseByIdx, uint32_t* __restrict__ rankOf, uint32_t* __restrict__ sizeByRank) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nWide || !(W.flags[b] & WF_TOP) || W.defCount[b] == 0) return;
+  uint32_t r = defBaseByIdx[W.idx[b]];
+  for (int k = 3; k >= 0; k--) {
+    const int32_t c = W.child[(size_t)b * 4 + k];
+    if (c < 0 || !(W.flags[c] & WF_DEFROOT)) continue;
+    rankOf[c] = r;
+    sizeByRank[r] = W.sizeAll[c];
+    r++;
+  }
+}
+__global__ void k_wide_number_def(WideTmp W, uint32_t nWide, const uint32_t* __restrict__ rankOf, const uint32_t* __restrict__ offByRank, uint32_t numTop) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nWide || !(W.flags[b] & WF_DEFROOT)) return;
+  W.idx[b] = numTop + offByRank[rankOf[b]];
+}
+// pass 3: inside the deferred subtrees, depth first
+__global__ void k_wide_number_rest(WideTmp W, uint32_t start, uint32_t end) {
+  const uint32_t b = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= end || (W.flags[b] & WF_TOP)) return;
+  uint32_t next = W.idx[b] + 1;
+  for (int k = 0; k < 4; k++) {
+    const int32_t c = W.child[(size_t)b * 4 + k];
+    if (c < 0) continue;
+    W.idx[c] = next;
+    next += W.sizeAll[c];
+  }
+}
+__global__ void k_wide_emit(WideTmp W, uint32_t nWide, BvhWideNode* __restrict__ wide, BvhSlot* __restrict__ slots) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nWide) return;
+  BvhWideNode w;
+  w.src = W.src[b];
+  for (int k = 0; k < 4; k++) w.kids[k] = W.kids[(size_t)b * 4 + k];
+  w.nk = W.nk[b];
+  w.depth = W.depth[b];
+  const uint32_t i = W.idx[b];
+  wide[i] = w;
+  BvhSlot s;
+  s.node = W.parent[b] < 0 ? -1 : (int32_t)W.idx[W.parent[b]];
+  s.idx = W.parent[b] < 0 ? -1 : W.kIdx[b];
+  slots[i] = s;
+}
+// the SAH cost as bvh_build.cpp sums it: float terms (computed side by side), summed in double in node order within blocks
+// of 65536 nodes (one thread per block: the order of the additions is the sum's definition)
+__global__ void k_sah_terms(const BvhWideNode* __restrict__ wide, uint32_t nWide, const BvhBuildNode* __restrict__ nodes, float rootArea, float* __restrict__ term) {
+  const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= nWide) return;
+  const BvhWideNode w = wide[wi];
+  for (int k = 0; k < 4; k++) {
+    float t = 0.0f;
+    if (k < w.nk) {
+      const BvhBuildNode c = nodes[w.kids[k]];
+      t = (c.left < 0 ? 1.0f * (float)c.count : 1.0f) * nodeArea(c) / rootArea;
+    }
+    term[(size_t)wi * 4 + k] = t;
+  }
+}
+__global__ void k_sah_sum(const BvhWideNode* __restrict__ wide, const float* __restrict__ term, uint32_t nWide, double* __restrict__ part) {
+  const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w0 = blk * 65536u;
+  if (w0 >= nWide) return;
+  const uint32_t w1 = w0 + 65536u < nWide ? w0 + 65536u : nWide;
+  double cost = 0.0;
+  for (uint32_t wi = w0; wi < w1; wi++) {
+    const int nk = wide[wi].nk;
+    for (int k = 0; k < nk; k++) cost += (double)term[(size_t)wi * 4 + k];
+  }
+  part[blk] = cost;
+}
+
 // Device -> pageable host memory through pinned staging buffers, the host-side copies shared among a few threads (a
 // plain hipMemcpy into pageable memory runs at ~3 GB/s here; the node list of a 10 M-triangle scene is 1 GB).
 bool downloadStaged(void* dst, const void* src, size_t bytes, std::string& err) {
@@ -1459,6 +1677,115 @@ bool allocLevel(BvhDeviceArena& pool, Level& L, size_t cap, std::string& err) {
          devAllocT(pool, &L.split, cap, err) && devAllocT(pool, &L.nLeft, cap, err) && devAllocT(pool, &L.sel, cap, err) &&
          devAllocT(pool, &L.pivotHi, cap, err) && devAllocT(pool, &L.pivotLo, cap, err) &&
          devAllocT(pool, &L.child, cap, err);
+}
+
+// The collapse of this build's tree (see the kernels above): wide nodes and slots in device memory, the summary to `out`.
+bool collapseOnDevice(BvhDeviceBuild* build, BvhDeviceArena& pool, BvhWideNode** dWideOut, BvhSlot** dSlotsOut, uint32_t* nWideOut, Bvh& out, std::string& err) {
+  auto ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err = std::string("device collapse: ") + what + ": " + hipGetErrorString(e);
+    return false;
+  };
+  hipStream_t st = nullptr;
+  const dim3 blk(256);
+  auto gridFor = [](size_t m) { return dim3((unsigned)((m + 255) / 256)); };
+  const uint32_t numNodes = build->numNodes;
+  const BvhBuildNode* nodes = build->nodes;
+  const std::vector<uint32_t>& ls = build->levelStart;  // first node of every level of the binary tree, + numNodes
+  if (ls.size() < 2 || ls.back() != numNodes) {
+    err = "device collapse: no tree of this build in device memory";
+    return false;
+  }
+  uint16_t* hgt = nullptr;
+  uint32_t* sub = nullptr;
+  if (!devAllocT(pool, &hgt, numNodes, err) || !devAllocT(pool, &sub, numNodes, err)) return false;
+  for (size_t l = ls.size() - 1; l-- > 0;)
+    if (ls[l + 1] > ls[l]) hipLaunchKernelGGL(k_tree_metrics, gridFor(ls[l + 1] - ls[l]), blk, 0, st, nodes, ls[l], ls[l + 1], hgt, sub);
+  const uint32_t capWide = numNodes / 2 + 2;  // every wide node covers an interior binary node of its own (or is the lone leaf root)
+  WideTmp W;
+  uint32_t *at = nullptr, *counters = nullptr;
+  Scan scan;
+  scan.capTiles = (capWide + kScanTile - 1) / kScanTile + 1;
+  if (!devAllocT(pool, &W.src, capWide, err) || !devAllocT(pool, &W.kids, (size_t)capWide * 4, err) || !devAllocT(pool, &W.nk, capWide, err) ||
+      !devAllocT(pool, &W.depth, capWide, err) || !devAllocT(pool, &W.above, capWide, err) || !devAllocT(pool, &W.need, capWide, err) ||
+      !devAllocT(pool, &W.parent, capWide, err) || !devAllocT(pool, &W.kIdx, capWide, err) || !devAllocT(pool, &W.flags, capWide, err) ||
+      !devAllocT(pool, &W.child, (size_t)capWide * 4, err) || !devAllocT(pool, &W.nInterior, capWide, err) || !devAllocT(pool, &W.sizeAll, capWide, err) ||
+      !devAllocT(pool, &W.sizeTop, capWide, err) || !devAllocT(pool, &W.defCount, capWide, err) || !devAllocT(pool, &W.idx, capWide, err) ||
+      !devAllocT(pool, &at, (size_t)capWide + 1, err) || !devAllocT(pool, &counters, 2, err) || !devAllocT(pool, &scan.sums, scan.capTiles, err) ||
+      !devAllocT(pool, &scan.total, 1, err))
+    return false;
+  const int deferral = numNodes > 4u * kCollapseGrainDev ? 1 : 0;
+  {  // the root job
+    const uint32_t zero = 0, top = WF_TOP;
+    const int32_t minus = -1;
+    if (!ok(hipMemsetAsync(counters, 0, 8, st), "memset") || !ok(hipMemcpy(W.src, &zero, 4, hipMemcpyHostToDevice), "root") ||
+        !ok(hipMemcpy(W.depth, &zero, 4, hipMemcpyHostToDevice), "root") || !ok(hipMemcpy(W.above, &zero, 4, hipMemcpyHostToDevice), "root") ||
+        !ok(hipMemcpy(W.parent, &minus, 4, hipMemcpyHostToDevice), "root") || !ok(hipMemcpy(W.kIdx, &minus, 4, hipMemcpyHostToDevice), "root") ||
+        !ok(hipMemcpy(W.flags, &top, 4, hipMemcpyHostToDevice), "root"))
+      return false;
+  }
+  std::vector<uint32_t> wl{0, 1};  // breadth-first ranges of the wide levels: [wl[i], wl[i + 1])
+  for (;;) {
+    const uint32_t s0 = wl[wl.size() - 2], s1 = wl.back();
+    hipLaunchKernelGGL(k_wide_expand, gridFor(s1 - s0), blk, 0, st, W, s0, s1, nodes, hgt, counters, counters + 1);
+    scan.run(W.nInterior + s0, s1 - s0, at, st);
+    uint32_t nNext = 0;
+    if (!ok(hipMemcpy(&nNext, at + (s1 - s0), 4, hipMemcpyDeviceToHost), "level")) return false;
+    if (nNext == 0) break;
+    if ((size_t)s1 + nNext > capWide || wl.size() > 4096) {
+      err = "device collapse: node count out of bounds";
+      return false;
+    }
+    hipLaunchKernelGGL(k_wide_children, gridFor(s1 - s0), blk, 0, st, W, s0, s1, at, nodes, sub, deferral);
+    wl.push_back(s1 + nNext);
+  }
+  const uint32_t nWide = wl.back();
+  for (size_t l = wl.size() - 1; l-- > 0;) hipLaunchKernelGGL(k_wide_sizes, gridFor(wl[l + 1] - wl[l]), blk, 0, st, W, wl[l], wl[l + 1]);
+  uint32_t numTop = 0;
+  if (!ok(hipMemcpy(&numTop, W.sizeTop, 4, hipMemcpyDeviceToHost), "sizes")) return false;
+  uint32_t *defCountByIdx = nullptr, *defBaseByIdx = nullptr, *rankOf = nullptr, *sizeByRank = nullptr, *offByRank = nullptr;
+  if (!devAllocT(pool, &defCountByIdx, (size_t)numTop + 1, err) || !devAllocT(pool, &defBaseByIdx, (size_t)numTop + 1, err) || !devAllocT(pool, &rankOf, nWide, err) ||
+      !devAllocT(pool, &sizeByRank, (size_t)nWide + 1, err) || !devAllocT(pool, &offByRank, (size_t)nWide + 1, err))
+    return false;
+  for (size_t l = 0; l + 1 < wl.size(); l++) hipLaunchKernelGGL(k_wide_number_top, gridFor(wl[l + 1] - wl[l]), blk, 0, st, W, wl[l], wl[l + 1], defCountByIdx);
+  scan.run(defCountByIdx, numTop, defBaseByIdx, st);
+  uint32_t numDef = 0;
+  if (!ok(hipMemcpy(&numDef, defBaseByIdx + numTop, 4, hipMemcpyDeviceToHost), "deferred")) return false;
+  if (numDef > 0) {
+    hipLaunchKernelGGL(k_wide_def_rank, gridFor(nWide), blk, 0, st, W, nWide, defBaseByIdx, rankOf, sizeByRank);
+    scan.run(sizeByRank, numDef, offByRank, st);
+    hipLaunchKernelGGL(k_wide_number_def, gridFor(nWide), blk, 0, st, W, nWide, rankOf, offByRank, numTop);
+    for (size_t l = 0; l + 1 < wl.size(); l++) hipLaunchKernelGGL(k_wide_number_rest, gridFor(wl[l + 1] - wl[l]), blk, 0, st, W, wl[l], wl[l + 1]);
+  }
+  BvhWideNode* dWide = nullptr;
+  BvhSlot* dSlots = nullptr;
+  float* term = nullptr;
+  double* part = nullptr;
+  const uint32_t nBlocks = (nWide + 65535u) / 65536u;
+  if (!devAllocT(pool, &dWide, nWide, err) || !devAllocT(pool, &dSlots, nWide, err) || !devAllocT(pool, &term, (size_t)nWide * 4, err) || !devAllocT(pool, &part, nBlocks, err))
+    return false;
+  hipLaunchKernelGGL(k_wide_emit, gridFor(nWide), blk, 0, st, W, nWide, dWide, dSlots);
+  BvhBuildNode root;
+  uint32_t hc[2] = {0, 0};
+  if (!ok(hipMemcpy(&root, nodes, sizeof(root), hipMemcpyDeviceToHost), "root") || !ok(hipMemcpy(hc, counters, 8, hipMemcpyDeviceToHost), "summary")) return false;
+  const float rootArea = root.box.area();
+  double cost = 0.0;
+  if (rootArea > 0) {
+    hipLaunchKernelGGL(k_sah_terms, gridFor(nWide), blk, 0, st, dWide, nWide, nodes, rootArea, term);
+    hipLaunchKernelGGL(k_sah_sum, gridFor(nBlocks), blk, 0, st, dWide, term, nWide, part);
+    std::vector<double> hp(nBlocks);
+    if (!ok(hipMemcpy(hp.data(), part, (size_t)nBlocks * 8, hipMemcpyDeviceToHost), "cost")) return false;
+    for (double v : hp) cost += v;
+  }
+  if (!ok(hipGetLastError(), "launch") || !ok(hipDeviceSynchronize(), "synchronise")) return false;
+  out.maxDepth = hc[0];
+  out.maxStack = hc[1];
+  out.numNodes = nWide;
+  out.sahCost = (float)cost + 1.0f;  // (+ kCostTraverse)
+  *dWideOut = dWide;
+  *dSlotsOut = dSlots;
+  *nWideOut = nWide;
+  return true;
 }
 
 }  // namespace
@@ -1550,6 +1877,7 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, st, L[0], T, n);
   uint32_t nA = 1, numNodes = 1;
   int cur = 0;
+  build->levelStart.assign({0u, 1u});
   uint32_t *selHist = nullptr, *selHi = nullptr, *selLo = nullptr, *selK = nullptr;  // (allocated when a level first needs them)
   for (int level = 0; nA > 0; level++) {
     if (level > kBvhBinaryMaxDepth + 2) {
@@ -1622,6 +1950,7 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
     std::swap(rA, rB);
     std::swap(ofA, ofB);
     numNodes += 2 * numSplit;
+    if (numSplit > 0) build->levelStart.push_back(numNodes);
     nA = 2 * numSplit;
     cur ^= 1;
     if (!ok(hipGetLastError(), "launch")) return false;
@@ -1651,8 +1980,10 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
   hipLaunchKernelGGL(k_pack_nodes, gridFor(numNodes), blk, 0, st, T, numNodes, dNodes);
   if (!ok(hipDeviceSynchronize(), "pack")) return false;
   order.resize(refs ? n : 0);  // (references that never left the device: the packer reads the order there)
-  nodes.resize(numNodes);
-  if ((refs && !downloadStaged(order.data(), dOrder, (size_t)n * 4, err)) || !downloadStaged(nodes.data(), dNodes, (size_t)numNodes * sizeof(BvhBuildNode), err))
+  const bool keepHere = build->collapseHere && !refs;  // the collapse happens here too: only the root goes back (a tree was built)
+  nodes.resize(keepHere ? 1 : numNodes);
+  if ((refs && !downloadStaged(order.data(), dOrder, (size_t)n * 4, err)) ||
+      !downloadStaged(nodes.data(), dNodes, (size_t)(keepHere ? 1 : numNodes) * sizeof(BvhBuildNode), err))
     return false;
   lap("download");
   return true;
@@ -1661,7 +1992,8 @@ bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, Bi
 // The BvhPacker bdpt_set_scene plugs into buildBvh (after buildBinaryTreeOnDevice of the same build).
 bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err) {
   BvhDeviceBuild* const build = static_cast<BvhDeviceBuild*>(user);
-  if (!build || !build->nodes || !build->order || build->numRefs != in.numRefs || in.numWide == 0 || in.numWide > 0x7fffffffull) {
+  const bool collapse = in.wide == nullptr;  // the four-wide collapse has not happened yet: it happens here
+  if (!build || !build->nodes || !build->order || build->numRefs != in.numRefs || (!collapse && (in.numWide == 0 || in.numWide > 0x7fffffffull))) {
     err = "device packer: no tree of this build in device memory";
     return false;
   }
@@ -1685,7 +2017,7 @@ bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err
     err = std::string("device packer: ") + what + ": " + hipGetErrorString(e);
     return false;
   };
-  const uint32_t nWide = (uint32_t)in.numWide;
+  uint32_t nWide = (uint32_t)in.numWide;
   BvhTri* dTri = nullptr;
   uint32_t *dRefTri = nullptr, *dBlock = nullptr, *dBase = nullptr, *dPos = nullptr;
   BvhWideNode* dWide = nullptr;
@@ -1701,16 +2033,20 @@ bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err
     dTri = build->triRecs;
     dRefTri = build->refTri;
   }
-  if ((!kept && (!devAllocT(pool, &dTri, in.numTris, err) || !devAllocT(pool, &dRefTri, in.numRefs, err))) || !devAllocT(pool, &dWide, nWide, err) ||
-      !devAllocT(pool, &dSlots, nWide, err) || !devAllocT(pool, &dTmp, nWide, err) || !devAllocT(pool, &dBlock, (size_t)nWide + 1, err) ||
+  if (collapse) {
+    if (!collapseOnDevice(build, pool, &dWide, &dSlots, &nWide, out, err)) return false;
+    lap("collapse");
+  }
+  if ((!kept && (!devAllocT(pool, &dTri, in.numTris, err) || !devAllocT(pool, &dRefTri, in.numRefs, err))) || (!collapse && !devAllocT(pool, &dWide, nWide, err)) ||
+      (!collapse && !devAllocT(pool, &dSlots, nWide, err)) || !devAllocT(pool, &dTmp, nWide, err) || !devAllocT(pool, &dBlock, (size_t)nWide + 1, err) ||
       !devAllocT(pool, &dBase, (size_t)nWide + 1, err) || !devAllocT(pool, &dPos, nWide, err))
     return false;
   scan.capTiles = (nWide + kScanTile - 1) / kScanTile + 1;
   if (!devAllocT(pool, &scan.sums, scan.capTiles, err) || !devAllocT(pool, &scan.total, 1, err)) return false;
   if ((!kept && (!ok(hipMemcpy(dTri, in.triRecs, (size_t)in.numTris * sizeof(BvhTri), hipMemcpyHostToDevice), "upload") ||
                  !ok(hipMemcpy(dRefTri, in.refTri, (size_t)in.numRefs * 4, hipMemcpyHostToDevice), "upload"))) ||
-      !ok(hipMemcpy(dWide, in.wide, (size_t)nWide * sizeof(BvhWideNode), hipMemcpyHostToDevice), "upload") ||
-      !ok(hipMemcpy(dSlots, in.slots, (size_t)nWide * sizeof(BvhSlot), hipMemcpyHostToDevice), "upload"))
+      (!collapse && (!ok(hipMemcpy(dWide, in.wide, (size_t)nWide * sizeof(BvhWideNode), hipMemcpyHostToDevice), "upload") ||
+                     !ok(hipMemcpy(dSlots, in.slots, (size_t)nWide * sizeof(BvhSlot), hipMemcpyHostToDevice), "upload"))))
     return false;
   lap("pack upload");
   hipStream_t st = nullptr;

@@ -697,9 +697,19 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       outlierArea = (float)BDPT_SPLIT_OUTLIER * areas[areas.size() / 2];
     }
   }
-  std::vector<double> prio(nTris, 0.0);
-  std::vector<float> capOf(nTris, (float)BDPT_SPLIT_MAX_PER_TRI);  // splits a triangle may get at most
-  std::vector<uint8_t> state(nTris, 0);  // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
+  // (sized without being touched, filled side by side: 130 MB of one-thread value-initialisation at 10 M triangles otherwise)
+  BigVec<double> prio(nTris);
+  BigVec<float> capOf(nTris);    // splits a triangle may get at most
+  BigVec<uint8_t> state(nTris);  // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
+  BigVec<uint32_t> splits(nTris);
+  parallelFor(nTris, threads, [&](size_t t0, size_t t1, int) {
+    for (size_t t = t0; t < t1; t++) {
+      prio[t] = 0.0;
+      capOf[t] = (float)BDPT_SPLIT_MAX_PER_TRI;
+      state[t] = 0;
+      splits[t] = 0;
+    }
+  });
   const bool anySplit = budgetOpaque > 0.0f || budgetAlpha > 0.0f;
   // the whole triangle as a piece, shrunk by the clipper where it is non-opaque; false: nothing of it can be hit.
   // (Recomputed where it is needed again instead of kept: a piece is ~400 bytes and a scene may hold millions.)
@@ -743,18 +753,31 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     }
   });
   // split counts per class: the largest D with sum floor(D p_t) <= budget (integer sums: thread-count independent)
-  std::vector<uint32_t> splits(nTris, 0);
   if (anySplit && nTris) {
     for (int cls = 0; cls < 2; cls++) {
       const float budgetF = cls ? budgetAlpha : budgetOpaque;
       if (!(budgetF > 0.0f)) continue;
       uint64_t members = 0;
       double pmax = 0.0;
-      for (uint32_t t = 0; t < nTris; t++)
-        if (state[t] != 2 && (((recs[t].flags & kTriNonOpaque) != 0) == (cls == 1))) {
-          members++;
-          pmax = std::max(pmax, prio[t]);
+      {  // (a count and a maximum: what the threads find does not depend on how the range was shared out)
+        std::vector<uint64_t> pm((size_t)threads, 0);
+        std::vector<double> px((size_t)threads, 0.0);
+        parallelFor(nTris, threads, [&](size_t t0, size_t t1, int th) {
+          uint64_t m = 0;
+          double x = 0.0;
+          for (size_t t = t0; t < t1; t++)
+            if (state[t] != 2 && (((recs[t].flags & kTriNonOpaque) != 0) == (cls == 1))) {
+              m++;
+              x = std::max(x, prio[t]);
+            }
+          pm[(size_t)th] = m;
+          px[(size_t)th] = x;
+        });
+        for (int th = 0; th < threads; th++) {
+          members += pm[(size_t)th];
+          pmax = std::max(pmax, px[(size_t)th]);
         }
+      }
       const uint64_t budget = (uint64_t)((double)members * (double)budgetF);
       if (!members || !budget || !(pmax > 0.0)) continue;
       auto total = [&](double D) {

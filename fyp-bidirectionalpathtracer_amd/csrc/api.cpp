@@ -419,7 +419,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
       ~Build() { bvhDeviceBuildEnd(b); }
     } build{bvhDeviceBuildBegin(c->device, std::getenv("BDPT_HOST_COLLAPSE") == nullptr)};  // (measurement knob: the collapse on the host)
     buildSceneBvh(d, 0, -1.0f, -1.0f, std::getenv("BDPT_NO_ALPHA_CLASSIFY") == nullptr, sb, buildBinaryTreeOnDevice, build.b, &treeError, packOnDevice, makeReferencesOnDevice,
-                  std::getenv("BDPT_HOST_COLLAPSE") == nullptr);
+                  std::getenv("BDPT_HOST_COLLAPSE") == nullptr, std::getenv("BDPT_HOST_PRIORITIES") == nullptr);
     if (sb.bvh.deviceRecs) c->sceneAllocs.push_back(sb.bvh.deviceRecs);  // (the context's from here on)
     if (!treeError.empty()) {
       fail(c, "scene: " + treeError);
@@ -1176,7 +1176,8 @@ int bdpt_bvh_recs_hash(const bdpt_scene_desc* d, int device, uint64_t* out_hash,
       BvhDeviceBuild* b;
       ~Build() { bvhDeviceBuildEnd(b); }
     } build{bvhDeviceBuildBegin(device, std::getenv("BDPT_HOST_COLLAPSE") == nullptr)};
-    buildSceneBvh(d, 0, -1.0f, -1.0f, true, sb, buildBinaryTreeOnDevice, build.b, &error, packOnDevice, makeReferencesOnDevice, std::getenv("BDPT_HOST_COLLAPSE") == nullptr);
+    buildSceneBvh(d, 0, -1.0f, -1.0f, true, sb, buildBinaryTreeOnDevice, build.b, &error, packOnDevice, makeReferencesOnDevice, std::getenv("BDPT_HOST_COLLAPSE") == nullptr,
+                  std::getenv("BDPT_HOST_PRIORITIES") == nullptr);
     if (!sb.bvh.deviceRecs && !sb.bvh.recs.empty() && error.empty()) {  // (nothing to build a tree over: the host's one empty node)
       recs = sb.bvh.recs.data();
       numRecs = sb.bvh.recs.size();

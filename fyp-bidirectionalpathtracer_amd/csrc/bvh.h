@@ -167,6 +167,45 @@ struct Bvh {
 // piece where the test can pass.  `poly` is a convex polygon in the triangle's barycentric plane, vertex k =
 // (bu, bv) with P = v0 + bu e1 + bv e2, at most kBvhPolyMax vertices.  Returns false when nothing is left.
 constexpr int kBvhPolyMax = 24;
+// Opaque triangles are only split when their box is an outlier — at least BDPT_SPLIT_OUTLIER times the median box area of
+// the scene's opaque triangles — and only down to about that size (bvh_build.cpp "References"); no triangle is split more
+// than BDPT_SPLIT_MAX_PER_TRI times.
+#ifndef BDPT_SPLIT_OUTLIER
+#define BDPT_SPLIT_OUTLIER 8.0f
+#endif
+#ifndef BDPT_SPLIT_MAX_PER_TRI
+#define BDPT_SPLIT_MAX_PER_TRI 255
+#endif
+#ifdef __HIPCC__
+#define BVH_HD __host__ __device__
+#else
+#define BVH_HD
+#endif
+// Cube root of a non-negative finite double in plain arithmetic — exponent reduced to a multiple of three by bit
+// manipulation, six Newton steps on the mantissa — so that the host compiler and the device compiler produce the same bits
+// (libm's cbrt is correctly rounded on neither in general, and the two differ): the split priorities are computed with it.
+BVH_HD inline double bvhCbrt(double x) {
+  if (!(x > 0.0)) return 0.0;
+  int scaled = 0;
+  if (x < 2.2250738585072014e-308) {  // denormal: an exact scaling by 2^108 first, 2^-36 at the end
+    x *= 324518553658426726783156020576256.0;
+    scaled = -36;
+  }
+  unsigned long long u;
+  __builtin_memcpy(&u, &x, 8);
+  const int e = (int)((u >> 52) & 0x7ffull) - 1023;
+  const int q = e >= 0 ? e / 3 : -((-e + 2) / 3);
+  const int r = e - 3 * q;  // 0, 1, 2
+  u = (u & 0x000fffffffffffffull) | ((unsigned long long)(1023 + r) << 52);
+  double m;
+  __builtin_memcpy(&m, &u, 8);  // in [1, 8)
+  double t = m < 2.0 ? 1.1 : (m < 4.0 ? 1.4 : 1.8);
+  for (int i = 0; i < 6; i++) t = t - (t * t * t - m) / (3.0 * t * t);
+  const unsigned long long p = (unsigned long long)(1023 + q + scaled) << 52;
+  double s2;
+  __builtin_memcpy(&s2, &p, 8);
+  return t * s2;
+}
 // What a clipper decides with, as plain tables — for an implementation of the same decisions somewhere else (the device:
 // bvh_device.hip runs alpha_clip.cpp's clip() from these).  All pointers stay the clipper's / the scene's.
 struct BvhClipTables {
@@ -271,9 +310,12 @@ struct BvhPackInput {
 struct BvhRefInput {
   const BvhTri* triRecs;   // one per input triangle
   const BvhBox* triBox;
-  const uint32_t* splits;  // split count per triangle
-  const uint8_t* state;    // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
-  uint32_t numTris;
+  const uint32_t* splits;  // split count per triangle; null: the maker also decides what the clipper leaves of every
+  const uint8_t* state;    // triangle (state: 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped), its split
+  uint32_t numTris;        // priority and the split counts that meet the budgets below (bvh_build.cpp pass 1 + "split counts")
+  float budgetOpaque, budgetAlpha;  // extra references per triangle of the class, on average (0: the class is not split)
+  float outlierArea;                // opaque triangles below this box area are never split
+  uint32_t* numDroppedOut;          // (with splits == null) receives the number of dropped triangles
   double gridLo[3], gridExt[3];      // the scene box: the split planes are its spatial medians
   const BvhRefClipper* clipper;      // for the non-opaque triangles; may be null
 };
@@ -304,6 +346,7 @@ struct BvhBuildOptions {
   float splitBudgetAlpha = -1.0f; // < 0: the build default (BDPT_SPLIT_BUDGET_ALPHA)
   const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
   BvhTreeBuilder treeBuilder = nullptr;    // null: the host code builds the binary tree
+  bool prioritiesInRefMaker = false;       // (with a refMaker) it also classifies, rates and assigns the split counts (BvhRefInput::splits = null)
   BvhRefMaker refMaker = nullptr;          // (with a treeBuilder and a packer only) null: the host code makes the references
   bool collapseInPacker = false;           // (with refMaker, treeBuilder and packer) the packer also does the four-wide collapse (in.wide = null) and fills the summary
   BvhPacker packer = nullptr;              // (with a treeBuilder only) null: the host code quantises and packs; else Bvh::deviceRecs is the result

@@ -54,17 +54,6 @@ inline TmpNode makeTmpNode(uint32_t first, uint32_t count, uint32_t depth) {
 #ifndef BDPT_SPLIT_BUDGET_ALPHA
 #define BDPT_SPLIT_BUDGET_ALPHA 4.0f
 #endif
-// Opaque triangles are only split when their box is an outlier — at least this many times the median box area of the
-// scene's opaque triangles — and only down to about that size: the Karras-Aila priority ranks triangles against each
-// other and would spend the whole budget on an evenly tessellated scene without a reason.  Non-opaque triangles are
-// split without this test: overlapping alpha-masked cards are what their budget is for, and each piece is also
-// clipped to the texels that can pass.
-#ifndef BDPT_SPLIT_OUTLIER
-#define BDPT_SPLIT_OUTLIER 8.0f
-#endif
-#ifndef BDPT_SPLIT_MAX_PER_TRI
-#define BDPT_SPLIT_MAX_PER_TRI 255
-#endif
 constexpr int kBins = kBvhBins;
 constexpr uint32_t kStablePartitionMin = 1u << 16;  // nodes of at least this many references are partitioned stably, in parallel
 constexpr size_t kPartitionChunk = 1u << 14;
@@ -477,7 +466,7 @@ double splitPriority(const SplitGrid& G, const BvhTri& r, const Box& bx, double 
   const double dx = (double)bx.hi[0] - bx.lo[0], dy = (double)bx.hi[1] - bx.lo[1], dz = (double)bx.hi[2] - bx.lo[2];
   const double gain = 2.0 * (dx * dy + dy * dz + dz * dx) - ideal;
   if (!(gain > 0.0)) return 0.0;
-  return std::cbrt(std::ldexp(gain, h - 30));
+  return bvhCbrt(std::ldexp(gain, h - 30));
 }
 
 double polyArea2(const double (*b)[2], int n) {  // twice the area in barycentric units (the whole triangle: 1)
@@ -697,12 +686,16 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       outlierArea = (float)BDPT_SPLIT_OUTLIER * areas[areas.size() / 2];
     }
   }
+  // (a plugged-in reference maker — bdpt_set_scene: the device — may do all of this, pass 1 and the split counts, itself)
+  const BvhRefMaker refMaker = (opt.treeBuilder && opt.packer) ? opt.refMaker : nullptr;
+  const bool decideElsewhere = refMaker && opt.prioritiesInRefMaker;
+  const size_t nHere = decideElsewhere ? 0 : nTris;
   // (sized without being touched, filled side by side: 130 MB of one-thread value-initialisation at 10 M triangles otherwise)
-  BigVec<double> prio(nTris);
-  BigVec<float> capOf(nTris);    // splits a triangle may get at most
-  BigVec<uint8_t> state(nTris);  // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
-  BigVec<uint32_t> splits(nTris);
-  parallelFor(nTris, threads, [&](size_t t0, size_t t1, int) {
+  BigVec<double> prio(nHere);
+  BigVec<float> capOf(nHere);    // splits a triangle may get at most
+  BigVec<uint8_t> state(nHere);  // 0 = plain reference (triBox), 1 = shrunk by the clipper, 2 = dropped
+  BigVec<uint32_t> splits(nHere);
+  parallelFor(nHere, threads, [&](size_t t0, size_t t1, int) {
     for (size_t t = t0; t < t1; t++) {
       prio[t] = 0.0;
       capOf[t] = (float)BDPT_SPLIT_MAX_PER_TRI;
@@ -733,7 +726,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   };
   // pass 1: what the clipper leaves of every non-opaque triangle, and every triangle's priority
   constexpr size_t kRefChunk = 8192;
-  parallelChunks(nTris, threads, kRefChunk, [&](size_t, size_t t0, size_t t1) {
+  parallelChunks(nHere, threads, kRefChunk, [&](size_t, size_t t0, size_t t1) {
     for (size_t t = t0; t < t1; t++) {
       const BvhTri& r = recs[t];
       Piece pc;
@@ -753,7 +746,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
     }
   });
   // split counts per class: the largest D with sum floor(D p_t) <= budget (integer sums: thread-count independent)
-  if (anySplit && nTris) {
+  if (anySplit && nTris && !decideElsewhere) {
     for (int cls = 0; cls < 2; cls++) {
       const float budgetF = cls ? budgetAlpha : budgetOpaque;
       if (!(budgetF > 0.0f)) continue;
@@ -818,14 +811,17 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   BigVec<Ref> refs;
   BigVec<uint32_t> refTri;
   // (a plugged-in reference maker — bdpt_set_scene: the device — makes the same references in the same order and keeps them)
-  const BvhRefMaker refMaker = (opt.treeBuilder && opt.packer) ? opt.refMaker : nullptr;
-  uint32_t madeElsewhere = 0;
+  uint32_t madeElsewhere = 0, droppedElsewhere = 0;
   if (refMaker) {
     BvhRefInput in;
     in.triRecs = recs.data();
     in.triBox = triBox.data();
-    in.splits = splits.data();
-    in.state = state.data();
+    in.splits = decideElsewhere ? nullptr : splits.data();
+    in.state = decideElsewhere ? nullptr : state.data();
+    in.budgetOpaque = budgetOpaque;
+    in.budgetAlpha = budgetAlpha;
+    in.outlierArea = outlierArea;
+    in.numDroppedOut = &droppedElsewhere;
     in.numTris = nTris;
     for (int a = 0; a < 3; a++) {
       in.gridLo[a] = G.lo[a];
@@ -883,7 +879,9 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       }
     });
   }
-  {
+  if (decideElsewhere) {
+    out.numDropped = droppedElsewhere;
+  } else {
     uint32_t dropped = 0;
     for (uint32_t t = 0; t < nTris; t++) dropped += state[t] == 2 ? 1u : 0u;
     out.numDropped = dropped;

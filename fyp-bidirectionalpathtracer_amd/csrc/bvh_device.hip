@@ -1239,6 +1239,109 @@ __device__ bool devClip(const RefArgs& A, uint32_t tri, double (*poly)[2], int& 
   return n >= 3;
 }
 
+// ---- pass 1 of bvh_build.cpp and its split counts on the device (BvhRefInput::splits == null) ----
+// splitPriority
+__device__ double devSplitPriority(const RefArgs& A, const BvhTri& r, const float* lo, const float* hi, double polyShare) {
+  int axis = 0;
+  double c = 0;
+  const int h = devDominant(A, lo, hi, axis, c);
+  if (h < 0) return 0.0;
+  const double cx = (double)r.e1[1] * r.e2[2] - (double)r.e1[2] * r.e2[1], cy = (double)r.e1[2] * r.e2[0] - (double)r.e1[0] * r.e2[2],
+               cz = (double)r.e1[0] * r.e2[1] - (double)r.e1[1] * r.e2[0];
+  const double ideal = (fabs(cx) + fabs(cy) + fabs(cz)) * polyShare;
+  const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+  const double gain = 2.0 * (dx * dy + dy * dz + dz * dx) - ideal;
+  if (!(gain > 0.0)) return 0.0;
+  return bvhCbrt(ldexp(gain, h - 30));
+}
+// what the clipper leaves of every triangle, its priority and the most splits it may get
+__global__ __launch_bounds__(64) void k_prio(RefArgs A, float budgetOpaque, float budgetAlpha, float outlierArea, uint8_t* __restrict__ state,
+                                             double* __restrict__ prio, float* __restrict__ capOf, uint32_t* __restrict__ splits) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.numTris) return;
+  const BvhTri r = A.triRecs[t];
+  const BvhBox tb = A.triBox[t];
+  double b[kBvhPolyMax][2];
+  int n = 3;
+  b[0][0] = 0.0;
+  b[0][1] = 0.0;
+  b[1][0] = 1.0;
+  b[1][1] = 0.0;
+  b[2][0] = 0.0;
+  b[2][1] = 1.0;
+  float lo[3] = {tb.lo[0], tb.lo[1], tb.lo[2]}, hi[3] = {tb.hi[0], tb.hi[1], tb.hi[2]};
+  bool shrunk = false;
+  splits[t] = 0;
+  prio[t] = 0.0;
+  capOf[t] = (float)BDPT_SPLIT_MAX_PER_TRI;
+  const bool nonOpaque = (r.flags & kTriNonOpaque) != 0;
+  if (nonOpaque && A.haveClipper) {
+    if (!devClip(A, t, b, n) || n < 3) {
+      state[t] = 2;
+      return;
+    }
+    shrunk = !(n == 3 && b[0][0] == 0.0 && b[0][1] == 0.0 && b[1][0] == 1.0 && b[1][1] == 0.0 && b[2][0] == 0.0 && b[2][1] == 1.0);
+    if (shrunk) devPolyBoxIn(r, b, n, tb.lo, tb.hi, lo, hi);
+  }
+  state[t] = shrunk ? 1 : 0;
+  const float budget = nonOpaque ? budgetAlpha : budgetOpaque;
+  const float area = areaOf(lo, hi);
+  if (budget > 0.0f && (nonOpaque || area >= outlierArea)) {
+    prio[t] = devSplitPriority(A, r, lo, hi, shrunk ? devPolyArea2(b, n) : 1.0);
+    if (!nonOpaque && outlierArea > 0.0f) {
+      const float f = floorf((float)BDPT_SPLIT_OUTLIER * area / outlierArea);
+      capOf[t] = f < (float)BDPT_SPLIT_MAX_PER_TRI ? f : (float)BDPT_SPLIT_MAX_PER_TRI;  // std::min(MAX, f)
+    }
+  }
+}
+BDV bool inClass(const RefArgs& A, const uint8_t* state, uint32_t t, int cls) {
+  return state[t] != 2 && (((A.triRecs[t].flags & kTriNonOpaque) != 0) == (cls == 1));
+}
+// members of a class and their largest priority (non-negative doubles order like their bit patterns)
+__global__ void k_class_stats(RefArgs A, const uint8_t* __restrict__ state, const double* __restrict__ prio, int cls, unsigned long long* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = t < A.numTris && inClass(A, state, t, cls);
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63u) == 0u && m) atomicAdd(&out[0], (unsigned long long)__popcll(m));
+  if (in) atomicMax(&out[1], (unsigned long long)__double_as_longlong(prio[t]));
+}
+// sum over the class of min(floor(D p), cap): integers, so the order of the additions does not matter
+__global__ __launch_bounds__(256) void k_split_total(RefArgs A, const uint8_t* __restrict__ state, const double* __restrict__ prio, const float* __restrict__ capOf,
+                                                     int cls, double D, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long s[256];
+  unsigned long long acc = 0;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < A.numTris; t += gridDim.x * blockDim.x)
+    if (inClass(A, state, t, cls)) {
+      const double v = floor(D * prio[t]), c = (double)capOf[t];
+      acc += (unsigned long long)(c < v ? c : v);
+    }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && s[0]) atomicAdd(out, s[0]);
+}
+__global__ void k_split_assign(RefArgs A, const uint8_t* __restrict__ state, const double* __restrict__ prio, const float* __restrict__ capOf, int cls, double D,
+                               uint32_t* __restrict__ splits) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.numTris || !inClass(A, state, t, cls)) return;
+  const double v = floor(D * prio[t]), c = (double)capOf[t];
+  splits[t] = (uint32_t)(c < v ? c : v);
+}
+// dropped triangles, reference slots (splits + 1 per kept triangle), triangles that need the reference kernel
+__global__ void k_ref_summary(uint32_t numTris, const uint8_t* __restrict__ state, const uint32_t* __restrict__ splits, unsigned long long* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= numTris) return;
+  if (state[t] == 2) {
+    atomicAdd(&out[0], 1ull);
+    return;
+  }
+  atomicAdd(&out[1], (unsigned long long)splits[t] + 1ull);
+  if (splits[t] != 0 || state[t] != 0) atomicAdd(&out[2], 1ull);
+}
+
 // upper bounds: a triangle makes at most splits + 1 references and stacks at most `splits` pieces
 __global__ void k_ref_caps(RefArgs A, uint32_t* __restrict__ capRefs, uint32_t* __restrict__ capStack) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2136,7 +2239,9 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
   BvhBox* dTriBox = nullptr;
   uint32_t* dSplits = nullptr;
   uint8_t* dState = nullptr;
-  if (!upload(&dTriBox, in.triBox, nT) || !upload(&dSplits, in.splits, nT) || !upload(&dState, in.state, nT)) return false;
+  const bool decideHere = in.splits == nullptr;  // classification, priorities and split counts happen here too
+  if (!upload(&dTriBox, in.triBox, nT)) return false;
+  if (decideHere ? (!devAllocT(pool, &dSplits, nT, err) || !devAllocT(pool, &dState, nT, err)) : (!upload(&dSplits, in.splits, nT) || !upload(&dState, in.state, nT))) return false;
   A.triBox = dTriBox;
   A.splits = dSplits;
   A.state = dState;
@@ -2177,6 +2282,53 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
   lap("refs upload");
   hipStream_t st = nullptr;
   const dim3 blk(256), grid((nT + 255) / 256);
+  unsigned long long* dSum = nullptr;
+  if (!devAllocT(pool, &dSum, 4, err)) return false;
+  if (decideHere) {
+    double* prio = nullptr;
+    float* capOf = nullptr;
+    if (!devAllocT(pool, &prio, nT, err) || !devAllocT(pool, &capOf, nT, err)) return false;
+    hipLaunchKernelGGL(k_prio, dim3((nT + 63) / 64), dim3(64), 0, st, A, in.budgetOpaque, in.budgetAlpha, in.outlierArea, dState, prio, capOf, dSplits);
+    for (int cls = 0; cls < 2; cls++) {  // split counts per class: the largest D with sum min(floor(D p), cap) <= budget
+      const float budgetF = cls ? in.budgetAlpha : in.budgetOpaque;
+      if (!(budgetF > 0.0f)) continue;
+      unsigned long long stats[2] = {0, 0};
+      if (!ok(hipMemsetAsync(dSum, 0, 16, st), "memset")) return false;
+      hipLaunchKernelGGL(k_class_stats, grid, blk, 0, st, A, dState, prio, cls, dSum);
+      if (!ok(hipMemcpy(stats, dSum, 16, hipMemcpyDeviceToHost), "class")) return false;
+      const uint64_t members = stats[0];
+      double pmax;
+      std::memcpy(&pmax, &stats[1], 8);
+      const uint64_t budget = (uint64_t)((double)members * (double)budgetF);
+      if (!members || !budget || !(pmax > 0.0)) continue;
+      bool failed = false;
+      auto total = [&](double D) -> uint64_t {
+        unsigned long long v = 0;
+        if (hipMemsetAsync(dSum, 0, 8, st) != hipSuccess) failed = true;
+        hipLaunchKernelGGL(k_split_total, dim3(1024), blk, 0, st, A, dState, prio, capOf, cls, D, dSum);
+        if (hipMemcpy(&v, dSum, 8, hipMemcpyDeviceToHost) != hipSuccess) failed = true;
+        return v;
+      };
+      double dLo = 0.0, dHi = ((double)BDPT_SPLIT_MAX_PER_TRI + 1.0) / pmax;  // at dHi the largest priority is capped
+      if (total(dHi) <= budget) {
+        dLo = dHi;
+      } else {
+        for (int it = 0; it < 40; it++) {
+          const double mid = 0.5 * (dLo + dHi);
+          if (total(mid) <= budget)
+            dLo = mid;
+          else
+            dHi = mid;
+        }
+      }
+      if (failed) {
+        err = "device reference maker: split counts failed";
+        return false;
+      }
+      hipLaunchKernelGGL(k_split_assign, grid, blk, 0, st, A, dState, prio, capOf, cls, dLo, dSplits);
+    }
+    lap("refs decide");
+  }
   uint32_t *capRefs = nullptr, *capStack = nullptr, *slotAt = nullptr, *stackAt = nullptr, *made = nullptr, *refAt = nullptr;
   Scan scan;
   scan.capTiles = (nT + kScanTile - 1) / kScanTile + 1;
@@ -2191,15 +2343,16 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
   if (!ok(hipMemcpy(&totalSlots, slotAt + nT, 4, hipMemcpyDeviceToHost), "caps") || !ok(hipMemcpy(&totalStack, stackAt + nT, 4, hipMemcpyDeviceToHost), "caps")) return false;
   bool plain = true;  // nothing to split, nothing shrunk
   {  // (the scans are 32-bit: make sure they did not wrap)
-    uint64_t s = 0;
-    for (uint32_t t = 0; t < nT; t++) {
-      s += in.state[t] == 2 ? 0u : (uint64_t)in.splits[t] + 1u;
-      plain = plain && (in.state[t] == 2 || (in.splits[t] == 0 && in.state[t] == 0));
-    }
-    if (s != totalSlots || s >= 0x7fffffffull) {
+    unsigned long long sum[3] = {0, 0, 0};
+    if (!ok(hipMemsetAsync(dSum, 0, 24, st), "memset")) return false;
+    hipLaunchKernelGGL(k_ref_summary, grid, blk, 0, st, nT, A.state, A.splits, dSum);
+    if (!ok(hipMemcpy(sum, dSum, 24, hipMemcpyDeviceToHost), "summary")) return false;
+    if (sum[1] != totalSlots || sum[1] >= 0x7fffffffull) {
       err = "bvh does not fit the packed record format (2^31 records)";
       return false;
     }
+    plain = sum[2] == 0;
+    if (in.numDroppedOut) *in.numDroppedOut = (uint32_t)sum[0];
   }
   BvhBox* boxes = nullptr;
   DevPiece* stacks = nullptr;

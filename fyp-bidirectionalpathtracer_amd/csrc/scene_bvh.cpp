@@ -35,7 +35,7 @@ void hostFor(size_t n, int threads, const F& f) {
 }  // namespace
 
 void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, bool classify, SceneBvh& out,
-                   BvhTreeBuilder treeBuilder, void* treeBuilderUser, std::string* error, BvhPacker packer, BvhRefMaker refMaker, bool collapseInPacker) {
+                   BvhTreeBuilder treeBuilder, void* treeBuilderUser, std::string* error, BvhPacker packer, BvhRefMaker refMaker, bool collapseInPacker, bool prioritiesInRefMaker) {
   if (threads <= 0) threads = bvhBuildThreads();
   const bool verbose = std::getenv("BDPT_BUILD_VERBOSE") != nullptr;
   auto tLap = std::chrono::steady_clock::now();
@@ -93,6 +93,7 @@ void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, flo
   opt.packer = packer;
   opt.refMaker = refMaker;
   opt.collapseInPacker = collapseInPacker;
+  opt.prioritiesInRefMaker = prioritiesInRefMaker;
   opt.error = error;
   lap("aux");
   buildBvh(d->positions, d->indices, n, out.triFlags.data(), out.bvh, opt, out.triAux.data());

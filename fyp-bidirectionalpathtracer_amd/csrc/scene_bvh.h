@@ -27,6 +27,6 @@ struct SceneBvh {
 // device implementations; when one fails *error says why (no nodes / no device records then).
 void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, float splitBudgetAlpha, bool classify, SceneBvh& out,
                    BvhTreeBuilder treeBuilder = nullptr, void* treeBuilderUser = nullptr, std::string* error = nullptr, BvhPacker packer = nullptr,
-                   BvhRefMaker refMaker = nullptr, bool collapseInPacker = false);
+                   BvhRefMaker refMaker = nullptr, bool collapseInPacker = false, bool prioritiesInRefMaker = false);
 
 }  // namespace bdpt

@@ -4,11 +4,12 @@
 // Falcor/Framework/Source/Raytracing/RtModel.cpp:181-254 and RtScene.cpp:220-308.  Four stages of buildBvh
 // (bvh_build.cpp) are plugged in from here by bdpt_set_scene, each producing the host code's result bit for bit (the host
 // code stays as what the CPU tests run and as the definition; tests/test_gpu_configs.py compares the two):
-//   makeReferencesOnDevice   the references: whole piece, clipped by the alpha clipper, split, every piece clipped again
+//   makeReferencesOnDevice   classification, split priorities and split counts; then the references: whole piece, clipped by
+//                            the alpha clipper, split, every piece clipped again
 //   buildBinaryTreeOnDevice  the binned-SAH binary tree over them
 //   packOnDevice             the four-wide collapse (collapseOnDevice), child boxes quantised, nodes + leaf triangles packed
 //                            into the record array the kernels traverse
-// (on the host: triangle records and split priorities, before all of it).
+// (on the host: the triangle records, before all of it).
 //
 // The tree is level-synchronous: every level is a handful of launches —
 //   bounds   node box + centroid box per active node ("slot")   (ordered-uint atomics; a block first reduces the

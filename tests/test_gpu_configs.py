@@ -366,8 +366,8 @@ def test_execute_at_lower_depth_than_the_context_is_sized_for(pkg, ob):
 
 def test_device_builder_builds_what_the_host_builder_builds(pkg, monkeypatch):
     """bdpt_set_scene builds the acceleration structure on the device (csrc/bvh_device.hip) — the reference's BLAS / TLAS
-    builds are GPU work too (RtModel.cpp:181-254, RtScene.cpp:220-308): the references (alpha-clipped, pre-split), the
-    binned-SAH binary tree, the four-wide collapse and the quantised, packed records; the host keeps the split priorities.  Every stage has to produce the host builder's result bit for bit:
+    builds are GPU work too (RtModel.cpp:181-254, RtScene.cpp:220-308): classification and split priorities, the references (alpha-clipped, pre-split), the
+    binned-SAH binary tree, the four-wide collapse and the quantised, packed records.  Every stage has to produce the host builder's result bit for bit:
       * bdpt_bvh_build_hash with the device tree builder plugged in (bdpt_test_tree_builder) = with the host one: nodes,
         leaf-ordered triangles, reference boxes, packed records, depth / stack / SAH cost;
       * bdpt_bvh_recs_hash of the whole device pipeline = of the host pipeline: every packed record.

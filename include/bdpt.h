@@ -346,8 +346,8 @@ int bdpt_bvh_build_hash(const bdpt_scene_desc* scene, int threads, uint64_t* out
  * two build the same tree bit for bit; the GPU tests compare bdpt_bvh_build_hash under both settings. */
 int bdpt_test_tree_builder(int device);
 /* Test hook: FNV-1a over the packed records (every node, every leaf triangle) and the summary of a scene's acceleration
- * structure.  device < 0: everything by the host code; device >= 0: as bdpt_set_scene builds it — binary tree, quantisation
- * and packing on that device — with the records read back.  The two must agree; info->reserved = number of records. */
+ * structure.  device < 0: everything by the host code; device >= 0: as bdpt_set_scene builds it — classification and split
+ * priorities, references, binary tree, four-wide collapse, quantisation and packing on that device — with the records read back.  The two must agree; info->reserved = number of records. */
 int bdpt_bvh_recs_hash(const bdpt_scene_desc* scene, int device, uint64_t* out_hash, bdpt_bvh_info* out_info);
 
 /* Host-only test hooks: the acceleration structure exactly as bdpt_set_scene builds it (traversal flags, alpha

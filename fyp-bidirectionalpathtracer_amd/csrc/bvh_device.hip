@@ -1303,8 +1303,15 @@ __global__ void k_class_stats(RefArgs A, const uint8_t* __restrict__ state, cons
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = t < A.numTris && inClass(A, state, t, cls);
   const unsigned long long m = __ballot(in);
-  if ((threadIdx.x & 63u) == 0u && m) atomicAdd(&out[0], (unsigned long long)__popcll(m));
-  if (in) atomicMax(&out[1], (unsigned long long)__double_as_longlong(prio[t]));
+  unsigned long long best = in ? (unsigned long long)__double_as_longlong(prio[t]) : 0ull;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63u) == 0u && m) {
+    atomicAdd(&out[0], (unsigned long long)__popcll(m));
+    if (best) atomicMax(&out[1], best);
+  }
 }
 // sum over the class of min(floor(D p), cap): integers, so the order of the additions does not matter
 __global__ __launch_bounds__(256) void k_split_total(RefArgs A, const uint8_t* __restrict__ state, const double* __restrict__ prio, const float* __restrict__ capOf,
@@ -1334,13 +1341,25 @@ __global__ void k_split_assign(RefArgs A, const uint8_t* __restrict__ state, con
 // dropped triangles, reference slots (splits + 1 per kept triangle), triangles that need the reference kernel
 __global__ void k_ref_summary(uint32_t numTris, const uint8_t* __restrict__ state, const uint32_t* __restrict__ splits, unsigned long long* __restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= numTris) return;
-  if (state[t] == 2) {
-    atomicAdd(&out[0], 1ull);
-    return;
+  unsigned long long dropped = 0, slots = 0, work = 0;
+  if (t < numTris) {
+    if (state[t] == 2) {
+      dropped = 1;
+    } else {
+      slots = (unsigned long long)splits[t] + 1ull;
+      work = (splits[t] != 0 || state[t] != 0) ? 1ull : 0ull;
+    }
   }
-  atomicAdd(&out[1], (unsigned long long)splits[t] + 1ull);
-  if (splits[t] != 0 || state[t] != 0) atomicAdd(&out[2], 1ull);
+  for (int off = 32; off > 0; off >>= 1) {  // (one atomic per wave and counter: ten million lanes on three words otherwise)
+    dropped += __shfl_xor(dropped, off);
+    slots += __shfl_xor(slots, off);
+    work += __shfl_xor(work, off);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    if (dropped) atomicAdd(&out[0], dropped);
+    if (slots) atomicAdd(&out[1], slots);
+    if (work) atomicAdd(&out[2], work);
+  }
 }
 
 // upper bounds: a triangle makes at most splits + 1 references and stacks at most `splits` pieces
@@ -1687,17 +1706,33 @@ __global__ void k_sah_terms(const BvhWideNode* __restrict__ wide, uint32_t nWide
     term[(size_t)wi * 4 + k] = t;
   }
 }
-__global__ void k_sah_sum(const BvhWideNode* __restrict__ wide, const float* __restrict__ term, uint32_t nWide, double* __restrict__ part) {
-  const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+// (one wave per block of nodes: all lanes fetch the next 256 terms into LDS, lane 0 adds them in order — a term of a child
+// slot that does not exist is +0 and adding it changes nothing, so the four slots of every node are simply added)
+__global__ __launch_bounds__(64) void k_sah_sum(const float* __restrict__ term, uint32_t nWide, double* __restrict__ part) {
+  __shared__ float4 s[64];
+  const uint32_t blk = blockIdx.x, lane = threadIdx.x;
   const uint32_t w0 = blk * 65536u;
   if (w0 >= nWide) return;
   const uint32_t w1 = w0 + 65536u < nWide ? w0 + 65536u : nWide;
+  const float4* t4 = reinterpret_cast<const float4*>(term);
   double cost = 0.0;
-  for (uint32_t wi = w0; wi < w1; wi++) {
-    const int nk = wide[wi].nk;
-    for (int k = 0; k < nk; k++) cost += (double)term[(size_t)wi * 4 + k];
+  for (uint32_t base = w0; base < w1; base += 64) {
+    const uint32_t wi = base + lane;
+    s[lane] = wi < w1 ? t4[wi] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+    if (lane == 0) {
+      const uint32_t n = w1 - base < 64u ? w1 - base : 64u;
+      for (uint32_t i = 0; i < n; i++) {
+        const float4 v = s[i];
+        cost += (double)v.x;
+        cost += (double)v.y;
+        cost += (double)v.z;
+        cost += (double)v.w;
+      }
+    }
+    __syncthreads();
   }
-  part[blk] = cost;
+  if (lane == 0) part[blk] = cost;
 }
 
 // Device -> pageable host memory through pinned staging buffers, the host-side copies shared among a few threads (a
@@ -1877,7 +1912,7 @@ bool collapseOnDevice(BvhDeviceBuild* build, BvhDeviceArena& pool, BvhWideNode**
   double cost = 0.0;
   if (rootArea > 0) {
     hipLaunchKernelGGL(k_sah_terms, gridFor(nWide), blk, 0, st, dWide, nWide, nodes, rootArea, term);
-    hipLaunchKernelGGL(k_sah_sum, gridFor(nBlocks), blk, 0, st, dWide, term, nWide, part);
+    hipLaunchKernelGGL(k_sah_sum, dim3(nBlocks), dim3(64), 0, st, term, nWide, part);
     std::vector<double> hp(nBlocks);
     if (!ok(hipMemcpy(hp.data(), part, (size_t)nBlocks * 8, hipMemcpyDeviceToHost), "cost")) return false;
     for (double v : hp) cost += v;

@@ -237,6 +237,8 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    if "RANK" in os.environ:  # said before torch is imported: a rank that is ended because a peer failed has still shown it ran
+        print("bench.py: rank %s of %s started" % (os.environ["RANK"], os.environ.get("WORLD_SIZE", "?")), file=sys.stderr, flush=True)
 
     import torch
     import __graft_entry__ as ge

@@ -103,7 +103,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect",
         "nodeVisitsClosest", "triTestsClosest", "nodeVisitsShadow", "triTestsShadow", "pixelsValid",
-        "splatsLanded", "raysConnectLazy", "alphaTestsClosest", "alphaTestsShadow")]
+        "splatsLanded", "raysConnectLazy", "alphaTestsClosest", "alphaTestsShadow", "hintedNee", "hintedSplat")]
 
     def total_rays(self):
         return (self.raysPrimary + self.raysEyeExtend + self.raysLightExtend + self.raysNee + self.raysSplat +

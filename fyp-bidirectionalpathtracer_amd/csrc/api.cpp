@@ -88,6 +88,10 @@ struct bdpt_ctx {
   // the splat and NEE generators run beside the connection generator on this stream (fork/join with events; capture-safe)
   hipStream_t walkStream = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr, evSplat = nullptr;
+  // occluder hints (kernels.hip "Occluder hints"): the primary-visibility triangle of every frame pixel, written by this
+  // context's G-buffer pass and read by its light-tracing generator.  BDPT_NO_HINTS (environment) switches both kinds off.
+  uint32_t* hintPix = nullptr;
+  bool hints = true;
 };
 
 namespace {
@@ -550,6 +554,23 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
   }
   if ((rc = devUpload(c, c->sceneAllocs, &c->S.sc, &sc, 1))) return rc;
   c->S.numLights = d->numLights;
+  // Occluder hints of next-event rays: one cube map of nearest triangles per light (directional lights: empty), traced
+  // here once; the primary-visibility hints of an earlier scene index records that are gone.
+  c->hints = std::getenv("BDPT_NO_HINTS") == nullptr;
+  if (c->hints) {
+    uint32_t res = 512;
+    if (const char* e = std::getenv("BDPT_LIGHT_MAP_RES")) res = (uint32_t)std::max(0, std::min(2048, std::atoi(e)));
+    if (res) {
+      uint32_t* maps = nullptr;
+      if ((rc = devAlloc(c, c->sceneAllocs, &maps, (size_t)6 * res * res * d->numLights))) return rc;
+      launchLightMaps(c->S, maps, res, nullptr);
+      HIPCHK(c, hipDeviceSynchronize());
+      c->S.lightMap = maps;
+      c->S.lightMapRes = res;
+    }
+  }
+  if (c->hintPix) HIPCHK(c, hipMemset(c->hintPix, 0xFF, (size_t)c->W * c->H * sizeof(uint32_t)));
+  lap("light maps");
   c->haveScene = true;
   return BDPT_OK;
 }
@@ -764,6 +785,11 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyCursor, np))) return rc;
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyRay, (size_t)std::max<uint32_t>(batch, 1) * np))) return rc;
   }
+  c->hintPix = nullptr;
+  if (std::getenv("BDPT_NO_HINTS") == nullptr) {
+    if ((rc = devAlloc(c, c->frameAllocs, &c->hintPix, (size_t)width * height))) return rc;
+    HIPCHK(c, hipMemset(c->hintPix, 0xFF, (size_t)width * height * sizeof(uint32_t)));
+  }
   const size_t splatU64 = (size_t)c->sl.owners * c->sl.chunkRows * width * 4;
   if ((rc = devAlloc(c, c->frameAllocs, &c->ownSplat, splatU64))) return rc;
   c->splat = c->ownSplat;
@@ -802,6 +828,7 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
   G.pix = c->P.pix;
   G.gb = *out;
   G.counters = nullptr;  // primary rays are tallied analytically by bdpt_get_counters (one per tile pixel)
+  G.hintPix = c->hintPix;
   launchGBuffer(c->S, G, st);
   HIPCHK(c, hipGetLastError());
   c->lastStream = st;
@@ -857,6 +884,7 @@ int frameSetup(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, float*
   F.envW = c->env.width;
   F.envH = c->env.height;
   for (int k = 0; k < 3; k++) F.envColor[k] = c->env.color[k];
+  F.hintPix = c->hintPix;
   return BDPT_OK;
 }
 
@@ -1230,16 +1258,18 @@ int bdpt_get_counters(bdpt_ctx* c, bdpt_counters* out) {
   HIPCHK(c, hipStreamSynchronize(c->lastStream));
   DevCounters h;
   HIPCHK(c, hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
-  static_assert(sizeof(bdpt_counters) == 15 * sizeof(uint64_t), "counter fields");
+  static_assert(sizeof(bdpt_counters) == 17 * sizeof(uint64_t), "counter fields");
   uint64_t* o = reinterpret_cast<uint64_t*>(out);
   for (int f = 0; f < 13; f++) {
     o[f] = 0;
     for (uint32_t sh = 0; sh < kCounterShards; sh++) o[f] += h.v[sh][f];
   }
-  out->alphaTestsClosest = out->alphaTestsShadow = 0;
+  out->alphaTestsClosest = out->alphaTestsShadow = out->hintedNee = out->hintedSplat = 0;
   for (uint32_t sh = 0; sh < kCounterShards; sh++) {
     out->alphaTestsClosest += h.v[sh][C_ALPHA_CLOSEST];
     out->alphaTestsShadow += h.v[sh][C_ALPHA_SHADOW];
+    out->hintedNee += h.v[sh][C_HINT_NEE];
+    out->hintedSplat += h.v[sh][C_HINT_SPLAT];
   }
   out->raysPrimary = (uint64_t)c->P.Np;  // GBufferRayGen traces exactly one ray per tile pixel
   return BDPT_OK;

@@ -13,10 +13,17 @@
 
 namespace bdpt {
 #define BD __device__ __forceinline__
+// First statement of every kernel built on "one workgroup = one wave" (kernels.hip, above launchWave): launched in any
+// other shape it does nothing, instead of indexing its one-wave LDS rows with threadIdx.x >= 64.
+#define BDPT_ONE_WAVE_PER_GROUP()               \
+  do {                                          \
+    if (blockDim.x != (unsigned)kWave) return;  \
+  } while (0)
 
 struct Hit {
   int prim;
   float t, u, v;
+  uint32_t rec;  // record index of the triangle hit (closest-hit queries; only the kernels that ask for it keep it alive)
 };
 
 constexpr int kDone = (int)0x80000000;  // traversal cursor value: stack exhausted
@@ -47,6 +54,7 @@ BD void travInit(TravState& T, f3 o, f3 d, float tmin, float tmax) {
   T.best.t = tmax;
   T.best.u = 0.0f;
   T.best.v = 0.0f;
+  T.best.rec = 0xFFFFFFFFu;
   // A ray with a NaN anywhere, or with an empty (tmin, tmax) interval, cannot satisfy
   // tmin < t < tmax for any triangle (the brute-force scan agrees): it misses without traversal.
   const bool finite = (o.x == o.x) && (o.y == o.y) && (o.z == o.z) && (d.x == d.x) && (d.y == d.y) && (d.z == d.z);
@@ -210,7 +218,7 @@ BD void nodeStep(const SceneDev& S, TravState& T, int* stk) {
 // whether the triangle is a candidate hit; the any-hit alpha test (IgnoreHit) may still reject it; triCommit records it.
 struct TriCand {
   float t, u, v;
-  uint32_t prim, flags, aux;
+  uint32_t prim, flags, aux, rec;
   bool ok, last;
 };
 template <int MODE>
@@ -222,6 +230,7 @@ BD TriCand triGeom(const TravState& T, const float4 a, const float4 b, const flo
   k.aux = __float_as_uint(c.w);
   k.last = (k.flags & 4u) != 0;  // kTriLastOfLeaf
   k.ok = false;
+  k.rec = 0u;
   k.t = k.u = k.v = 0.0f;
   const f3 pvec = cross(T.d, e2);
   const float det = dot(e1, pvec);
@@ -258,12 +267,14 @@ BD bool triCommit(TravState& T, const TriCand& k) {
     T.best.t = k.t;
     T.best.u = k.u;
     T.best.v = k.v;
+    T.best.rec = k.rec;
   }
   return false;
 }
 template <int MODE, bool COUNT>
-BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, bool& last, uint32_t& nAlpha) {
-  const TriCand k = triGeom<MODE>(T, a, b, c);
+BD bool triStep(const SceneDev& S, TravState& T, const float4 a, const float4 b, const float4 c, uint32_t rec, bool& last, uint32_t& nAlpha) {
+  TriCand k = triGeom<MODE>(T, a, b, c);
+  k.rec = rec;
   last = k.last;
   if (!k.ok) return false;
   if (COUNT && (k.flags & 1u) && (MODE == 2 || k.t <= T.best.t)) nAlpha++;
@@ -286,13 +297,15 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris, uint32_t& nAl
   const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2], a1 = tp[kRecF4], b1 = tp[kRecF4 + 1], c1 = tp[kRecF4 + 2];
   if (COUNT) nTris++;
   TriCand k0 = triGeom<MODE>(T, a0, b0, c0), k1;
+  k0.rec = (uint32_t)~T.cur;
   k1.ok = false;
   k1.last = true;
   k1.t = k1.u = k1.v = 0.0f;
-  k1.prim = k1.flags = k1.aux = 0u;
+  k1.prim = k1.flags = k1.aux = k1.rec = 0u;
   if (!k0.last) {
     if (COUNT) nTris++;
     k1 = triGeom<MODE>(T, a1, b1, c1);
+    k1.rec = (uint32_t)~T.cur + 1u;
   }
   // (closest hit: a candidate beyond the hit already held cannot be committed whatever its alpha test says: not run)
   const bool n0 = k0.ok && (k0.flags & 1u) && (MODE == 2 || k0.t <= T.best.t);
@@ -308,11 +321,13 @@ BD bool leafStep(const SceneDev& S, TravState& T, uint32_t& nTris, uint32_t& nAl
   if (k1.ok && triCommit<MODE>(T, k1)) return true;
   bool last = k1.last;
   tp += 2 * kRecF4;
+  uint32_t rec = (uint32_t)~T.cur + 2u;
   while (!last) {  // leaves of more than two triangles (builder knob BDPT_LEAF_MAX)
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) nTris++;
-    if (triStep<MODE, COUNT>(S, T, a, b, c, last, nAlpha)) return true;
+    if (triStep<MODE, COUNT>(S, T, a, b, c, rec, last, nAlpha)) return true;
     tp += kRecF4;
+    rec++;
   }
   return false;
 }
@@ -333,6 +348,27 @@ BD Hit traverse(const SceneDev& S, f3 o, f3 d, float tmin, float tmax, int* stk,
     T.cur = travPop<kStackEntries>(S, T, stk);
   }
   return T.best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occluder hints.  An any-hit answer is an OR over the scene's triangles, so testing ONE triangle of the scene before
+// (instead of) the traversal cannot change it: if that triangle occludes the segment the query is answered, if not the
+// ray is traced as before.  The test is the leaf's own — triGeom<2> on the packed record, then the any-hit alpha test —
+// so a triangle decides here exactly as it decides inside the traversal.  Where hints come from: kernels.hip
+// ("Occluder hints": the primary-visibility triangle of a light-tracing ray's target pixel, the light's cube map of
+// nearest triangles for a next-event ray).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kNoHint = 0xFFFFFFFFu;
+BD bool recOccludes(const SceneDev& S, uint32_t rec, f3 o, f3 d, float tmin, float tmax) {
+  if (rec >= S.numRecs) return false;  // kNoHint, or a stale word: never read outside the array
+  TravState T;
+  travInit(T, o, d, tmin, tmax);
+  if (T.cur == kDone) return false;  // (a ray the traversal retires at entry misses: no triangle may say otherwise)
+  const float4* tp = reinterpret_cast<const float4*>(S.recs) + (size_t)rec * kRecF4;
+  const TriCand k = triGeom<2>(T, tp[0], tp[1], tp[2]);
+  if (!k.ok) return false;
+  if ((k.flags & 1u) && alphaTestFails(S, k.aux, k.u, k.v)) return false;
+  return true;
 }
 
 BD void addCount(DevCounters* c, int idx, uint32_t n) {
@@ -383,6 +419,7 @@ struct RayQueue {         // SoA planes, stride = cap: ox oy oz dx dy dz tmax
 template <bool COUNT>
 __global__ __launch_bounds__(kWave) void trace_shadow_kernel(SceneDev S, RayQueue Q, uint8_t* __restrict__ vis, DevCounters* counters,
                                                              float shadowTmin) {
+  BDPT_ONE_WAVE_PER_GROUP();
   __shared__ int s_stack[kStackLds * kWave];
   int* stk = s_stack + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63u);

@@ -79,16 +79,21 @@ struct SceneDev {
   const float4* alphaRecs;  // 4 per non-opaque triangle (device_scene.hpp alphaTestFails), indexed by BvhTri::aux
   int* stackOvf;            // overflow rows of the persistent kernels' stacks: [entry - kStackLds][workgroup * 64 + lane]
   uint32_t stackOvfStride;  // lanes per row
+  // occluder hints for next-event rays (kernels.hip "Occluder hints"): per point / spot light a cube map of the record
+  // index of the nearest triangle in each direction from the light; [light][face][v][u], kNoHint where nothing is seen
+  const uint32_t* lightMap;
+  uint32_t lightMapRes;     // texels per cube-face edge (0: no maps)
 };
 
-struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; one 128-byte line per shard
-  unsigned long long v[kCounterShards][16];
+struct DevCounters {  // [shard][field]; fields mirror bdpt_counters; two 128-byte lines per shard
+  unsigned long long v[kCounterShards][32];
 };
 enum : int {
   C_RAYS_PRIMARY = 0, C_RAYS_EYE, C_RAYS_LIGHT, C_RAYS_NEE, C_RAYS_SPLAT, C_RAYS_CONNECT,
   C_NODE_CLOSEST, C_TRI_CLOSEST, C_NODE_SHADOW, C_TRI_SHADOW, C_PIX_VALID, C_SPLATS, C_RAYS_LAZY,
   C_STACK_MAX,  // deepest any-hit traversal stack seen (a maximum, not a sum; with BDPT_PARAM_COUNTERS)
-  C_ALPHA_CLOSEST, C_ALPHA_SHADOW  // any-hit alpha tests run by closest-hit / any-hit queries (with BDPT_PARAM_COUNTERS)
+  C_ALPHA_CLOSEST, C_ALPHA_SHADOW,  // any-hit alpha tests run by closest-hit / any-hit queries (with BDPT_PARAM_COUNTERS)
+  C_HINT_NEE, C_HINT_SPLAT          // any-hit queries answered "occluded" by their occluder hint (not part of C_RAYS_*)
 };
 
 // Number of connection pairs the reference defines for depth D (cameraLength <= totalLength,
@@ -160,6 +165,9 @@ struct FrameDev {
   const float* envMap;
   uint32_t envW, envH;
   float envColor[3];
+  // occluder hints for light-tracing rays: record index of the triangle the primary ray of each FRAME pixel hit
+  // (written by the context's own G-buffer pass; kNoHint where it has not run or saw nothing); NULL = no hints
+  const uint32_t* hintPix;
 };
 
 struct GBufferDev {
@@ -169,6 +177,7 @@ struct GBufferDev {
   const uint32_t* pix;  // the tile's pixels (PathBuf::pix)
   bdpt_gbuffer gb;
   DevCounters* counters;
+  uint32_t* hintPix;    // FrameDev::hintPix, written here (may be NULL)
 };
 
 // BMFR denoise pass (bmfr.hip).  History buffers come in ping-pong pairs: R = previous frame (read), W = this
@@ -190,6 +199,8 @@ void launchBmfr(const BmfrDev& A, uint32_t flags, hipStream_t st);
 
 // launchers (kernels.hip)
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
+// SceneDev::lightMap of every point / spot light of the scene (res texels per face edge), closest-hit rays from the light
+void launchLightMaps(const SceneDev& S, uint32_t* maps, uint32_t res, hipStream_t st);
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);
 // Persistent-grid sizes of one context's device, filled on first use (occupancy query per kernel variant).
 struct LaunchGrids {

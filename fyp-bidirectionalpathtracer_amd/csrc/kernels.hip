@@ -176,6 +176,7 @@ BD f3 envLookup(const float* envMap, uint32_t envW, uint32_t envH, f3 d) {
 
 template <bool COUNT>
 __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G) {
+  BDPT_ONE_WAVE_PER_GROUP();
   __shared__ int s_stack[kStackEntries * kWave];
   const uint32_t p = blockIdx.x * kWave + threadIdx.x;
   if (p >= G.Np) return;
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G
     addCount(G.counters, C_TRI_CLOSEST, nTris);
   }
   float4* oP = reinterpret_cast<float4*>(G.gb.worldPosition);
+  if (G.hintPix) G.hintPix[pix] = (h.prim < 0) ? kNoHint : h.rec;  // occluder hint of light-tracing rays aimed at this pixel
   if (h.prim < 0) {
     const f3 c = G.gp.envMap ? envLookup(G.gp.envMap, G.gp.envWidth, G.gp.envHeight, d) : ld3(G.gp.envColor);
     oP[pix] = make_float4(0, 0, 0, 0);
@@ -229,11 +231,79 @@ __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G
 }
 
 // ------------------------------------------------------------------------------------------------
+// Occluder hints (device_trace.hpp recOccludes).  Two kinds of any-hit rays end at a point the whole frame shares:
+//   * a light-tracing ray ends at the camera: whatever lies beyond the surface the camera sees through the target pixel
+//     is hidden by that surface, so the triangle the pixel's PRIMARY ray hit is tried first (FrameDev::hintPix, written
+//     by the G-buffer pass of the same context);
+//   * a next-event ray ends at a point / spot light: the nearest triangle the light sees in that direction hides
+//     everything behind it, so a cube map of nearest triangles per light (SceneDev::lightMap, built once per scene by
+//     closest-hit rays from the light) supplies the triangle to try.
+// A hint only ever picks WHICH triangle is tested first; a ray its hint does not occlude is traced as before, so the
+// image does not depend on the map's resolution, on a stale G-buffer, or on there being hints at all.
+// ------------------------------------------------------------------------------------------------
+// cube-map texel of direction v (from the light): face = 2 * major axis + (negative ? 1 : 0), the two other components
+// over the major one mapped from [-1, 1] to [0, res)
+BD uint32_t cubeTexel(f3 v, uint32_t res) {
+  const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z);
+  uint32_t face;
+  float ma, uc, vc;
+  if (ax >= ay && ax >= az) {
+    face = v.x < 0.0f ? 1u : 0u;
+    ma = ax;
+    uc = v.y;
+    vc = v.z;
+  } else if (ay >= az) {
+    face = v.y < 0.0f ? 3u : 2u;
+    ma = ay;
+    uc = v.x;
+    vc = v.z;
+  } else {
+    face = v.z < 0.0f ? 5u : 4u;
+    ma = az;
+    uc = v.x;
+    vc = v.y;
+  }
+  if (!(ma > 0.0f)) return kNoHint;  // zero or NaN direction
+  const float fr = (float)res;
+  const float fu = (uc / ma * 0.5f + 0.5f) * fr, fv = (vc / ma * 0.5f + 0.5f) * fr;
+  const uint32_t iu = fu >= fr ? res - 1u : (uint32_t)(fu < 0.0f ? 0.0f : fu), iv = fv >= fr ? res - 1u : (uint32_t)(fv < 0.0f ? 0.0f : fv);
+  return (face * res + iv) * res + iu;
+}
+BD uint32_t lightHint(const SceneDev& S, int light, f3 lightPos, f3 pos) {
+  if (!S.lightMap) return kNoHint;
+  const uint32_t t = cubeTexel(pos - lightPos, S.lightMapRes);
+  if (t == kNoHint) return kNoHint;
+  return S.lightMap[(size_t)light * 6u * S.lightMapRes * S.lightMapRes + t];
+}
+
+__global__ __launch_bounds__(kWave) void light_map_kernel(SceneDev S, uint32_t* __restrict__ maps, uint32_t res) {
+  BDPT_ONE_WAVE_PER_GROUP();
+  __shared__ int s_stack[kStackEntries * kWave];
+  const uint32_t perLight = 6u * res * res;
+  const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+  if (i >= perLight * S.numLights) return;
+  const uint32_t light = i / perLight, t = i - light * perLight;
+  const bdpt_light& l = S.sc->lights[light];
+  uint32_t out = kNoHint;
+  if (l.type != BDPT_LIGHT_DIRECTIONAL) {
+    const uint32_t face = t / (res * res), iv = (t / res) % res, iu = t % res;
+    const float uc = (((float)iu + 0.5f) / (float)res) * 2.0f - 1.0f, vc = (((float)iv + 0.5f) / (float)res) * 2.0f - 1.0f;
+    const float m = (face & 1u) ? -1.0f : 1.0f;
+    const f3 d = (face < 2u) ? mk(m, uc, vc) : ((face < 4u) ? mk(uc, m, vc) : mk(uc, vc, m));
+    uint32_t nNodes = 0, nTris = 0;
+    const Hit h = traverse<0, false>(S, ld3(l.posW), d, 0.0f, 1.0e38f, s_stack + threadIdx.x, nNodes, nTris);
+    if (h.prim >= 0) out = h.rec;
+  }
+  maps[i] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // init_paths: eye vertex 1 from the G-buffer, light vertex 0 from sampleLight, valid-pixel queue
 // (BDPTMain.rt.hlsl:51-103, 124-135; sampleLight BDPTUtils.hlsli:140-152)
 // ------------------------------------------------------------------------------------------------
 template <bool GGX>
 __global__ __launch_bounds__(kWave) void init_paths_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  BDPT_ONE_WAVE_PER_GROUP();
   const uint32_t p = blockIdx.x * kWave + threadIdx.x;
   const bool inTile = p < P.Np;
   const size_t pix = inTile ? P.pix[p] : 0;
@@ -373,6 +443,7 @@ constexpr int kWalkStackLds = BDPT_WALK_STACK_LDS;
 constexpr uint32_t kParkedMiss = 1u << 30;
 template <bool GGX, bool COUNT, bool EXT>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BDPT_WALK_WAVES_PER_EU, 8))) void walk_kernel(SceneDev S, FrameDev F, PathBuf P, uint32_t* __restrict__ head) {
+  BDPT_ONE_WAVE_PER_GROUP();
   __shared__ int s_stack[kWalkStackLds * kWave];
   __shared__ uint4 s_pool[kPoolEntries];
   int* stk = s_stack + threadIdx.x;
@@ -656,6 +727,7 @@ BD float evalGWithoutVPos(f3 posA, f3 nA, f3 posB, f3 nB) {  // BDPTUtils.hlsli:
 }
 
 __global__ __launch_bounds__(kWave) void mis_prefix_kernel(FrameDev F, PathBuf P) {
+  BDPT_ONE_WAVE_PER_GROUP();
   bool act = false;
   uint32_t i = 0;
   if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
@@ -776,6 +848,7 @@ BD bool queueGroup(const uint32_t* count, uint32_t subCap, bool& act, uint32_t& 
 
 template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  BDPT_ONE_WAVE_PER_GROUP();
   bool act = false;  // inactive lanes still take part in the wave-collective emitRay
   uint32_t i = 0;
   int t = 0;
@@ -790,7 +863,7 @@ __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, 
   uint32_t seed = act ? P.seedL[p] : 0u;
   float r = 0.0f;
   for (int k = 0; k <= t; k++) r = nextRand(seed);
-  bool emit = false;
+  bool emit = false, hinted = false;
   f3 pos = mk(0), L = mk(0), shade = mk(0);
   float distToLight = 0.0f;
   if (act && (t + 1) <= eyeLast) {
@@ -807,15 +880,23 @@ __global__ __launch_bounds__(kWave) void gen_nee_kernel(SceneDev S, FrameDev F, 
     f3 direct = directIfVisible<GGX>((float)lightsCount, L, lightIntensity, v.N, V, v.dif, v.spec, v.rough);
     shade = clampVec(applyStrategyWeight(F, P, p, prevColor * direct, t + 2, t + 1, 0), F.p.clampUpper);
     emit = !allZero(shade);
+    // the nearest triangle the light sees towards this vertex is tried first: an occluded term adds nothing and needs no ray
+    if (emit && S.sc->lights[lightToSample].type != BDPT_LIGHT_DIRECTIONAL &&
+        recOccludes(S, lightHint(S, lightToSample, ld3(S.sc->lights[lightToSample].posW), pos), pos, L, F.p.minT, distToLight)) {
+      emit = false;
+      hinted = true;
+    }
   }
   const uint32_t id = emitRay(P, RAY_TERMS, emit, pos, L, distToLight, shade);
   if (act) P.slotRay[(size_t)t * P.Np + p] = id;
   waveAddCount(F.counters, C_RAYS_NEE, emit ? 1u : 0u);
+  waveAddCount(F.counters, C_HINT_NEE, hinted ? 1u : 0u);
   waveAddCount(F.counters, C_PIX_VALID, firstOfPixel ? 1u : 0u);
 }
 
 template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  BDPT_ONE_WAVE_PER_GROUP();
   bool act = false;
   uint32_t i = 0;
   int t = 0;
@@ -827,7 +908,7 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
   const f3 camPos = ld3(F.cam.posW);
   const f3 U = ld3(F.cam.cameraU), Vc = ld3(F.cam.cameraV), Wc = ld3(F.cam.cameraW);
   const f3 cameraN = normalize(Wc);
-  bool emit = false;
+  bool emit = false, hinted = false;
   f3 pos = mk(0), dirToCamera = mk(0), shade = mk(0);
   float disToCamera = 0.0f;
   uint32_t target = kNoRay;
@@ -862,6 +943,11 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
         f3 prevColor = ldPlane3(P, PATH_LIGHT, t, F_COL, p);
         shade = clampVec(applyStrategyWeight(F, P, p, (prevColor * fr) * Gt, t + 2, 0, t + 1), F.p.clampUpper);
         if (isnan3(shade)) shade = mk(0);
+        // the surface the camera sees through the target pixel is tried first: a hidden vertex lands no splat and needs no ray
+        if (F.hintPix && recOccludes(S, F.hintPix[(size_t)(uint32_t)(int)fy * F.W + (uint32_t)(int)fx], pos, dirToCamera, F.p.minT, disToCamera)) {
+          emit = false;
+          hinted = true;
+        }
       }
     }
   }
@@ -871,6 +957,7 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
     P.splatPix[(size_t)t * P.Np + p] = target;
   }
   waveAddCount(F.counters, C_RAYS_SPLAT, emit ? 1u : 0u);
+  waveAddCount(F.counters, C_HINT_SPLAT, hinted ? 1u : 0u);
 }
 
 // Connections.  Lane g of a pixel's group LOADS camera length g + 1 (its vertex record, the two path colours and the
@@ -885,6 +972,7 @@ __global__ __launch_bounds__(kWave) void gen_splat_kernel(SceneDev S, FrameDev F
 // The l = 0 pairs (c in 2..D-1) never carry a ray: their slot is written as empty by the lane of c.
 template <bool GGX, int G>
 __global__ __launch_bounds__(kWave) void gen_connect_kernel(SceneDev S, FrameDev F, PathBuf P) {
+  BDPT_ONE_WAVE_PER_GROUP();
   constexpr int kPix = kWave / G;
   __shared__ float4 s_light[kPix][G][4];       // q0..q3 of light vertex g (zeros past the end of the sub-path)
   __shared__ float4 s_eyePos[kPix][G];         // position of eye vertex g + 1 (zero past the end)
@@ -1126,6 +1214,7 @@ BD bool gatherLane(const FrameDev& F, const PathBuf& P, uint32_t p, uint32_t& nS
 
 __global__ __launch_bounds__(kWave) void gather_kernel(FrameDev F, PathBuf P, uint32_t* __restrict__ lazyList,
                                                        uint32_t* __restrict__ lazyCount) {
+  BDPT_ONE_WAVE_PER_GROUP();
   bool act = false;
   uint32_t i = 0;
   if (!queueChunk(P.qcount, P.pathSubCap, act, i)) return;
@@ -1166,6 +1255,7 @@ BD void pairFromOrdinal(int D, int ord, int& totalLength, int& cameraLength) {
 template <int G>
 __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
                                                          const uint32_t* __restrict__ listCount, int batch) {
+  BDPT_ONE_WAVE_PER_GROUP();
   bool act = false;
   uint32_t i = 0;
   int g = 0;
@@ -1237,6 +1327,7 @@ __global__ __launch_bounds__(kWave) void lazy_gen_kernel(FrameDev F, PathBuf P, 
 __global__ __launch_bounds__(kWave) void lazy_check_kernel(FrameDev F, PathBuf P, const uint32_t* __restrict__ list,
                                                            const uint32_t* __restrict__ listCount, int batch,
                                                            uint32_t* __restrict__ nextList, uint32_t* __restrict__ nextCount) {
+  BDPT_ONE_WAVE_PER_GROUP();
   bool act = false;
   uint32_t i = 0;
   if (!queueChunk(listCount, P.pathSubCap, act, i)) return;
@@ -1342,6 +1433,7 @@ __global__ void test_rng_kernel(const uint32_t* v0, const uint32_t* v1, uint32_t
 }
 template <int MODE>
 __global__ __launch_bounds__(kWave) void test_trace_kernel(SceneDev S, const float* rays, uint32_t n, int32_t* prim, float* tuv) {
+  BDPT_ONE_WAVE_PER_GROUP();
   __shared__ int s_stack[kStackEntries * kWave];
   const uint32_t i = blockIdx.x * kWave + threadIdx.x;
   if (i >= n) return;
@@ -1394,6 +1486,20 @@ static inline uint32_t blocksFor(uint64_t n) { return (uint32_t)((n + kWave - 1)
 // grid of a dense kernel over a sharded path queue: every (list, chunk) pair gets a workgroup
 static inline uint32_t queueGrid(const PathBuf& P) { return (P.pathSubCap / kWave) * kNumSubQueues; }
 
+// ONE WORKGROUP = ONE WAVE.  Every kernel above this line that is declared __launch_bounds__(kWave) relies on it: LDS arrays
+// are sized for one wave and indexed by threadIdx.x (s_stack + threadIdx.x with kWave-strided rows, s_pool, s_light[e][g] with
+// e = threadIdx.x / G, s_eyePos, s_pair), ovfSlot() addresses blockIdx.x * kWave + lane, queueChunk / queueGroup deal
+// list entries by threadIdx.x, __syncthreads() is used as a wave barrier, and emitRay / wavePush / waveAddCount are wave
+// collectives whose atomics assume one leader per workgroup.  With a second wave in the workgroup threadIdx.x runs to 127:
+// the rows alias or run past the arrays (round 4's multi-wave gen_connect variant: s_pair overwritten by the other wave
+// -> light lengths up to 15 -> slot indices past slotRay's planes -> the wrong terms and the memory fault recorded in
+// profiles/README.md).  So these kernels are launched through launchWave() only — there is no block size to get wrong —
+// and each starts with oneWavePerGroup(), which makes a launch of any other shape do nothing instead of corrupting.
+template <class K, class... Args>
+static void launchWave(K kernel, uint32_t grid, hipStream_t st, Args... args) {
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWave), 0, st, args...);
+}
+
 // Persistent grids: as many one-wave workgroups as can be resident (LDS 8 KiB/wave, VGPRs).
 template <class K>
 static uint32_t persistentGrid(K kernel, int numCUs) {
@@ -1408,17 +1514,23 @@ void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st) {
   const uint32_t Np = G.Np;
   if (!Np) return;
   if (G.counters)
-    hipLaunchKernelGGL(gbuffer_kernel<true>, dim3(blocksFor(Np)), dim3(kWave), 0, st, S, G);
+    launchWave(gbuffer_kernel<true>, (uint32_t)(blocksFor(Np)), st, S, G);
   else
-    hipLaunchKernelGGL(gbuffer_kernel<false>, dim3(blocksFor(Np)), dim3(kWave), 0, st, S, G);
+    launchWave(gbuffer_kernel<false>, (uint32_t)(blocksFor(Np)), st, S, G);
+}
+
+void launchLightMaps(const SceneDev& S, uint32_t* maps, uint32_t res, hipStream_t st) {
+  const uint64_t n = (uint64_t)6 * res * res * S.numLights;
+  if (!n) return;
+  launchWave(light_map_kernel, (uint32_t)((n + kWave - 1) / kWave), st, S, maps, res);
 }
 
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
   if (F.p.matIndex == 0)
-    hipLaunchKernelGGL(init_paths_kernel<true>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
+    launchWave(init_paths_kernel<true>, (uint32_t)(blocksFor(P.Np)), st, S, F, P);
   else
-    hipLaunchKernelGGL(init_paths_kernel<false>, dim3(blocksFor(P.Np)), dim3(kWave), 0, st, S, F, P);
+    launchWave(init_paths_kernel<false>, (uint32_t)(blocksFor(P.Np)), st, S, F, P);
 }
 
 void launchWalk(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGrids& G, int numCUs, hipStream_t st) {
@@ -1431,7 +1543,7 @@ void launchWalk(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGr
 #define BDPT_LAUNCH_WALK(GGX, CNT, EXT)                                                                        \
   {                                                                                                           \
     if (!g) g = persistentGrid(walk_kernel<GGX, CNT, EXT>, numCUs);                                            \
-    hipLaunchKernelGGL((walk_kernel<GGX, CNT, EXT>), dim3(std::min(g, need)), dim3(kWave), 0, st, S, F, P, P.qhead); \
+    launchWave((walk_kernel<GGX, CNT, EXT>), (uint32_t)(std::min(g, need)), st, S, F, P, P.qhead); \
   }
   if (ext) {
     if (ggx && cnt) BDPT_LAUNCH_WALK(true, true, true)
@@ -1449,18 +1561,17 @@ void launchWalk(const SceneDev& S, const FrameDev& F, const PathBuf& P, LaunchGr
 
 void launchMisPrefix(const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(mis_prefix_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P);
+  launchWave(mis_prefix_kernel, (uint32_t)(queueGrid(P)), st, F, P);
 }
 // The three generators only share the ray queues (atomic appends), so the host may launch them on different streams.
 // G lanes per pixel: 8 for contexts sized up to depth 8, else 16 (the ray queues are sized for that shape).
 #define BDPT_LAUNCH_GEN(KERNEL)                                                                   \
   {                                                                                               \
     const bool ggx = F.p.matIndex == 0, wide = P.D1 > 9; /* the depth the context is sized for */  \
-    const dim3 b(kWave);                                                                          \
-    if (ggx && !wide) hipLaunchKernelGGL((KERNEL<true, 8>), dim3(queueGrid(P) * 8), b, 0, st, S, F, P);    \
-    else if (ggx) hipLaunchKernelGGL((KERNEL<true, 16>), dim3(queueGrid(P) * 16), b, 0, st, S, F, P);      \
-    else if (!wide) hipLaunchKernelGGL((KERNEL<false, 8>), dim3(queueGrid(P) * 8), b, 0, st, S, F, P);     \
-    else hipLaunchKernelGGL((KERNEL<false, 16>), dim3(queueGrid(P) * 16), b, 0, st, S, F, P);              \
+    if (ggx && !wide) launchWave(KERNEL<true, 8>, queueGrid(P) * 8, st, S, F, P);     \
+    else if (ggx) launchWave(KERNEL<true, 16>, queueGrid(P) * 16, st, S, F, P);       \
+    else if (!wide) launchWave(KERNEL<false, 8>, queueGrid(P) * 8, st, S, F, P);      \
+    else launchWave(KERNEL<false, 16>, queueGrid(P) * 16, st, S, F, P);               \
   }
 void launchGenNee(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st) {
   if (!P.Np) return;
@@ -1486,28 +1597,28 @@ void launchTraceShadow(const SceneDev& S, const FrameDev& F, const PathBuf& P, i
   uint32_t& g = G.shadow[cnt ? 1 : 0];
   if (cnt) {
     if (!g) g = persistentGrid(trace_shadow_kernel<true>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
+    launchWave(trace_shadow_kernel<true>, (uint32_t)(g), st, S, Q, vis, F.counters, F.p.minT);
   } else {
     if (!g) g = persistentGrid(trace_shadow_kernel<false>, numCUs);
-    hipLaunchKernelGGL(trace_shadow_kernel<false>, dim3(g), dim3(kWave), 0, st, S, Q, vis, F.counters, F.p.minT);
+    launchWave(trace_shadow_kernel<false>, (uint32_t)(g), st, S, Q, vis, F.counters, F.p.minT);
   }
 }
 
 void launchGather(const FrameDev& F, const PathBuf& P, uint32_t* lazyList, uint32_t* lazyCount, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(gather_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, lazyList, lazyCount);
+  launchWave(gather_kernel, (uint32_t)(queueGrid(P)), st, F, P, lazyList, lazyCount);
 }
 void launchLazyGen(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch, hipStream_t st) {
   if (!P.Np) return;
   if (P.D1 > 9)  // the depth the context is sized for: 16 lanes per pixel, as the generators
-    hipLaunchKernelGGL(lazy_gen_kernel<16>, dim3(queueGrid(P) * 16), dim3(kWave), 0, st, F, P, list, listCount, batch);
+    launchWave(lazy_gen_kernel<16>, (uint32_t)(queueGrid(P) * 16), st, F, P, list, listCount, batch);
   else
-    hipLaunchKernelGGL(lazy_gen_kernel<8>, dim3(queueGrid(P) * 8), dim3(kWave), 0, st, F, P, list, listCount, batch);
+    launchWave(lazy_gen_kernel<8>, (uint32_t)(queueGrid(P) * 8), st, F, P, list, listCount, batch);
 }
 void launchLazyCheck(const FrameDev& F, const PathBuf& P, const uint32_t* list, const uint32_t* listCount, int batch,
                      uint32_t* nextList, uint32_t* nextCount, hipStream_t st) {
   if (!P.Np) return;
-  hipLaunchKernelGGL(lazy_check_kernel, dim3(queueGrid(P)), dim3(kWave), 0, st, F, P, list, listCount, batch, nextList, nextCount);
+  launchWave(lazy_check_kernel, (uint32_t)(queueGrid(P)), st, F, P, list, listCount, batch, nextList, nextCount);
 }
 
 void launchResolve(const unsigned long long* splat, bool tileLocal, uint32_t splatRow0, const SplatLayout& L, float* out, uint32_t W,
@@ -1538,11 +1649,11 @@ void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t 
 void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode, int32_t* prim, float* tuv, hipStream_t st) {
   if (!n) return;
   if (mode == 0)
-    hipLaunchKernelGGL(test_trace_kernel<0>, dim3(blocksFor(n)), dim3(kWave), 0, st, S, rays, n, prim, tuv);
+    launchWave(test_trace_kernel<0>, (uint32_t)(blocksFor(n)), st, S, rays, n, prim, tuv);
   else if (mode == 1)
-    hipLaunchKernelGGL(test_trace_kernel<1>, dim3(blocksFor(n)), dim3(kWave), 0, st, S, rays, n, prim, tuv);
+    launchWave(test_trace_kernel<1>, (uint32_t)(blocksFor(n)), st, S, rays, n, prim, tuv);
   else
-    hipLaunchKernelGGL(test_trace_kernel<2>, dim3(blocksFor(n)), dim3(kWave), 0, st, S, rays, n, prim, tuv);
+    launchWave(test_trace_kernel<2>, (uint32_t)(blocksFor(n)), st, S, rays, n, prim, tuv);
 }
 // The persistent any-hit kernel over a caller's ray list (planes ox oy oz dx dy dz tmax of stride `cap`, one sub-queue):
 // visibility bytes and, through `counters`, the visit tallies and the deepest stack.
@@ -1550,7 +1661,7 @@ void launchTestTraceShadow(const SceneDev& S, const float* planes, uint32_t cap,
                            DevCounters* counters, float tmin, int numCUs, hipStream_t st) {
   RayQueue Q{planes, cap, cap, 1u, count, head};
   const uint32_t g = persistentGrid(trace_shadow_kernel<true>, numCUs);
-  hipLaunchKernelGGL(trace_shadow_kernel<true>, dim3(g), dim3(kWave), 0, st, S, Q, vis, counters, tmin);
+  launchWave(trace_shadow_kernel<true>, (uint32_t)(g), st, S, Q, vis, counters, tmin);
 }
 void launchTestBsdf(const float* in, uint32_t n, uint32_t matIndex, float* out, hipStream_t st) {
   if (!n) return;

@@ -1,5 +1,6 @@
 // Passes.cpp — host mirror of the reference's pass framework and passes over the C ABI.
 #include "Passes.h"
+#include "RankSync.h"
 
 #include "../../include/bdpt_scene.h"
 
@@ -1028,35 +1029,26 @@ std::vector<float> RenderingPipeline::readOutput() {
   (void)hipStreamSynchronize(stream);
   const uint32_t W = t->getWidth(), H = t->getHeight(), world = mTileWorld, R = mpRays->stripeRows();
   const bdpt_tile_info& ti = mpRays->tileInfo();
-  const size_t perRank = (size_t)ti.chunkRows * W * 4;
+  const size_t perRank = (size_t)ti.chunkRows * W * 4;  // (= stripeChunkRows(H, world, R) rows: bdpt_get_tile_info agrees, checked below)
   float *mine = nullptr, *all = nullptr;
   std::vector<float> out;
+  if (ti.chunkRows != stripeChunkRows(H, world, R)) return out;
   if (hipMalloc(&mine, std::max<size_t>(perRank * 4, 16)) != hipSuccess || hipMalloc(&all, std::max<size_t>(perRank * 4 * world, 16)) != hipSuccess) {
     if (mine) (void)hipFree(mine);
     return out;
   }
   (void)hipMemsetAsync(mine, 0, perRank * 4, stream);
-  const uint32_t numStripes = (H + R - 1) / R;
   const float* src = (const float*)t->getDevicePointer();
-  size_t at = 0;
-  for (uint32_t s = mTileRank; s < numStripes; s += world) {
-    const uint32_t a = s * R, b = std::min(H, a + R);
-    (void)hipMemcpyAsync(mine + at, src + (size_t)a * W * 4, (size_t)(b - a) * W * 16, hipMemcpyDeviceToDevice, stream);
-    at += (size_t)(b - a) * W * 4;
-  }
+  const size_t rowFloats = (size_t)W * 4;
+  for (const StripeSpan& s : stripeSpans(H, world, mTileRank, R))  // this rank's rows, in order, at the head of its chunk (RankSync.h)
+    (void)hipMemcpyAsync(mine + (size_t)s.packedRow * rowFloats, src + (size_t)s.firstRow * rowFloats, (size_t)s.rows * rowFloats * 4,
+                         hipMemcpyDeviceToDevice, stream);
   const bool ok = mpRays->exchange()->allGather(mine, all, perRank, stream);
   std::vector<float> packed(perRank * world);
   if (ok && hipStreamSynchronize(stream) == hipSuccess &&
       hipMemcpy(packed.data(), all, packed.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
     out.assign((size_t)W * H * 4, 0.0f);
-    for (uint32_t r = 0; r < world; r++) {
-      size_t from = (size_t)r * perRank;
-      for (uint32_t s = r; s < numStripes; s += world) {
-        const uint32_t a = s * R, b = std::min(H, a + R);
-        std::memcpy(&out[(size_t)a * W * 4], &packed[from], (size_t)(b - a) * W * 16);
-        from += (size_t)(b - a) * W * 4;
-      }
-    }
+    unpackStripes(reinterpret_cast<const uint8_t*>(packed.data()), reinterpret_cast<uint8_t*>(out.data()), H, world, R, rowFloats * 4);
   } else if (!ok) {
     std::fprintf(stderr, "[RenderingPipeline] gather failed: %s\n", mpRays->exchange()->lastError().c_str());
   }

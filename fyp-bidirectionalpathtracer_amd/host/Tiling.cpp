@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "../../include/bdpt.h"
+#include "RankSync.h"
 
 namespace bdpt {
 
@@ -71,26 +72,13 @@ bool TileExchange::allGather(const float* mine, float* all, size_t count, hipStr
   return hipMemcpyAsync(all + (size_t)mRank * count, mine, count * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess;
 }
 
-bool exchangeUniqueIdThroughFile(const std::string& path, uint32_t rank, ncclUniqueId* id, double timeoutSeconds) {
+bool exchangeUniqueIdThroughFile(const std::string& path, uint32_t rank, ncclUniqueId* id, double timeoutSeconds, uint64_t nonce) {
   if (rank == 0) {
     if (ncclGetUniqueId(id) != ncclSuccess) return false;
-    const std::string tmp = path + ".tmp";
-    FILE* f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return false;
-    const bool ok = std::fwrite(id, sizeof(*id), 1, f) == 1;
-    if (std::fclose(f) != 0 || !ok) return false;
-    return std::rename(tmp.c_str(), path.c_str()) == 0;
+    return writeIdFile(path, nonce, id, sizeof(*id));
   }
-  const auto t0 = std::chrono::steady_clock::now();
-  for (;;) {
-    if (FILE* f = std::fopen(path.c_str(), "rb")) {
-      const bool ok = std::fread(id, sizeof(*id), 1, f) == 1;
-      std::fclose(f);
-      if (ok) return true;
-    }
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) return false;
-    std::this_thread::sleep_for(std::chrono::milliseconds(20));
-  }
+  return waitForIdFile(path, nonce, id, sizeof(*id), timeoutSeconds);
 }
+void retireUniqueIdFile(const std::string& path) { retireIdFile(path); }
 
 }  // namespace bdpt

@@ -63,7 +63,12 @@ class TileExchange {
 uint32_t stripeRows(uint32_t height, uint32_t world);
 
 // Multi-process hosts (one process per GPU, e.g. under mpirun or a job scheduler): rank 0 writes the ncclUniqueId to
-// `path` (atomically: temporary name + rename), the others wait for the file.  false after `timeoutSeconds`.
-bool exchangeUniqueIdThroughFile(const std::string& path, uint32_t rank, ncclUniqueId* id, double timeoutSeconds = 120.0);
+// `path`, the others wait for it; false after `timeoutSeconds`.  The file is single-use and carries `nonce` (RankSync.h
+// "id file": rank 0 removes what it finds at `path` first, the others only take a file with their own nonce, and rank 0
+// calls retireUniqueIdFile once ncclCommInitRank has returned — by then every rank has read it).  A launcher that
+// re-runs a job with the same path gives each run its own nonce (bdpt_render --job-id) and is then safe against the
+// file a crashed earlier run left behind; with nonce 0 only the single-use rule protects.
+bool exchangeUniqueIdThroughFile(const std::string& path, uint32_t rank, ncclUniqueId* id, double timeoutSeconds = 120.0, uint64_t nonce = 0);
+void retireUniqueIdFile(const std::string& path);
 
 }  // namespace bdpt

@@ -286,6 +286,11 @@ typedef struct bdpt_counters {
   uint64_t raysConnectLazy;   /* subset of raysConnect traced by the gather stage for zero-valued pairs */
   uint64_t alphaTestsClosest; /* any-hit alpha tests (alphaTestFails, BDPTUtils.hlsli:115-127) run by closest-hit queries, */
   uint64_t alphaTestsShadow;  /* ... and by any-hit queries; with BDPT_PARAM_COUNTERS (the G-buffer ray is not tallied) */
+  /* Any-hit queries answered "occluded" by their occluder hint — one triangle tried before the traversal: the nearest
+   * triangle the light sees towards the vertex (next-event rays), the triangle the camera sees through the target pixel
+   * (light-tracing rays).  Such a query never enters the ray queue and is NOT part of raysNee / raysSplat. */
+  uint64_t hintedNee;
+  uint64_t hintedSplat;
 } bdpt_counters;
 
 /* The environment secondary misses see (BDPT_PARAM_ENV_ON_MISS): an RGBA32F lat-long map (device pointer for

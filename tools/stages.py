@@ -31,4 +31,6 @@ print("frame %.2f ms | walk %.2f gen_terms %.2f trace_terms %.2f trace_pairs %.2
     "| visits/ray closest %.2f nodes %.2f tris, shadow %.2f nodes %.2f tris | sah %.2f nodes %d" % (
         c["nodeVisitsClosest"] / max(1, c["raysEyeExtend"] + c["raysLightExtend"]), c["triTestsClosest"] / max(1, c["raysEyeExtend"] + c["raysLightExtend"]),
         c["nodeVisitsShadow"] / max(1, c["raysNee"] + c["raysSplat"] + c["raysConnect"]), c["triTestsShadow"] / max(1, c["raysNee"] + c["raysSplat"] + c["raysConnect"]),
-        info.sahCost, info.numNodes))
+        info.sahCost, info.numNodes),
+    "| any-hit NEE %.2fM + %.2fM hinted, splat %.2fM + %.2fM hinted, connect %.2fM (lazy %.2fM)" % (
+        c["raysNee"] / 1e6, c["hintedNee"] / 1e6, c["raysSplat"] / 1e6, c["hintedSplat"] / 1e6, c["raysConnect"] / 1e6, c["raysConnectLazy"] / 1e6))

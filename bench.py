@@ -31,6 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 RAY_KEYS = ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")
+# any-hit queries answered "occluded" by their occluder hint (one triangle of the scene tried before the traversal:
+# DESIGN.md section 4): queries the integrator issued and the pass answered, counted in `value` like every other any-hit
+# query and reported on their own as well (config.rays_hinted_per_frame, config.value_traversals_only)
+HINT_KEYS = ("hintedNee", "hintedSplat")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; its measured float4 copy rate is 6290 GB/s)
 # Rates the traversal kernels are priced against (MI355X_MICROARCH.md "Indexed rows: gather", chip-wide; the low ends):
 L2_GATHER_GBS = 16800.0         # rows served by the XCDs' L2s
@@ -43,7 +47,7 @@ LANE_LOADS_PER_CLK_PER_CU = 1.03
 VALU_CLK_FAST, VALU_CLK_SLOW = 2.4, 4.3
 SHADER_CLK_HZ = 2.4e9
 NUM_CUS, NUM_SIMDS = 256, 1024
-PROFILE_ROUND = "r4"   # profiles/<round>/roofline_pmc.json holds the PMC counts the roofline block quotes
+PROFILE_ROUND = "r5"   # profiles/<round>/roofline_pmc.json holds the PMC counts the roofline block quotes
 
 
 SURVEY_NODE_BYTES, SURVEY_TRI_BYTES = 64, 48  # algorithmic bytes per interior-node / triangle visit
@@ -73,31 +77,130 @@ def algorithmic_bytes(cnt, n_pairs_eval, n_pix_tile, node_b, tri_b, D):
     # trace_shadow_kernel: main launch + lazy rounds
     b["trace_shadow_kernel"] = 36 * shadow + node_b * cnt["nodeVisitsShadow"] + tri_b * cnt["triTestsShadow"]
     # gen_nee + gen_splat + gen_connect (+ lazy_gen): the vertex reads of every term and pair, the ray they append (28 B + 12 B)
-    b["gen_kernels"] = 84 * cnt["raysNee"] + 84 * cnt["raysSplat"] + 168 * n_pairs_eval + 40 * shadow
+    # (a term its occluder hint answered read its vertex like any other, plus 4 B of hint word and the 48-B triangle record)
+    hinted = cnt.get("hintedNee", 0) + cnt.get("hintedSplat", 0)
+    b["gen_kernels"] = 84 * (cnt["raysNee"] + cnt["raysSplat"] + hinted) + 52 * hinted + 168 * n_pairs_eval + 40 * shadow
     # clear + init_paths + gather + lazy_check + resolve
     b["per_pixel_kernels"] = (n_pix_tile * (56 + 16 + 32 + 32) + valid * (2 * 96 + 24 + 8 + 3 + 4) +
                               valid * (4 * (2 * D + pairs) + 32 + 4 * D) + shadow * (1 + 12) + cnt["splatsLanded"] * (32 + 32))
     return b
 
 
-def load_pmc(pkg, scene, W, H, D, world):
-    """Per-kernel, per-frame hardware counts of the committed rocprofv3 --pmc passes of this command
-    (tools/collect_profiles.sh -> tools/roofline_pmc.py): {kernel base name: {counter: value per frame}}.  The file names
-    the sources it was measured on (source_hash); counts of another build are not quoted (pmc_build_match false)."""
-    pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "roofline_pmc.json")
-    if not (scene == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1) and os.path.exists(pj)):
+def load_pmc(pkg, sub=""):
+    """Per-kernel, per-frame hardware counts of the committed rocprofv3 --pmc passes of a workload (tools/prof_pmc.sh for
+    the bench frame, tools/prof_config_pmc.sh for the configs[3] / configs[4] shapes -> tools/roofline_pmc.py):
+    {kernel base name: {counter: value per frame}} from profiles/<round>/<sub>/roofline_pmc.json.  The file names the
+    sources it was measured on (source_hash); counts of another build are not quoted (pmc_build_match false)."""
+    pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, sub, "roofline_pmc.json")
+    if not os.path.exists(pj):
         return {}
     with open(pj) as f:
         raw = json.load(f)
     if raw.get("source_hash") != pkg.source_hash():
         return {"_mismatch": True}
-    out = {}
-    for k, v in raw["kernels"].items():
-        name = k.split("<")[0]
-        if name not in out or v.get("dispatches_per_frame", 0) > out[name].get("dispatches_per_frame", 0):
-            out[name] = v  # the timed variant (no visit counters) has more launches than the one statistics frame
-    out["_meta"] = {k: v for k, v in raw.items() if k != "kernels"}
+    # counts per frame by kernel NAME: a frame runs one template variant of each kernel (the statistics frame the variant
+    # with visit counters), so the variants of a name add up to whole frames (tools/roofline_pmc.py "by_name")
+    out = dict(raw["by_name"])
+    out["_meta"] = {k: v for k, v in raw.items() if k not in ("kernels", "by_name")}
     return out
+
+
+KERNEL_MEMBERS = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
+                  "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
+                  "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
+
+
+def kernel_durations(ms):
+    """Stage times (bdpt_get_stage_times: one stage = one kernel of the launch stream, a wait for the second stream, or a
+    "side:" kernel of the second stream) -> summed KERNEL time per roofline block, the waits, and the critical path."""
+    k = {"walk_kernel": ms.get("walk", 0.0),
+         "trace_shadow_kernel": ms.get("trace_terms", 0.0) + ms.get("trace_pairs", 0.0) + ms.get("lazy_trace", 0.0),
+         # gen_splat and gen_connect run on the second stream beside gen_nee / trace_terms: their own event pairs
+         "gen_kernels": ms.get("gen_nee", 0.0) + ms.get("gen_splat", 0.0) + ms.get("gen_connect", 0.0) +
+                        ms.get("side:gen_splat", 0.0) + ms.get("side:gen_connect", 0.0) + ms.get("lazy_gen", 0.0),
+         "per_pixel_kernels": ms.get("clear", 0.0) + ms.get("init_paths", 0.0) + ms.get("mis_prefix", 0.0) + ms.get("gather", 0.0) +
+                              ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0)}
+    waits = ms.get("splat_wait", 0.0) + ms.get("connect_wait", 0.0) + ms.get("tail_wait", 0.0)
+    critical = sum(v for n, v in ms.items() if not n.startswith("side:"))
+    return k, waits, critical
+
+
+def roofline_kernels(kernel_ms, alg, fetched, pmc):
+    """One roofline entry per kernel block: the contract's figure (algorithmic bytes / kernel time / HBM peak) and, when
+    PMC counts of this build are committed, the HBM-side traffic and the fractions of the ceilings that can bind."""
+    def roof(name):
+        t_ms, by = kernel_ms[name], alg[name]
+        sec = t_ms * 1e-3
+        ach = by / sec / 1e9 if sec > 0 else 0.0
+        r = {"ms_per_frame": round(t_ms, 3), "bytes_per_frame": int(by), "achieved": round(ach, 1),
+             "frac": round(ach / HBM_PEAK_GBS, 4)}
+        if r["frac"] > 1.0:
+            r["frac_note"] = "above 1: cache-served (algorithmic bytes exceed what leaves the chip's caches; see hbm_side_frac and fractions)"
+        have = [pmc[k] for k in KERNEL_MEMBERS[name] if k in pmc]
+        if not have or sec <= 0:
+            r["traffic"] = None
+            return r
+
+        def tot(c):
+            return sum(p.get(c, 0.0) for p in have)
+
+        # HBM / fabric side: 2 x FETCH_SIZE + WRITE_SIZE.  FETCH_SIZE tallies 64 B per 128-byte request on gfx950
+        # (MI355X_MICROARCH.md, measured there on coalesced streams); tools/microbench/fetch_calib.hip shows the same
+        # for 16-byte gathers (profiles/r3/fetch_calib.txt), so the factor applies to the traversal kernels too.
+        fetch_factor = pmc["_meta"].get("fetch_factor", {}).get(name, 2.0)
+        if not tot("FETCH_SIZE_bytes") and not tot("WRITE_SIZE_bytes"):
+            r["traffic"] = None
+        else:
+            traffic = fetch_factor * tot("FETCH_SIZE_bytes") + tot("WRITE_SIZE_bytes")
+            r["traffic"] = int(traffic)
+            r["traffic_over_algorithmic"] = round(traffic / by, 3)
+            # counter bytes / kernel time / 8 TB/s: what of the HBM roof this kernel really uses
+            r["hbm_side_frac"] = round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)
+        fr = {"hbm": r.get("hbm_side_frac")}
+        if name in fetched and tot("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            fb = fetched[name]
+            r["fetched"] = {"bytes_per_frame": int(fb), "rate_gbs": round(fb / sec / 1e9, 1),
+                            "note": "bytes at the record sizes this build loads (48-B nodes and triangles) / time; most are served by L1 / L2"}
+            req = tot("TCP_TCC_READ_REQ_sum")
+            l1 = tot("TCP_TOTAL_CACHE_ACCESSES_sum")
+            miss = tot("TCC_MISS_sum")
+            r["l2_side"] = {"l1_to_l2_requests_per_frame": int(req), "request_bytes": 128,
+                            "rate_gbs": round(req * 128 / sec / 1e9, 1), "l2_gather_peak_gbs": L2_GATHER_GBS,
+                            "l2_misses_per_frame": int(miss), "fabric_rate_gbs": round(miss * 128 / sec / 1e9, 1),
+                            "infinity_cache_gather_peak_gbs": MALL_GATHER_GBS,
+                            "l1_hit": round(1.0 - req / l1, 3) if l1 else None,
+                            "l2_hit": round(1.0 - miss / max(1.0, tot("TCC_HIT_sum") + miss), 3)}
+            fr["l2_gather"] = round(req * 128 / sec / 1e9 / L2_GATHER_GBS, 3)
+            fr["infinity_cache_gather"] = round(miss * 128 / sec / 1e9 / MALL_GATHER_GBS, 3)
+            clks = sec * SHADER_CLK_HZ
+            lane_loads = l1 / (NUM_CUS * clks) if clks else 0.0
+            fast = tot("SQ_INSTS_VALU_FAST")
+            valu = tot("SQ_INSTS_VALU")
+            slow = max(0.0, valu - fast)
+            r["issue"] = {"lane_loads_per_clk_per_cu": round(lane_loads, 3), "lane_load_ceiling": LANE_LOADS_PER_CLK_PER_CU,
+                          "valu_wave_instructions_per_frame": int(valu), "valu_fast_share": round(fast / valu, 3) if valu else None,
+                          "valu_clk_fast_slow": [VALU_CLK_FAST, VALU_CLK_SLOW],
+                          "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / (64.0 * tot("SQ_ACTIVE_INST_VALU")), 3)
+                          if tot("SQ_ACTIVE_INST_VALU") else None,
+                          "wait_any": round(tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"), 3) if tot("SQ_WAVE_CYCLES") else None,
+                          "shader_clock_hz_assumed": SHADER_CLK_HZ}
+            fr["vmem_address_unit"] = round(lane_loads / LANE_LOADS_PER_CLK_PER_CU, 3)
+            if valu and tot("SQ_INSTS_VALU_FAST"):
+                fr["valu_issue"] = round((fast * VALU_CLK_FAST + slow * VALU_CLK_SLOW) / (NUM_SIMDS * clks), 3) if clks else None
+        r["fractions"] = fr
+        r["bound"] = max(((v, k) for k, v in fr.items() if v is not None), default=(0, "hbm"))[1]
+        return r
+
+    return {k: roof(k) for k in kernel_ms}
+
+
+def fetched_bytes(stat, info):
+    """bytes the build really loads per unit: 48-byte records for nodes and triangles (bvh.h), a 28-byte ray + 1 visibility
+    byte per any-hit ray, origin + direction + 16-byte hit record per closest-hit ray, SURVEY's 388 B per shade"""
+    closest_rays = stat["raysEyeExtend"] + stat["raysLightExtend"]
+    n_shadow = stat["raysNee"] + stat["raysSplat"] + stat["raysConnect"]
+    return {"walk_kernel": 44 * closest_rays + info.nodeBytes * stat["nodeVisitsClosest"] + info.triBytes * stat["triTestsClosest"] + 388 * closest_rays,
+            "trace_shadow_kernel": 29 * n_shadow + info.nodeBytes * stat["nodeVisitsShadow"] + info.triBytes * stat["triTestsShadow"]}
 
 
 def solo_frames(R, pkg, torch, n, flags=0):
@@ -112,7 +215,7 @@ def solo_frames(R, pkg, torch, n, flags=0):
         for name, ms in cx.stage_times():
             stage_ms[name] = stage_ms.get(name, 0.0) + ms
         last = cx.counters().as_dict()
-        for k in RAY_KEYS:
+        for k in RAY_KEYS + HINT_KEYS:
             rays[k] = rays.get(k, 0) + last[k]
     for pp in R.pipes:
         pp.ctx.enable_stage_timing(False)
@@ -120,7 +223,7 @@ def solo_frames(R, pkg, torch, n, flags=0):
 
 
 def timed_frames(R, pkg, K):
-    """K frames, no host synchronisation inside; returns (seconds, rays traced by this rank)."""
+    """K frames, no host synchronisation inside; returns (seconds, ray queries of this rank, of which answered by a hint)."""
     R.barrier()
     first = R.state["frame"]
     t0 = time.perf_counter()
@@ -128,19 +231,21 @@ def timed_frames(R, pkg, K):
         R.step(pkg.abi.PARAM_KEEP_COUNTERS if k >= R.inflight else 0)  # first use of each context zeroes its tallies
     R.barrier()
     dt = time.perf_counter() - t0
-    rays = 0
+    rays = hinted = 0
     for i, pp in enumerate(R.pipes):
         used = sum(1 for k in range(K) if (first + k) % R.inflight == i)  # frames this context rendered
         if used:
             c = pp.ctx.counters().as_dict()
-            rays += sum(c[k] for k in RAY_KEYS) + used * R.num_pixels  # + one primary ray per pixel
-    return dt, rays
+            h = sum(c[k] for k in HINT_KEYS)
+            rays += sum(c[k] for k in RAY_KEYS) + h + used * R.num_pixels  # + one primary ray per pixel
+            hinted += h
+    return dt, rays, hinted
 
 
 _CLOSE_LAST = []  # renderers of the side measurements: nothing is freed on the device before the last shape has been set up
 
 
-def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
+def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3, pmc_sub=None):
     """One more BASELINE shape on this GPU, one frame in flight: ms per frame, Mrays/s, visits per ray, stage times.
     The pipeline is left open (appended to `keep`): the driver wipes freed VRAM before it hands it out again, and the
     next shape's set-up would be charged the wait for this one's tens of GB (measured: 0.9-1.2 s per shape)."""
@@ -177,7 +282,8 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / frames
         c = pipe.ctx.counters().as_dict()
-        rays = (sum(c[k] for k in RAY_KEYS) + frames * W * H) / frames
+        hinted = sum(c[k] for k in HINT_KEYS) / frames
+        rays = (sum(c[k] for k in RAY_KEYS) + frames * W * H) / frames + hinted
         pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
         torch.cuda.synchronize()
         s = pipe.ctx.counters().as_dict()
@@ -187,6 +293,7 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
         free, total = torch.cuda.mem_get_info()
         out = {"workload": name, "resolution": [W, H], "max_depth": D, "mat_index": mat, "frames_timed": frames, "frames_in_flight": 1,
                "ms_per_frame": round(dt * 1e3, 3), "value": round(rays / dt / 1e6, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
+               "rays_hinted_per_frame": int(hinted),
                "visits_per_ray": {"closest_nodes": round(s["nodeVisitsClosest"] / closest, 2), "closest_tris": round(s["triTestsClosest"] / closest, 2),
                                   "shadow_nodes": round(s["nodeVisitsShadow"] / shadow, 2), "shadow_tris": round(s["triTestsShadow"] / shadow, 2),
                                   # any-hit shader invocations (alpha tests) per ray: the "any-hit rate" of BASELINE.md section 3 row 5
@@ -200,6 +307,25 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3):
                # VRAM it hands out has been used before — by this process or an earlier one (0.03 s for 94 GB on a fresh box)
                "scene_setup_s": round(pipe.setup_times["context_s"] + pipe.setup_times["set_scene_s"], 2),
                "setup_breakdown_s": {k: round(v, 2) for k, v in pipe.setup_times.items()}, "device_memory_gb": round((free0 - free) / 2 ** 30, 1)}
+        # the same roofline block as the headline's: algorithmic bytes from this shape's own tallies, kernel times from its
+        # stage events (one frame run alone), HBM-side bytes from the committed PMC passes of tools/big_configs.py when
+        # they were measured on this build (profiles/<round>/<pmc_sub>/roofline_pmc.json)
+        alg = algorithmic_bytes(s, s["pixelsValid"] * num_connect_pairs(D), W * H, SURVEY_NODE_BYTES, SURVEY_TRI_BYTES, D)
+        kernel_ms, wait_ms, critical_ms = kernel_durations(agg)
+        pmc = load_pmc(pkg, pmc_sub) if pmc_sub else {}
+        pmc_match = None if not pmc else not pmc.get("_mismatch", False)
+        if pmc_match is False:
+            pmc = {}
+        kernels = roofline_kernels(kernel_ms, alg, fetched_bytes(s, info), pmc)
+        dominant = max(kernel_ms.items(), key=lambda kv: kv[1])[0]
+        dom = kernels[dominant]
+        out["roofline"] = {"kernel": dominant, "bound": dom.get("bound", "hbm"), "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": dom["frac"], "traffic": dom.get("traffic"), "hbm_side_frac": dom.get("hbm_side_frac"),
+                           "kernels": kernels, "waits_ms_per_frame": round(wait_ms, 3),
+                           "frame": {"ms_per_frame": round(critical_ms, 3), "bytes_per_frame": int(sum(alg.values())),
+                                     "frac": round(sum(alg.values()) / (critical_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if critical_ms > 0 else 0.0,
+                                     "traffic": sum(k["traffic"] for k in kernels.values() if k.get("traffic")) or None},
+                           "pmc_build_match": pmc_match}
     except Exception:
         keep.remove(pipe)
         pipe.close()
@@ -363,9 +489,9 @@ def main():
     R.rewind(*mark)
 
     # ---- timed region: exactly K steps, no host synchronisation inside
-    elapsed, rays_total = timed_frames(R, pkg, args.steps)
+    elapsed, rays_total, hinted_total = timed_frames(R, pkg, args.steps)
 
-    t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(rays_total), float(hinted_total)], dtype=torch.float64, device=dev)
     per_rank = None
     if dist is not None:
         gdev = dev if backend == "nccl" else torch.device("cpu")
@@ -374,6 +500,7 @@ def main():
         dist.all_gather(allv, tg)
         elapsed_max = max(float(v[0]) for v in allv)
         rays_all = sum(float(v[1]) for v in allv)
+        hinted_all = sum(float(v[2]) for v in allv)
         rows_all = [None] * world
         dist.all_gather_object(rows_all, n_pix_tile // W)
         per_rank = {"ms_per_step": [round(float(v[0]) / args.steps * 1e3, 3) for v in allv],
@@ -381,7 +508,7 @@ def main():
                     "ms_per_step_max": round(elapsed_max / args.steps * 1e3, 3),
                     "mrays": [round(float(v[1]) / float(v[0]) / 1e6, 1) for v in allv], "rows": rows_all}
     else:
-        elapsed_max, rays_all = elapsed, float(rays_total)
+        elapsed_max, rays_all, hinted_all = elapsed, float(rays_total), float(hinted_total)
 
     out = None
     if rank == 0:
@@ -398,87 +525,16 @@ def main():
         # (bdpt_get_stage_times), summed over the frame, averaged over the frames named in stage_timing.
         alg = algorithmic_bytes(stat, stat["pixelsValid"] * num_connect_pairs(D), n_pix_tile, SURVEY_NODE_BYTES, SURVEY_TRI_BYTES, D)
         ms = {k: v / stage_frames for k, v in stage_ms.items()}
-        kernel_ms = {
-            "walk_kernel": ms.get("walk", 0.0),
-            # trace_terms runs beside gen_connect_kernel (second stream); trace_pairs starts when both are done
-            "trace_shadow_kernel": ms.get("trace_terms", 0.0) + ms.get("trace_pairs", 0.0) + ms.get("lazy_trace", 0.0),
-            "gen_kernels": ms.get("gen_terms", 0.0) + ms.get("lazy_gen", 0.0),
-            "per_pixel_kernels": ms.get("clear", 0.0) + ms.get("init_paths", 0.0) + ms.get("gather", 0.0) +
-                                 ms.get("lazy_check", 0.0) + ms.get("resolve", 0.0),
-        }
-        pmc = load_pmc(pkg, scene_name, W, H, D, world)
+        # one stage = one kernel (or a wait for the second stream); gen_splat / gen_connect run on the second stream and
+        # carry event pairs of their own ("side:" stages): a block's time is the sum of its KERNELS' times
+        kernel_ms, wait_ms, critical_ms = kernel_durations(ms)
+        pmc = load_pmc(pkg) if (scene_name == "atrium" and (W, H, D, world) == (1920, 1080, 8, 1)) else {}
         pmc_match = None if not pmc else not pmc.get("_mismatch", False)
         if pmc_match is False:
             pmc = {}
-        members = {"walk_kernel": ["walk_kernel"], "trace_shadow_kernel": ["trace_shadow_kernel"],
-                   "gen_kernels": ["gen_nee_kernel", "gen_splat_kernel", "gen_connect_kernel", "lazy_gen_kernel"],
-                   "per_pixel_kernels": ["init_paths_kernel", "gather_kernel", "lazy_check_kernel", "resolve_kernel"]}
-        # bytes the build really loads per unit: 48-byte records for nodes and triangles (bvh.h), a 28-byte ray + 1
-        # visibility byte per any-hit ray, origin + direction + 16-byte hit record per closest-hit ray, SURVEY's 388 B per shade
-        closest_rays = stat["raysEyeExtend"] + stat["raysLightExtend"]
-        fetched = {"walk_kernel": 44 * closest_rays + info.nodeBytes * stat["nodeVisitsClosest"] + info.triBytes * stat["triTestsClosest"] + 388 * closest_rays,
-                   "trace_shadow_kernel": 29 * n_shadow + info.nodeBytes * stat["nodeVisitsShadow"] + info.triBytes * stat["triTestsShadow"]}
-
-        def roof(name):
-            t_ms, by = kernel_ms[name], alg[name]
-            sec = t_ms * 1e-3
-            ach = by / sec / 1e9 if sec > 0 else 0.0
-            r = {"ms_per_frame": round(t_ms, 3), "bytes_per_frame": int(by), "achieved": round(ach, 1),
-                 "frac": round(ach / HBM_PEAK_GBS, 4)}
-            if r["frac"] > 1.0:
-                r["frac_note"] = "above 1: cache-served (algorithmic bytes exceed what leaves the chip's caches; see fractions)"
-            have = [pmc[k] for k in members[name] if k in pmc]
-            if not have or sec <= 0:
-                r["traffic"] = None
-                return r
-
-            def tot(c):
-                return sum(p.get(c, 0.0) for p in have)
-
-            # HBM / fabric side: 2 x FETCH_SIZE + WRITE_SIZE.  FETCH_SIZE tallies 64 B per 128-byte request on gfx950
-            # (MI355X_MICROARCH.md, measured there on coalesced streams); tools/microbench/fetch_calib.hip shows the same
-            # for 16-byte gathers (profiles/r3/fetch_calib.txt), so the factor applies to the traversal kernels too.
-            fetch_factor = pmc["_meta"].get("fetch_factor", {}).get(name, 2.0)
-            traffic = fetch_factor * tot("FETCH_SIZE_bytes") + tot("WRITE_SIZE_bytes")
-            r["traffic"] = int(traffic)
-            r["traffic_over_algorithmic"] = round(traffic / by, 3)
-            fr = {"hbm": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 3)}
-            if name in fetched:
-                fb = fetched[name]
-                r["fetched"] = {"bytes_per_frame": int(fb), "rate_gbs": round(fb / sec / 1e9, 1),
-                                "note": "bytes at the record sizes this build loads (48-B nodes and triangles) / time; most are served by L1 / L2"}
-                req = tot("TCP_TCC_READ_REQ_sum")
-                l1 = tot("TCP_TOTAL_CACHE_ACCESSES_sum")
-                miss = tot("TCC_MISS_sum")
-                r["l2_side"] = {"l1_to_l2_requests_per_frame": int(req), "request_bytes": 128,
-                                "rate_gbs": round(req * 128 / sec / 1e9, 1), "l2_gather_peak_gbs": L2_GATHER_GBS,
-                                "l2_misses_per_frame": int(miss), "fabric_rate_gbs": round(miss * 128 / sec / 1e9, 1),
-                                "infinity_cache_gather_peak_gbs": MALL_GATHER_GBS,
-                                "l1_hit": round(1.0 - req / l1, 3) if l1 else None,
-                                "l2_hit": round(1.0 - miss / max(1.0, tot("TCC_HIT_sum") + miss), 3)}
-                fr["l2_gather"] = round(req * 128 / sec / 1e9 / L2_GATHER_GBS, 3)
-                fr["infinity_cache_gather"] = round(miss * 128 / sec / 1e9 / MALL_GATHER_GBS, 3)
-                clks = sec * SHADER_CLK_HZ
-                lane_loads = l1 / (NUM_CUS * clks) if clks else 0.0
-                fast = tot("SQ_INSTS_VALU_FAST")
-                valu = tot("SQ_INSTS_VALU")
-                slow = max(0.0, valu - fast)
-                r["issue"] = {"lane_loads_per_clk_per_cu": round(lane_loads, 3), "lane_load_ceiling": LANE_LOADS_PER_CLK_PER_CU,
-                              "valu_wave_instructions_per_frame": int(valu), "valu_fast_share": round(fast / valu, 3) if valu else None,
-                              "valu_clk_fast_slow": [VALU_CLK_FAST, VALU_CLK_SLOW],
-                              "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / (64.0 * tot("SQ_ACTIVE_INST_VALU")), 3)
-                              if tot("SQ_ACTIVE_INST_VALU") else None,
-                              "wait_any": round(tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"), 3) if tot("SQ_WAVE_CYCLES") else None,
-                              "shader_clock_hz_assumed": SHADER_CLK_HZ}
-                fr["vmem_address_unit"] = round(lane_loads / LANE_LOADS_PER_CLK_PER_CU, 3)
-                fr["valu_issue"] = round((fast * VALU_CLK_FAST + slow * VALU_CLK_SLOW) / (NUM_SIMDS * clks), 3) if clks else None
-            r["fractions"] = fr
-            r["bound"] = max(((v, k) for k, v in fr.items() if v is not None), default=(0, "hbm"))[1]
-            return r
-
-        kernels = {k: roof(k) for k in kernel_ms}
+        kernels = roofline_kernels(kernel_ms, alg, fetched_bytes(stat, info), pmc)
         dominant = max(kernel_ms.items(), key=lambda kv: kv[1])[0]
-        frame_ms = sum(kernel_ms.values())
+        frame_ms = critical_ms  # the launch stream's stages, waits included: what one frame run alone takes
         frame_bytes = sum(alg.values())
         dom = kernels[dominant]
         closest_per_frame = (per_stage_rays.get("raysEyeExtend", 0) + per_stage_rays.get("raysLightExtend", 0)) / stage_frames
@@ -512,6 +568,9 @@ def main():
                            "exchange_exposed_ms": round(max(0.0, ex_plus_tail_ms - tail_ms), 3),
                            "per_rank": per_rank},
                 "rays_per_frame": int(rays_all / K),
+                # of which answered by an occluder hint (a triangle test instead of a traversal), and the rate without them
+                "rays_hinted_per_frame": int(hinted_all / K),
+                "value_traversals_only": round((rays_all - hinted_all) / elapsed_max / 1e6, 2),
                 "rays_reference_equivalent_per_frame": int(stat["pixelsValid"] * ((D + 1) ** 2 - 1) + n_pix_tile)
                 if world == 1 else None,
                 "bvh": {"nodes": info.numNodes, "node_bytes": info.nodeBytes, "tri_bytes": info.triBytes,
@@ -522,7 +581,8 @@ def main():
                                    "shadow_alpha_tests": round(stat["alphaTestsShadow"] / n_shadow, 3)},
                 "frames_in_flight": inflight,
                 "stage_timing": "HIP events over %d untimed frames run alone on rank 0's tile before the timed region "
-                                "(timed frames overlap each other)" % stage_frames,
+                                "(timed frames overlap each other); one stage = one kernel of the launch stream, a wait for the "
+                                "second stream (*_wait) or a kernel of the second stream (side:*, beside the stages before it)" % stage_frames,
                 "stage_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
                 "stage_mrays": {"walk_kernel": round(closest_per_frame / (kernel_ms["walk_kernel"] * 1e-3) / 1e6, 1)
                                 if kernel_ms["walk_kernel"] > 0 else None,
@@ -535,11 +595,15 @@ def main():
             "roofline": {
                 "kernel": dominant, "bound": dom.get("bound", "hbm"), "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac"], "traffic": dom.get("traffic"),
+                # HBM-side counter bytes (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s: beside the contract's `frac`,
+                # which prices cache-served bytes against HBM
+                "hbm_side_frac": dom.get("hbm_side_frac"),
                 "frac_note": dom.get("frac_note", "algorithmic bytes over HBM peak; see `fractions` for the ceilings that can bind"),
                 "fractions": dom.get("fractions"),
                 "peak_achievable_copy": 6290.0,  # float4 copy rate MI355X_MICROARCH.md reports (79 % of spec)
                 "bytes_per_frame": dom["bytes_per_frame"], "ms_per_frame": dom["ms_per_frame"],
                 "kernels": kernels,
+                "waits_ms_per_frame": round(wait_ms, 3),
                 "frame": {"ms_per_frame": round(frame_ms, 3), "bytes_per_frame": int(frame_bytes),
                           "achieved": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 1) if frame_ms > 0 else 0.0,
                           "frac": round(frame_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_ms > 0 else 0.0,
@@ -578,7 +642,7 @@ def main():
                         R1.step()
                     R1.barrier()
                     R1.rewind(*mark)
-                    dt1, rays1 = timed_frames(R1, pkg, args.steps)
+                    dt1, rays1, _ = timed_frames(R1, pkg, args.steps)
                     out["config"]["single_frame_in_flight"] = {
                         "frames_in_flight": 1, "value": round(rays1 / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 3),
                         "note": "same frames, one context, no host synchronisation either; informational (the kernels' solo durations of the roofline block add up to this loop)"}
@@ -595,11 +659,11 @@ def main():
     if rank == 0 and world == 1 and dist is None and args.other_configs and scene_name == "atrium" and (W, H, D) == (1920, 1080, 8):
         others = []
 
-        def other(name, make, w, h, d, m):
+        def other(name, make, w, h, d, m, pmc_sub=None):
             def run():
                 sc = make()
                 try:
-                    others.append(other_config(pkg, torch, name, sc, w, h, d, m, keep))
+                    others.append(other_config(pkg, torch, name, sc, w, h, d, m, keep, pmc_sub=pmc_sub))
                 finally:
                     sc.close()
             guarded(name.split(":")[0], run)
@@ -619,9 +683,10 @@ def main():
         finally:
             os.environ.pop("BDPT_SPLIT_BUDGET", None)
         other("BASELINE configs[3] shape on ONE GPU: 2.8 M triangles (atrium generator, Bistro stand-in) 3840x2160 depth 12",
-              lambda: pkg.Scene.atrium(1, 2800000), 3840, 2160, 12, 0)
+              lambda: pkg.Scene.atrium(1, 2800000), 3840, 2160, 12, 0, pmc_sub="config4")
         other("BASELINE configs[4] shape on ONE GPU: 10 M triangles, half of them alpha-masked leaf cards "
-              "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", lambda: pkg.Scene.courtyard(2, 10000000, 0.5), 3840, 2160, 16, 0)
+              "(courtyard generator, San Miguel stand-in) 3840x2160 depth 16", lambda: pkg.Scene.courtyard(2, 10000000, 0.5), 3840, 2160, 16, 0,
+              pmc_sub="config5")
         out["config"]["other_configs"] = others
     for p in keep + _CLOSE_LAST:
         p.close()

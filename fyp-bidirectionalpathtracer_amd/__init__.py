@@ -25,18 +25,23 @@ class BdptError(RuntimeError):
 
 
 def source_hash():
-    """SHA-256 over the sources libbdpt_amd.so is built from (csrc/*.{hip,hpp,h,cpp}, the host files linked into it and
-    the Makefile): ties hardware-counter files (profiles/<round>/roofline_pmc.json) to the build they were measured on."""
+    """SHA-256 over the sources libbdpt_amd.so is built from — exactly the Makefile's prerequisites: csrc/*.{hip,hpp,h,cpp},
+    the host files linked into it (host/Scene.cpp, Atrium.cpp, SceneLoader.cpp, ImageDecode.cpp: the scene generators and
+    the loader shape the measured workload), host/Scene.h, include/*.h and the Makefile.  Ties hardware-counter files
+    (profiles/<round>/roofline_pmc.json) to the build they were measured on."""
     import glob
     import hashlib
     import os
     here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
     files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.hpp")) +
                    glob.glob(os.path.join(here, "csrc", "*.h")) + glob.glob(os.path.join(here, "csrc", "*.cpp")) +
-                   [os.path.join(here, "csrc", "Makefile")])
+                   [os.path.join(here, "csrc", "Makefile")] +
+                   [os.path.join(here, "host", f) for f in ("Scene.cpp", "Atrium.cpp", "SceneLoader.cpp", "ImageDecode.cpp")] +
+                   [os.path.join(here, "host", "Scene.h")] + glob.glob(os.path.join(root, "include", "*.h")))
     h = hashlib.sha256()
     for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(os.path.relpath(f, root).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()
 

@@ -71,6 +71,12 @@ struct bdpt_ctx {
   const char* stageNames[kMaxStages]{};
   int numStages = 0;
   bool evCreated = false;
+  // kernels on the context's second stream (the splat and connection generators): their own event pairs, so that a
+  // kernel's time is the kernel's and the caller's stream shows the WAIT for it as a stage of its own
+  static constexpr int kMaxSideStages = 4;
+  hipEvent_t sideEv[2 * kMaxSideStages]{};
+  const char* sideNames[kMaxSideStages]{};
+  int numSideStages = 0;
   int lazyRounds = 3;
   LaunchGrids grids{};  // persistent-grid sizes for this context's device
   int* stackOvf = nullptr;      // overflow rows of the persistent kernels' traversal stacks (kernels.h kStackLds)
@@ -223,6 +229,17 @@ void stageMark(bdpt_ctx* c, hipStream_t st, const char* name) {
   c->numStages++;
   (void)hipEventRecord(c->ev[c->numStages], st);
 }
+// bracket of a kernel on the second stream: sideBegin before its launch, sideEnd after
+void sideBegin(bdpt_ctx* c, hipStream_t side, const char* name) {
+  if (!c->timing || c->numSideStages >= bdpt_ctx::kMaxSideStages) return;
+  c->sideNames[c->numSideStages] = name;
+  (void)hipEventRecord(c->sideEv[2 * c->numSideStages], side);
+}
+void sideEnd(bdpt_ctx* c, hipStream_t side) {
+  if (!c->timing || c->numSideStages >= bdpt_ctx::kMaxSideStages) return;
+  (void)hipEventRecord(c->sideEv[2 * c->numSideStages + 1], side);
+  c->numSideStages++;
+}
 
 }  // namespace
 
@@ -266,6 +283,8 @@ void bdpt_destroy(bdpt_ctx* c) {
   freePool(c->frameAllocs);
   if (c->evCreated)
     for (int i = 0; i <= kMaxStages; i++) (void)hipEventDestroy(c->ev[i]);
+  if (c->evCreated)
+    for (hipEvent_t e : c->sideEv) (void)hipEventDestroy(e);
   if (c->evFork) (void)hipEventDestroy(c->evFork);
   if (c->evJoin) (void)hipEventDestroy(c->evJoin);
   if (c->evSplat) (void)hipEventDestroy(c->evSplat);
@@ -799,6 +818,7 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
   c->P = P;
   if (!c->evCreated) {
     for (int i = 0; i <= kMaxStages; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    for (hipEvent_t& e : c->sideEv) HIPCHK(c, hipEventCreate(&e));
     c->evCreated = true;
   }
   c->haveSize = true;
@@ -947,6 +967,7 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   }
 
   c->numStages = 0;
+  c->numSideStages = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
   HIPCHK(c, hipMemsetAsync(P.qcount, 0, (size_t)kCursorWords * sizeof(uint32_t), st));
   HIPCHK(c, hipMemsetAsync(c->splat, 0, (size_t)c->sl.owners * c->sl.chunkRows * c->W * 4 * sizeof(unsigned long long), st));
@@ -967,25 +988,39 @@ int bdpt_execute(bdpt_ctx* c, const bdpt_params* p, const bdpt_gbuffer* in, floa
   const bool mis = (p->flags & (BDPT_PARAM_MIS_POWER | BDPT_PARAM_MIS_LINEAR)) != 0;
   if (mis) {
     launchMisPrefix(F, P, st);
+    stageMark(c, st, "mis_prefix");
     launchGenNee(c->S, F, P, st);
+    stageMark(c, st, "gen_nee");
     launchGenSplat(c->S, F, P, st);
+    stageMark(c, st, "gen_splat");
     launchGenConnect(c->S, F, P, st);
-    stageMark(c, st, "gen_terms");
+    stageMark(c, st, "gen_connect");
     launchTraceShadow(c->S, F, P, RAY_TERMS, c->grids, c->numCUs, st);
     stageMark(c, st, "trace_terms");
   } else {
+    // Stage names: a stage of the caller's stream is ONE kernel (or one memset group) — "gen_nee", "trace_terms",
+    // "trace_pairs" ... — or a wait for the second stream ("splat_wait", "connect_wait": what of gen_splat / gen_connect
+    // the caller's stream did not cover); the second stream's kernels are timed by event pairs of their own and reported
+    // behind the caller's stages as "side:gen_splat", "side:gen_connect" (they overlap the stages above: not part of the
+    // critical-path sum).
     HIPCHK(c, hipEventRecord(c->evFork, st));
     HIPCHK(c, hipStreamWaitEvent(c->walkStream, c->evFork, 0));
+    sideBegin(c, c->walkStream, "side:gen_splat");
     launchGenSplat(c->S, F, P, c->walkStream);  // beside the NEE generator; both are short and latency-bound
+    sideEnd(c, c->walkStream);
     HIPCHK(c, hipEventRecord(c->evSplat, c->walkStream));
+    sideBegin(c, c->walkStream, "side:gen_connect");
     launchGenConnect(c->S, F, P, c->walkStream);
+    sideEnd(c, c->walkStream);
     HIPCHK(c, hipEventRecord(c->evJoin, c->walkStream));
     launchGenNee(c->S, F, P, st);
+    stageMark(c, st, "gen_nee");
     HIPCHK(c, hipStreamWaitEvent(st, c->evSplat, 0));
-    stageMark(c, st, "gen_terms");
+    stageMark(c, st, "splat_wait");
     launchTraceShadow(c->S, F, P, RAY_TERMS, c->grids, c->numCUs, st);
     stageMark(c, st, "trace_terms");
     HIPCHK(c, hipStreamWaitEvent(st, c->evJoin, 0));
+    stageMark(c, st, "connect_wait");
   }
   launchTraceShadow(c->S, F, P, RAY_PAIRS, c->grids, c->numCUs, st);
   stageMark(c, st, "trace_pairs");
@@ -1292,6 +1327,13 @@ int bdpt_get_stage_times(bdpt_ctx* c, const char** names, float* ms, int cap) {
     float t = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
     ms[i] = t;
+  }
+  // the second stream's kernels, behind the caller's stages ("side:" names; the caller's stream joined them before its end)
+  for (int i = 0; i < c->numSideStages && n < cap; i++, n++) {
+    names[n] = c->sideNames[i];
+    float t = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->sideEv[2 * i], c->sideEv[2 * i + 1]));
+    ms[n] = t;
   }
   return n;
 }

@@ -482,7 +482,11 @@ int bdpt_get_counters(bdpt_ctx* ctx, bdpt_counters* out);
 
 /* Per-stage device time (ms) of the most recent bdpt_execute, measured with
  * HIP events on the launch stream.  names/ms hold up to `cap` entries; returns
- * the number written (>= 0) or a negative error. */
+ * the number written (>= 0) or a negative error.  A stage of the launch stream is one kernel ("walk", "gen_nee",
+ * "trace_terms", "trace_pairs", "gather", "lazy_gen", "lazy_trace" ...), one group of memsets ("clear") or a wait for
+ * the context's second stream ("splat_wait", "connect_wait"); their sum is the frame's critical path.  The kernels of
+ * the second stream follow with names that start with "side:" ("side:gen_splat", "side:gen_connect"), timed by event
+ * pairs on that stream: they run beside the stages above and are not part of that sum. */
 int bdpt_get_stage_times(bdpt_ctx* ctx, const char** names, float* ms, int cap);
 int bdpt_enable_stage_timing(bdpt_ctx* ctx, int enable);
 

@@ -354,31 +354,46 @@ def test_exported_scene_loads_back(pkg, exported_atrium):
 
 @pytest.mark.gpu
 def test_exported_scene_frame_matches_oracle_and_the_in_memory_scene(pkg, ob, exported_atrium):
-    """The exported-and-loaded atrium through the HIP path: bit-identical to the oracle on the same loaded scene (the
-    parity gate), and the same picture as the in-memory scene up to the noise of one sample per pixel (the importer
-    re-normalises normals, flips v and regenerates bitangents: last-place differences that a random walk amplifies)."""
+    """The exported-and-loaded atrium through the HIP path: (1) bit-identical to the oracle on the same loaded scene — the
+    parity gate; (2) the SAME PICTURE as the in-memory scene.  The importer re-normalises normals, flips v and regenerates
+    bitangents: last-place differences that send a 1-spp random walk elsewhere, so single frames of the two scenes are
+    different noise realisations (round 4: RMSE 0.027, 26 % identical pixels) and cannot be compared directly.  Their
+    MEANS can: with n independent frames each (frame counters 0x1337 + k) the two running means are two estimates of one
+    image when the scenes agree, so the RMSE of their difference is sqrt(2 / n) x the estimator's per-pixel deviation and
+    falls as 1 / sqrt(n) — r(64) = r(1) / 8 — while a wrong material, normal or texture coordinate leaves a bias b that
+    does not fall: r(n)^2 = r(1)^2 / n + b^2.  The bound asserted, r(64) <= 1.5 x r(1) / 8, therefore admits
+    b <= r(1) x sqrt(1.5^2 - 1) / 8 = 0.14 r(1), about 0.004 in linear radiance here; one material of the 24 000-triangle
+    hall off by 0.1 on a tenth of the image would already give b = 0.03.  (Round 4's "means within 5 %" over one frame
+    would have let that through.)"""
     import torch
     ex, src, back, _ = exported_atrium
-    W, H, D = 96, 54, 4
-    frames = {}
+    W, H, D, N = 96, 54, 4, 64
+    first, mean = {}, {}
     for name, sc in (("memory", src), ("loaded", back)):
-        pipe = pkg.FramePipeline(sc, W, H, max_depth=D, mat_index=1)
-        gp, p = pipe.render_frame()
+        pipe = pkg.FramePipeline(sc, W, H, max_depth=D, mat_index=1, accum_limit=1 << 20)
+        gp, p = pipe.render_frame(accumulate=True)
         torch.cuda.synchronize()
-        frames[name] = pipe.output.cpu().numpy().copy()
+        first[name] = pipe.output.cpu().numpy().copy()
         if name == "loaded":
             orc = ob.OracleRender(pkg.abi, sc.desc, W, H)
             orc.gbuffer(pipe.cam, gp)
             orc.bdpt(pipe.cam, p)
             orc.resolve()
             ref = orc.image()
-            assert np.array_equal(frames[name].view(np.uint32), ref.view(np.uint32)), f"{(frames[name] != ref).any(axis=-1).sum()} pixels differ"
+            assert np.array_equal(first[name].view(np.uint32), ref.view(np.uint32)), f"{(first[name] != ref).any(axis=-1).sum()} pixels differ"
             orc.close()
+        for _ in range(N - 1):
+            pipe.render_frame(accumulate=True)
+        torch.cuda.synchronize()
+        mean[name] = pipe.last_frame.cpu().numpy().copy()
         pipe.close()
-    # one sample per pixel: a last-place difference in a normal or a texture coordinate sends a random walk elsewhere, so
-    # the two frames are different noise realisations of (nearly) the same image — compare what is stable, the means
-    ma, mb = frames["memory"][..., :3].mean(), frames["loaded"][..., :3].mean()
-    assert abs(ma - mb) < 0.05 * ma, (float(ma), float(mb))
+
+    def rmse(a, b):
+        d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+        return float(np.sqrt(np.mean(d * d)))
+    r1, rn = rmse(first["memory"], first["loaded"]), rmse(mean["memory"], mean["loaded"])
+    assert r1 > 0.0, "the two scenes gave identical first frames: the comparison below would be vacuous"
+    assert rn <= 1.5 * r1 / np.sqrt(N), (r1, rn, r1 / np.sqrt(N))
 
 
 @pytest.mark.gpu

@@ -32,17 +32,19 @@ def run(name, scene, W, H, D, frames=3, mat=0):
     dt = (time.time() - t0) / frames
     pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
     c = pipe.ctx.counters().as_dict()
-    rays = sum(c[k] for k in ("raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect"))
+    hinted = c["hintedNee"] + c["hintedSplat"]  # any-hit queries answered by their occluder hint: queries, but not traversals
+    rays = sum(c[k] for k in ("raysPrimary", "raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")) + hinted
     shadow = max(1, c["raysNee"] + c["raysSplat"] + c["raysConnect"])
     closest = max(1, c["raysEyeExtend"] + c["raysLightExtend"])
     info = pipe.ctx.bvh_info()
     free, total = torch.cuda.mem_get_info()
     print("%s: %d triangles %dx%d depth %d | set-up %.1f s (%s) | %.1f ms/frame, %.0f Mrays/s, %.0f M rays/frame | stages %s | "
-          "visits/ray closest %.1f nodes %.1f tris %.2f alpha tests, shadow %.1f nodes %.1f tris %.2f alpha tests | bvh %d nodes depth %d | device memory in use %.1f GB" % (
+          "visits/ray closest %.1f nodes %.1f tris %.2f alpha tests, shadow %.1f nodes %.1f tris %.2f alpha tests | hinted %.1f M of %.1f M NEE, %.1f M of %.1f M light-tracing queries | bvh %d nodes depth %d | device memory in use %.1f GB" % (
               name, scene.desc.numTriangles, W, H, D, setup, ", ".join("%s %.2f" % (k, v) for k, v in pipe.setup_times.items()), dt * 1e3, rays / dt / 1e6, rays / 1e6,
               {k: round(v, 1) for k, v in agg.items() if v >= 0.05},
               c["nodeVisitsClosest"] / closest, c["triTestsClosest"] / closest, c["alphaTestsClosest"] / closest,
               c["nodeVisitsShadow"] / shadow, c["triTestsShadow"] / shadow, c["alphaTestsShadow"] / shadow,
+              c["hintedNee"] / 1e6, (c["hintedNee"] + c["raysNee"]) / 1e6, c["hintedSplat"] / 1e6, (c["hintedSplat"] + c["raysSplat"]) / 1e6,
               info.numNodes, info.maxDepth, (total - free) / 2 ** 30), flush=True)
     pipe.close()
 

@@ -24,6 +24,9 @@ def short(name):
 
 def main():
     out_json, dirs = sys.argv[1], sys.argv[2:]
+    command = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-pass --no-other-configs (tools/prof_pmc.sh)"
+    if dirs and dirs[0].startswith("--command="):
+        command = dirs.pop(0)[len("--command="):]
     per_pass = []
     for d in dirs:
         fs = glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv")
@@ -48,8 +51,7 @@ def main():
             launches[k].append(len(disp[k]) / frames)
             for c, v in cs.items():
                 kernels[k][c].append(v / frames)
-    out = {"command": "rocprofv3 --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-pass --no-other-configs "
-                      "(one run per counter set; tools/prof_pmc.sh)",
+    out = {"command": "rocprofv3 --pmc <counters> -- " + command + " (one run per counter set)",
            "unit": "counts per frame (all dispatches of the kernel in a frame summed); *_bytes = counter x 1024",
            # the build the counts belong to: bench.py drops them (pmc_build_match false) when its sources differ
            "source_hash": __import__("__graft_entry__").load_package().source_hash(),
@@ -66,6 +68,16 @@ def main():
         if all(c in e for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")):
             e["SQ_INSTS_VALU_FAST"] = e["SQ_INSTS_VALU_ADD_F32"] + e["SQ_INSTS_VALU_MUL_F32"] + e["SQ_INSTS_VALU_FMA_F32"]
         out["kernels"][k] = e
+    # Per frame by kernel NAME.  A frame runs ONE template variant of each kernel (the statistics frame the variant with
+    # the visit counters), so a variant's counts over ALL frames of the run understate what one of ITS frames costs
+    # (round 4's file: walk_kernel<true, false, false> ran in 6 of the 7 frames, 0.857 dispatches "per frame", and every
+    # count was 14 % low); summed over the variants of a name the counts are whole frames.
+    by_name = collections.defaultdict(lambda: collections.defaultdict(float))
+    for k, e in out["kernels"].items():
+        base = k.split("<")[0]
+        for c, v in e.items():
+            by_name[base][c] += v
+    out["by_name"] = {k: dict(v) for k, v in sorted(by_name.items())}
     json.dump(out, open(out_json, "w"), indent=1)
     for k, e in out["kernels"].items():
         if e["dispatches_per_frame"] >= 0.5:

@@ -23,10 +23,16 @@ pipe.render_frame(extra_flags=pkg.abi.PARAM_COUNTERS)
 c = pipe.ctx.counters().as_dict()
 info = pipe.ctx.bvh_info()
 tot = sum(agg.values())
-print("frame %.2f ms | walk %.2f gen_terms %.2f trace_terms %.2f trace_pairs %.2f lazy %.2f other %.2f | rays %.1fM" % (
-    tot, agg.get("walk", 0), agg.get("gen_terms", 0), agg.get("trace_terms", 0), agg.get("trace_pairs", 0),
+side = {k: v for k, v in agg.items() if k.startswith("side:")}  # kernels of the second stream: beside the stages, not in the sum
+for k in side:
+    del agg[k]
+tot = sum(agg.values())
+gen = agg.get("gen_nee", 0) + agg.get("splat_wait", 0)
+print("frame %.2f ms | walk %.2f gen_nee+wait %.2f trace_terms %.2f connect_wait %.2f trace_pairs %.2f lazy %.2f other %.2f | side: gen_splat %.2f gen_connect %.2f | rays %.1fM" % (
+    tot, agg.get("walk", 0), gen, agg.get("trace_terms", 0), agg.get("connect_wait", 0), agg.get("trace_pairs", 0),
     agg.get("lazy_gen", 0) + agg.get("lazy_trace", 0) + agg.get("lazy_check", 0),
-    tot - sum(agg.get(k, 0) for k in ("walk", "gen_terms", "trace_terms", "trace_pairs", "lazy_gen", "lazy_trace", "lazy_check")),
+    tot - gen - sum(agg.get(k, 0) for k in ("walk", "trace_terms", "connect_wait", "trace_pairs", "lazy_gen", "lazy_trace", "lazy_check")),
+    side.get("side:gen_splat", 0), side.get("side:gen_connect", 0),
     sum(c[k] for k in ("raysEyeExtend", "raysLightExtend", "raysNee", "raysSplat", "raysConnect")) / 1e6),
     "| visits/ray closest %.2f nodes %.2f tris, shadow %.2f nodes %.2f tris | sah %.2f nodes %d" % (
         c["nodeVisitsClosest"] / max(1, c["raysEyeExtend"] + c["raysLightExtend"]), c["triTestsClosest"] / max(1, c["raysEyeExtend"] + c["raysLightExtend"]),

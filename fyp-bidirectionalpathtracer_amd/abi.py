@@ -160,6 +160,11 @@ PROTOTYPES = {
     "bdpt_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bdpt_bmfr_execute": (C.c_int, [C.c_void_p, C.POINTER(BmfrParams), C.POINTER(GBuffer), C.c_void_p, C.c_void_p]),
     "bdpt_bmfr_reset": (C.c_int, [C.c_void_p]),
+    "bdpt_bmfr_history_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "bdpt_bmfr_save_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bdpt_bmfr_load_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bdpt_tile_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bdpt_tile_unpack": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bdpt_camera_view_proj": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "bdpt_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,

@@ -1054,13 +1054,8 @@ int bdpt_prepare(bdpt_ctx* c, uint32_t what) {
   ENTER(c);
   if (what & BDPT_PREPARE_PRIMARY)
     if (int rc = allocOwnGbuffer(c)) return rc;
-  if (what & BDPT_PREPARE_BMFR) {
-    if (c->tileRows != c->H) {
-      fail(c, "prepare: the denoiser works on the whole frame; this context renders a band");
-      return BDPT_E_STATE;
-    }
+  if (what & BDPT_PREPARE_BMFR)  // (whole-frame history also on a band / stripes context: bdpt_bmfr_execute takes whole-frame buffers)
     if (int rc = allocBmfrHistory(c)) return rc;
-  }
   return BDPT_OK;
 }
 
@@ -1069,10 +1064,6 @@ int bdpt_bmfr_execute(bdpt_ctx* c, const bdpt_bmfr_params* p, const bdpt_gbuffer
   if (!c || !p || !g || !noisy) return BDPT_E_INVALID;
   if (!c->haveSize) {
     fail(c, "bmfr: bdpt_resize must be called first");
-    return BDPT_E_STATE;
-  }
-  if (c->tileRows != c->H) {
-    fail(c, "bmfr: the denoiser works on the whole frame; this context renders a band");
     return BDPT_E_STATE;
   }
   if (!g->worldPosition || !g->worldNormal || !g->materialDiffuse) {
@@ -1134,6 +1125,73 @@ int bdpt_bmfr_reset(bdpt_ctx* c) {
   HIPCHK(c, hipMemset(c->bmfrAccept, 0, n));
   HIPCHK(c, hipMemset(c->bmfrPrevPixel, 0, n * sizeof(uint32_t)));
   c->bmfrRead = 0;
+  return BDPT_OK;
+}
+
+// [pos | norm | noisy | filtered] of the read side, W * H float4 each
+int bdpt_bmfr_history_bytes(const bdpt_ctx* c, uint64_t* out_bytes) {
+  if (!c || !out_bytes) return BDPT_E_INVALID;
+  *out_bytes = (c->haveSize && c->bmfrAccept) ? (uint64_t)c->W * c->H * sizeof(float4) * 4 : 0;
+  return BDPT_OK;
+}
+int bdpt_bmfr_save_history(bdpt_ctx* c, void* blob, uint64_t bytes) {
+  if (!c || !blob) return BDPT_E_INVALID;
+  if (!c->haveSize || !c->bmfrAccept) {
+    fail(c, "bmfr_save_history: no history (the denoiser has not run on this context)");
+    return BDPT_E_STATE;
+  }
+  const size_t plane = (size_t)c->W * c->H * sizeof(float4);
+  if (bytes < 4 * plane) return BDPT_E_INVALID;
+  ENTER(c);
+  HIPCHK(c, hipStreamSynchronize(c->lastStream));
+  const int r = c->bmfrRead;
+  const float4* src[4] = {c->bmfrPos[r], c->bmfrNorm[r], c->bmfrNoisy[r], c->bmfrFiltered[r]};
+  for (int k = 0; k < 4; k++) HIPCHK(c, hipMemcpy(static_cast<uint8_t*>(blob) + k * plane, src[k], plane, hipMemcpyDeviceToHost));
+  return BDPT_OK;
+}
+int bdpt_bmfr_load_history(bdpt_ctx* c, const void* blob, uint64_t bytes) {
+  if (!c || !blob) return BDPT_E_INVALID;
+  if (!c->haveSize) {
+    fail(c, "bmfr_load_history: bdpt_resize must be called first");
+    return BDPT_E_STATE;
+  }
+  const size_t plane = (size_t)c->W * c->H * sizeof(float4);
+  if (bytes != 4 * plane) {
+    fail(c, "bmfr_load_history: the blob was written for another frame size");
+    return BDPT_E_INVALID;
+  }
+  ENTER(c);
+  if (int rc = allocBmfrHistory(c)) return rc;  // (resets: read side 0)
+  HIPCHK(c, hipStreamSynchronize(c->lastStream));
+  const int r = c->bmfrRead;
+  float4* dst[4] = {c->bmfrPos[r], c->bmfrNorm[r], c->bmfrNoisy[r], c->bmfrFiltered[r]};
+  for (int k = 0; k < 4; k++) HIPCHK(c, hipMemcpy(dst[k], static_cast<const uint8_t*>(blob) + k * plane, plane, hipMemcpyHostToDevice));
+  return BDPT_OK;
+}
+
+int bdpt_tile_pack(bdpt_ctx* c, const void* frame, void* packed, uint32_t bytesPerPixel, void* stream) {
+  if (!c || !frame || !packed || (bytesPerPixel != 4 && bytesPerPixel != 8 && bytesPerPixel != 16)) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  ENTER(c);
+  launchTilePack(frame, packed, bytesPerPixel, c->P.pix, c->P.Np, reinterpret_cast<hipStream_t>(stream));
+  HIPCHK(c, hipGetLastError());
+  return BDPT_OK;
+}
+int bdpt_tile_unpack(bdpt_ctx* c, uint32_t owner, const void* packed, void* frame, uint32_t bytesPerPixel, void* stream) {
+  if (!c || !frame || !packed || (bytesPerPixel != 4 && bytesPerPixel != 8 && bytesPerPixel != 16)) return BDPT_E_INVALID;
+  if (!c->haveSize) return BDPT_E_STATE;
+  ENTER(c);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (c->stripes.stripeRows == 0) {  // a band: its rows are one run
+    if (owner != 0) return BDPT_E_INVALID;
+    if (c->tileRows)
+      HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t*>(frame) + (size_t)c->rowRanges.front().first * c->W * bytesPerPixel, packed,
+                               (size_t)c->tileRows * c->W * bytesPerPixel, hipMemcpyDeviceToDevice, st));
+    return BDPT_OK;
+  }
+  if (owner >= c->stripes.numOwners) return BDPT_E_INVALID;
+  launchTileUnpack(packed, frame, bytesPerPixel, c->W, c->H, c->stripes.stripeRows, c->stripes.numOwners, owner, c->sl.chunkRows, st);
+  HIPCHK(c, hipGetLastError());
   return BDPT_OK;
 }
 

@@ -227,6 +227,10 @@ void launchResolve(const unsigned long long* splat, bool tileLocal, uint32_t spl
 void launchAccumulate(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, uint64_t numTexels, hipStream_t st);
 void launchAccumulateTile(float* last, float* cur, uint32_t accumCount, uint32_t maxAccum, const uint32_t* pix, uint32_t Np,
                           hipStream_t st);
+// rows of a tile <-> a contiguous run (bdpt_tile_pack / bdpt_tile_unpack): elements of 4, 8 or 16 bytes
+void launchTilePack(const void* frame, void* packed, uint32_t bytesPerPixel, const uint32_t* pix, uint32_t Np, hipStream_t st);
+void launchTileUnpack(const void* packed, void* frame, uint32_t bytesPerPixel, uint32_t W, uint32_t H, uint32_t stripeRows, uint32_t owners,
+                      uint32_t owner, uint32_t packedRows, hipStream_t st);
 void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t draws, uint32_t* states, float* floats,
                    hipStream_t st);
 void launchTestTrace(const SceneDev& S, const float* rays, uint32_t n, int mode, int32_t* prim, float* tuv, hipStream_t st);

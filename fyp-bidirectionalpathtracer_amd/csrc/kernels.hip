@@ -1641,6 +1641,44 @@ void launchAccumulateTile(float* last, float* cur, uint32_t accumCount, uint32_t
   hipLaunchKernelGGL(accumulate_tile_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4*>(last), reinterpret_cast<float4*>(cur),
                      accumCount, maxAccum, pix, Np);
 }
+template <class T>
+__global__ void tile_pack_kernel(const T* __restrict__ frame, T* __restrict__ packed, const uint32_t* __restrict__ pix, uint32_t Np) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Np) packed[i] = frame[pix[i]];
+}
+// packed row r of owner o: stripe k = r / R of that owner = frame stripe k * owners + o, row r % R within it
+template <class T>
+__global__ void tile_unpack_kernel(const T* __restrict__ packed, T* __restrict__ frame, uint32_t W, uint32_t H, uint32_t R, uint32_t owners,
+                                   uint32_t owner, uint32_t packedRows) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)packedRows * W) return;
+  const uint32_t r = (uint32_t)(i / W), x = (uint32_t)(i - (size_t)r * W);
+  const uint32_t y = ((r / R) * owners + owner) * R + r % R;
+  if (y < H) frame[(size_t)y * W + x] = packed[i];
+}
+void launchTilePack(const void* frame, void* packed, uint32_t bpp, const uint32_t* pix, uint32_t Np, hipStream_t st) {
+  if (!Np) return;
+  const dim3 g((Np + 255) / 256), b(256);
+  if (bpp == 16)
+    hipLaunchKernelGGL(tile_pack_kernel<uint4>, g, b, 0, st, (const uint4*)frame, (uint4*)packed, pix, Np);
+  else if (bpp == 8)
+    hipLaunchKernelGGL(tile_pack_kernel<uint2>, g, b, 0, st, (const uint2*)frame, (uint2*)packed, pix, Np);
+  else
+    hipLaunchKernelGGL(tile_pack_kernel<uint32_t>, g, b, 0, st, (const uint32_t*)frame, (uint32_t*)packed, pix, Np);
+}
+void launchTileUnpack(const void* packed, void* frame, uint32_t bpp, uint32_t W, uint32_t H, uint32_t R, uint32_t owners, uint32_t owner,
+                      uint32_t packedRows, hipStream_t st) {
+  const size_t n = (size_t)packedRows * W;
+  if (!n) return;
+  const dim3 g((uint32_t)((n + 255) / 256)), b(256);
+  if (bpp == 16)
+    hipLaunchKernelGGL(tile_unpack_kernel<uint4>, g, b, 0, st, (const uint4*)packed, (uint4*)frame, W, H, R, owners, owner, packedRows);
+  else if (bpp == 8)
+    hipLaunchKernelGGL(tile_unpack_kernel<uint2>, g, b, 0, st, (const uint2*)packed, (uint2*)frame, W, H, R, owners, owner, packedRows);
+  else
+    hipLaunchKernelGGL(tile_unpack_kernel<uint32_t>, g, b, 0, st, (const uint32_t*)packed, (uint32_t*)frame, W, H, R, owners, owner, packedRows);
+}
+
 void launchTestRng(const uint32_t* v0, const uint32_t* v1, uint32_t n, uint32_t draws, uint32_t* states, float* floats,
                    hipStream_t st) {
   if (!n) return;

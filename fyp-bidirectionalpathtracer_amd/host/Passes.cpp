@@ -13,6 +13,20 @@
 
 namespace bdpt {
 
+// ---- checkpoint byte helpers (RenderingPipeline::saveCheckpoint / the passes' saveState)
+namespace {
+constexpr uint32_t kCheckpointMagic = 0x42445054u;  // "BDPT"
+constexpr uint32_t kCheckpointVersion = 2u;
+void put32(std::vector<uint8_t>& o, uint32_t v) {
+  for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i)));
+}
+void put64(std::vector<uint8_t>& o, uint64_t v) {
+  for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i)));
+}
+uint32_t get32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t get64(const uint8_t* p) { return (uint64_t)get32(p) | ((uint64_t)get32(p + 4) << 32); }
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
 // HostTypes
 // ------------------------------------------------------------------------------------------------
@@ -681,12 +695,6 @@ void BlockwiseMultiOrderFeatureRegression::execute(RenderContext* pRenderContext
   if (!mpResManager || !mpRays) return;
   Texture::SharedPtr inputTexture = mpResManager->getTexture(mDenoiseChannel);
   if (!inputTexture || !mDoDenoise) return;
-  if (mpRays->tiled()) {  // the filter's blocks need their neighbours: it works on the whole frame, a rank holds its stripes
-    static bool told = false;
-    if (!told) std::fprintf(stderr, "[BMFR] skipped: a tiled pipeline holds only its own rows; denoise the gathered frame\n");
-    told = true;
-    return;
-  }
   Texture::SharedPtr pos = mpResManager->getTexture("WorldPosition"), nrm = mpResManager->getTexture("WorldNormal"),
                      alb = mpResManager->getTexture("MaterialDiffuse");
   if (!pos || !nrm || !alb || !mpScene || !mpScene->getActiveCamera()) return;
@@ -700,11 +708,98 @@ void BlockwiseMultiOrderFeatureRegression::execute(RenderContext* pRenderContext
   gb.worldPosition = (float*)pos->getDevicePointer();
   gb.worldNormal = (uint16_t*)nrm->getDevicePointer();
   gb.materialDiffuse = (uint16_t*)alb->getDevicePointer();
-  if (bdpt_bmfr_execute(mpRays->ctx(), &p, &gb, (float*)inputTexture->getDevicePointer(), pRenderContext->getStream()) != BDPT_OK) {
+  float* noisy = (float*)inputTexture->getDevicePointer();
+  if (mpRays->tiled()) {  // a rank holds its stripes: gather the whole frame of all four channels first
+    if (!gatherWholeFrame(pRenderContext, inputTexture, pos, nrm, alb)) {
+      std::fprintf(stderr, "[BMFR] gathering the frame failed: %s\n", mpRays->exchange()->lastError().c_str());
+      return;
+    }
+    gb.worldPosition = mFullPos;
+    gb.worldNormal = mFullNorm;
+    gb.materialDiffuse = mFullAlb;
+    noisy = mFullNoisy;
+  }
+  if (bdpt_bmfr_execute(mpRays->ctx(), &p, &gb, noisy, pRenderContext->getStream()) != BDPT_OK) {
     std::fprintf(stderr, "[BMFR] %s\n", mpRays->lastError());
     return;
   }
+  if (mpRays->tiled())  // every rank filtered the same whole frame: its output channel now holds all rows of it
+    (void)hipMemcpyAsync(inputTexture->getDevicePointer(), mFullNoisy, (size_t)mGatherW * mGatherH * 16, hipMemcpyDeviceToDevice, pRenderContext->getStream());
   mAccumCount++;
+}
+void BlockwiseMultiOrderFeatureRegression::freeGather() {
+  for (void* q : {(void*)mPackedMine, (void*)mPackedAll, (void*)mFullNoisy, (void*)mFullPos, (void*)mFullNorm, (void*)mFullAlb})
+    if (q) (void)hipFree(q);
+  mPackedMine = mPackedAll = nullptr;
+  mFullNoisy = mFullPos = nullptr;
+  mFullNorm = mFullAlb = nullptr;
+  mGatherW = mGatherH = 0;
+}
+// A rank's chunk of the all-gather: [noisy 16 B | position 16 B | normal 8 B | albedo 8 B] x (chunkRows x W) pixels, channel
+// after channel; chunkRows is the same on every rank (bdpt_get_tile_info), rows past a rank's own are padding that
+// bdpt_tile_unpack maps outside the frame and skips.  Collective: every rank's denoiser runs every frame.
+bool BlockwiseMultiOrderFeatureRegression::gatherWholeFrame(RenderContext* pRenderContext, Texture::SharedPtr noisy, Texture::SharedPtr pos,
+                                                            Texture::SharedPtr nrm, Texture::SharedPtr alb) {
+  const uint32_t W = noisy->getWidth(), H = noisy->getHeight(), world = mpRays->exchange()->world();
+  const size_t px = (size_t)mpRays->tileInfo().chunkRows * W, chunk = px * 48;
+  static const uint32_t kBpp[4] = {16, 16, 8, 8};
+  if (mGatherW != W || mGatherH != H) {
+    freeGather();
+    const size_t n = (size_t)W * H;
+    if (hipMalloc((void**)&mPackedMine, std::max<size_t>(chunk, 16)) != hipSuccess || hipMalloc((void**)&mPackedAll, std::max<size_t>(chunk * world, 16)) != hipSuccess ||
+        hipMalloc((void**)&mFullNoisy, n * 16) != hipSuccess || hipMalloc((void**)&mFullPos, n * 16) != hipSuccess ||
+        hipMalloc((void**)&mFullNorm, n * 8) != hipSuccess || hipMalloc((void**)&mFullAlb, n * 8) != hipSuccess) {
+      freeGather();
+      return false;
+    }
+    mGatherW = W;
+    mGatherH = H;
+  }
+  hipStream_t st = pRenderContext->getStream();
+  const void* src[4] = {noisy->getDevicePointer(), pos->getDevicePointer(), nrm->getDevicePointer(), alb->getDevicePointer()};
+  void* full[4] = {mFullNoisy, mFullPos, mFullNorm, mFullAlb};
+  size_t off = 0;
+  for (int k = 0; k < 4; k++) {
+    if (bdpt_tile_pack(mpRays->ctx(), src[k], mPackedMine + off, kBpp[k], st) != BDPT_OK) return false;
+    off += px * kBpp[k];
+  }
+  if (!mpRays->exchange()->allGather((const float*)mPackedMine, (float*)mPackedAll, chunk / 4, st)) return false;
+  for (uint32_t r = 0; r < world; r++) {
+    off = 0;
+    for (int k = 0; k < 4; k++) {
+      if (bdpt_tile_unpack(mpRays->ctx(), r, mPackedAll + (size_t)r * chunk + off, full[k], kBpp[k], st) != BDPT_OK) return false;
+      off += px * kBpp[k];
+    }
+  }
+  return true;
+}
+// [frame number][history bytes][history]: the denoiser switched off, or not run yet, saves no history
+void BlockwiseMultiOrderFeatureRegression::saveState(RenderContext*, std::vector<uint8_t>& out) {
+  put32(out, mAccumCount);
+  uint64_t bytes = 0;
+  if (mDoDenoise && mpRays) (void)bdpt_bmfr_history_bytes(mpRays->ctx(), &bytes);
+  std::vector<uint8_t> blob((size_t)bytes);
+  if (bytes && bdpt_bmfr_save_history(mpRays->ctx(), blob.data(), bytes) != BDPT_OK) {
+    std::fprintf(stderr, "[BMFR] %s\n", mpRays->lastError());
+    blob.clear();
+  }
+  put64(out, blob.size());
+  out.insert(out.end(), blob.begin(), blob.end());
+}
+bool BlockwiseMultiOrderFeatureRegression::loadState(RenderContext*, const uint8_t* data, size_t size) {
+  if (size < 12) return false;
+  const uint64_t bytes = get64(data + 4);
+  if (bytes != size - 12) return false;
+  if (bytes) {
+    if (!mpRays || !mpResManager) return false;
+    if (!mpRays->ensureSize(mpResManager->getScreenSize().x, mpResManager->getScreenSize().y)) return false;
+    if (bdpt_bmfr_load_history(mpRays->ctx(), data + 12, bytes) != BDPT_OK) {
+      std::fprintf(stderr, "[BMFR] %s\n", mpRays->lastError());
+      return false;
+    }
+  }
+  mAccumCount = get32(data);
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -770,7 +865,7 @@ std::string RenderingPipeline::rankPath(const std::string& path) const {
 bool RenderingPipeline::inFlightActive() {
   if (mFramesInFlight <= 1 || mSlotStreams.empty()) return false;
   for (auto& p : mActivePasses)
-    if (p && p->onHasUnsavedCrossFrameState()) return false;  // a pass with temporal state of its own needs the frames one by one
+    if (p && (p->onHasUnsavedCrossFrameState() || p->onHoldsTemporalState())) return false;  // a pass with temporal state of its own needs the frames one by one
   return true;
 }
 void RenderingPipeline::setPass(uint32_t passNum, RenderPass::SharedPtr pTargetPass) {
@@ -846,19 +941,7 @@ void RenderingPipeline::renderFrame() {
   }
   mFrameIndex++;
 }
-// ---- checkpoints
-namespace {
-constexpr uint32_t kCheckpointMagic = 0x42445054u;  // "BDPT"
-constexpr uint32_t kCheckpointVersion = 2u;
-void put32(std::vector<uint8_t>& o, uint32_t v) {
-  for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i)));
-}
-void put64(std::vector<uint8_t>& o, uint64_t v) {
-  for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i)));
-}
-uint32_t get32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-uint64_t get64(const uint8_t* p) { return (uint64_t)get32(p) | ((uint64_t)get32(p + 4) << 32); }
-}  // namespace
+// ---- checkpoints (byte helpers: top of the file)
 
 static uint32_t floatBits(float f) {
   uint32_t u;

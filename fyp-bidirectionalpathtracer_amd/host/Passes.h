@@ -161,6 +161,7 @@ class BlockwiseMultiOrderFeatureRegression : public RenderPass {
     return SharedPtr(new BlockwiseMultiOrderFeatureRegression(bufferToDenoise));
   }
   uint32_t getAccumCount() const { return mAccumCount; }
+  ~BlockwiseMultiOrderFeatureRegression() override { freeGather(); }
 
  protected:
   BlockwiseMultiOrderFeatureRegression(const std::string& bufferToDenoise) : RenderPass("BMFR Denoise Pass", "BMFR Denoise Options") {
@@ -173,9 +174,17 @@ class BlockwiseMultiOrderFeatureRegression : public RenderPass {
   void resize(uint32_t width, uint32_t height) override;
   bool appliesPostprocess() override { return true; }
   bool hasAnimation() override { return false; }
-  // the temporal history (frame number, previous position / normal / noisy / filtered frames, accept masks) lives
-  // inside the context and has no serializer: a pipeline with the denoiser switched on cannot be checkpointed
-  bool hasUnsavedCrossFrameState() override { return mDoDenoise; }
+  // The temporal history (previous position / normal / noisy / filtered frames) lives inside the launcher context: frames
+  // run one by one while the denoiser is on, and a checkpoint carries the history (bdpt_bmfr_save_history) beside the
+  // frame number.
+  bool holdsTemporalState() override { return mDoDenoise; }
+  void saveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) override;
+  bool loadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) override;
+  // Tiled (RenderingPipeline::setTiling): the filter's blocks need their neighbours, so every rank gathers the WHOLE
+  // noisy frame and the three feature channels (its rows packed, one all-gather, the rows put back) and filters the
+  // same whole frame; the result replaces the rank's output channel, all rows of it.
+  bool gatherWholeFrame(RenderContext* pRenderContext, Texture::SharedPtr noisy, Texture::SharedPtr pos, Texture::SharedPtr nrm, Texture::SharedPtr alb);
+  void freeGather();
 
   std::string mDenoiseChannel;
   RayLaunch::SharedPtr mpRays;
@@ -186,6 +195,11 @@ class BlockwiseMultiOrderFeatureRegression : public RenderPass {
   bool mBMFR_regression = false;
   bool mBMFR_removeFeatures = true;
   uint32_t mAccumCount = 0;
+  // tiled: this rank's packed rows of the four channels, all ranks' (after the all-gather), and the whole-frame copies
+  uint8_t *mPackedMine = nullptr, *mPackedAll = nullptr;
+  float *mFullNoisy = nullptr, *mFullPos = nullptr;
+  uint16_t *mFullNorm = nullptr, *mFullAlb = nullptr;
+  uint32_t mGatherW = 0, mGatherH = 0;
 };
 
 // Headless counterpart of SharedUtils/RenderingPipeline (setPass + per-frame loop,

@@ -106,6 +106,9 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   // true when the pass carries state from frame to frame that saveState does NOT capture: a pipeline holding such a
   // pass refuses to write or read a checkpoint instead of resuming into a silently different sequence
   virtual bool hasUnsavedCrossFrameState() { return false; }
+  // true when a frame of this pass reads what its previous frame left behind (the denoiser's history): the pipeline then
+  // runs the frames one by one instead of keeping several in flight
+  virtual bool holdsTemporalState() { return false; }
   // true when the pass must see the frames in their order (the running mean): with frames in flight the pipeline
   // makes this pass of frame f + 1 wait for the same pass of frame f; every other pass only depends on its own frame
   virtual bool needsFrameOrder() { return false; }
@@ -135,6 +138,7 @@ class RenderPass : public std::enable_shared_from_this<RenderPass> {
   void onSaveState(RenderContext* pRenderContext, std::vector<uint8_t>& out) { saveState(pRenderContext, out); }
   bool onLoadState(RenderContext* pRenderContext, const uint8_t* data, size_t size) { return loadState(pRenderContext, data, size); }
   bool onHasUnsavedCrossFrameState() { return hasUnsavedCrossFrameState(); }
+  bool onHoldsTemporalState() { return holdsTemporalState(); }
   bool onNeedsFrameOrder() { return needsFrameOrder(); }
 
   void setName(const std::string& name) { mName = name; }

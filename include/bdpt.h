@@ -465,11 +465,37 @@ typedef struct bdpt_bmfr_params {
 /* One execute() of the denoise pass on `noisy` (full-frame RGBA32F, in/out: the channel being
  * denoised) with the G-buffer's WorldPosition / WorldNormal / MaterialDiffuse as features.  History
  * (previous position, normal, noisy and filtered frames, accept masks) lives in the context; it is allocated
- * by bdpt_prepare(BDPT_PREPARE_BMFR) or by the first call (not inside a stream capture: BDPT_E_STATE). */
+ * by bdpt_prepare(BDPT_PREPARE_BMFR) or by the first call (not inside a stream capture: BDPT_E_STATE).
+ * The filter's blocks need their neighbours, so ALL FOUR buffers must hold the WHOLE frame, also when the context
+ * renders only a band or the stripes of one rank: a tiled host gathers them first (bdpt_tile_pack -> all-gather ->
+ * bdpt_tile_unpack; host/Passes.cpp BlockwiseMultiOrderFeatureRegression::execute) and every rank filters the same
+ * whole frame. */
 int bdpt_bmfr_execute(bdpt_ctx* ctx, const bdpt_bmfr_params* p, const bdpt_gbuffer* features, float* noisy, void* stream);
 
 /* Forget the history (BlockwiseMultiOrderFeatureRegression::resize / initScene set mAccumCount = 0). */
 int bdpt_bmfr_reset(bdpt_ctx* ctx);
+
+/* The denoiser's state that crosses frames — the previous frame's position, normal, noisy and filtered images, what the
+ * next bdpt_bmfr_execute reads — as one host blob, so that a host can checkpoint a pipeline with the denoiser on
+ * (the reference keeps these in textures of the pass, DenoisePass.h:40-66, and has no checkpoints at all).
+ * bdpt_bmfr_history_bytes: the blob's size for this context's frame (0 before the history exists).
+ * save: synchronises the last stream used; `bytes` must be at least that size.  load: allocates the history if need
+ * be; `bytes` must be exactly that size (BDPT_E_INVALID otherwise: a blob of another frame size). */
+int bdpt_bmfr_history_bytes(const bdpt_ctx* ctx, uint64_t* out_bytes);
+int bdpt_bmfr_save_history(bdpt_ctx* ctx, void* host_blob, uint64_t bytes);
+int bdpt_bmfr_load_history(bdpt_ctx* ctx, const void* host_blob, uint64_t bytes);
+
+/* Rows of a tile as one contiguous run, and back: `frame` is a whole-frame buffer of `bytesPerPixel` (4, 8 or 16) bytes
+ * per pixel, `packed` holds rows of `width` pixels.
+ * bdpt_tile_pack:   packed[i] = frame[pixel i of this context's tile] (its rows in ascending order: the order of a
+ *                   stripes context's chunk of an all-gather).
+ * bdpt_tile_unpack: the rows of owner `owner` of this context's stripe layout (bdpt_resize_stripes; a band context has
+ *                   the one owner 0) go from `packed` (numRows of that owner, in order; rows the padding of a chunk
+ *                   stands for lie outside the frame and are skipped) back to their places in `frame`.
+ * What a tiled host needs around an all-gather of tile framebuffers when the gathered frame
+ * stays on the device (the denoiser); RenderingPipeline::readOutput does the same on the host. */
+int bdpt_tile_pack(bdpt_ctx* ctx, const void* frame, void* packed, uint32_t bytesPerPixel, void* stream);
+int bdpt_tile_unpack(bdpt_ctx* ctx, uint32_t owner, const void* packed, void* frame, uint32_t bytesPerPixel, void* stream);
 
 /* projMat * viewMat of Falcor's camera without the jitter matrix (glm::perspective * glm::lookAt,
  * Camera.cpp:77-105), row-major as bdpt_bmfr_params::prevViewProj wants it.  Host only. */

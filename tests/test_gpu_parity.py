@@ -837,6 +837,52 @@ def test_cpp_host_tiled_over_rccl_reproduces_the_plain_run(pkg, tmp_path):
     assert r.returncode == 0 and "frame gathered on every rank" in r.stdout, r.stderr + r.stdout
 
 
+def test_cpp_host_denoiser_under_tiling_and_across_a_checkpoint(pkg, tmp_path):
+    """The reference's four-pass pipeline (BidirectionalPathtracing/Main.cpp:15-18: G-buffer, BDPT, accumulation, BMFR) under
+    `bdpt_render --gpus N`: a rank holds only its stripes, the filter's blocks need their neighbours, so the tiled denoiser
+    gathers the whole noisy frame and the three feature channels (bdpt_tile_pack -> ncclAllGather -> bdpt_tile_unpack) and
+    every rank filters the same frame.  Through the real one-rank communicator, as threads and as a process, the denoised
+    image must equal the plain denoised run bit for bit — and so must a run cut in two by a checkpoint, which now carries
+    the denoiser's history (bdpt_bmfr_save_history / _load_history), tiled or not."""
+    import os
+    import subprocess
+    import __graft_entry__ as ge
+    exe = os.path.join(ge.PKG_DIR, "host", "bdpt_render")
+    assert os.path.exists(exe)
+    common = ["--scene", "atrium", "--width", "160", "--height", "90", "--depth", "4", "--frames", "5", "--denoise-regression",
+              "--out", str(tmp_path / "o.pfm")]
+
+    def run(extra, raw):
+        r = subprocess.run([exe] + common + extra + ["--raw", str(tmp_path / raw)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "[BMFR] skipped" not in r.stderr
+        return np.fromfile(tmp_path / raw, np.float32)
+
+    plain = run([], "plain.f32")
+    noisy = subprocess.run([exe] + [a for a in common if a != "--denoise-regression"] + ["--raw", str(tmp_path / "noisy.f32")],
+                           capture_output=True, text=True, timeout=300)
+    assert noisy.returncode == 0
+    assert not np.array_equal(plain, np.fromfile(tmp_path / "noisy.f32", np.float32)), "the denoiser did nothing"
+    assert plain.size == 160 * 90 * 4 and np.isfinite(plain).all()
+    tiled = run(["--gpus", "1"], "tiled.f32")
+    assert np.array_equal(plain.view(np.uint32), tiled.view(np.uint32)), int((plain != tiled).sum())
+    proc = run(["--rank", "0", "--world", "1", "--id-file", str(tmp_path / "nccl.id"), "--job-id", "t1"], "proc.f32")
+    assert np.array_equal(plain.view(np.uint32), proc.view(np.uint32)), int((plain != proc).sum())
+    assert not os.path.exists(str(tmp_path / "nccl.id")), "the id file is single-use: rank 0 removes it once the communicator is up"
+    # the history crosses a checkpoint: 2 + 3 frames = 5 frames
+    run(["--frames", "2", "--checkpoint", str(tmp_path / "d.ckpt")], "part.f32")
+    res = run(["--frames", "3", "--resume", str(tmp_path / "d.ckpt")], "res.f32")
+    assert np.array_equal(plain.view(np.uint32), res.view(np.uint32)), int((plain != res).sum())
+    run(["--gpus", "1", "--frames", "2", "--checkpoint", str(tmp_path / "t.ckpt")], "tpart.f32")
+    tres = run(["--gpus", "1", "--frames", "3", "--resume", str(tmp_path / "t.ckpt")], "tres.f32")
+    assert np.array_equal(plain.view(np.uint32), tres.view(np.uint32)), int((plain != tres).sum())
+    # a rank whose set-up or read-back fails takes the job down promptly instead of leaving it waiting (ADVICE r4)
+    for stage in ("setup", "readback"):
+        env = dict(os.environ, BDPT_RENDER_INJECT_FAILURE="0:" + stage)
+        r = subprocess.run([exe] + common + ["--gpus", "1"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode != 0, stage
+
+
 def test_per_piece_alpha_classification_on_the_device(pkg, ob):
     """The acceleration structure bdpt_set_scene uploads is built over clipped / dropped pieces (csrc/alpha_clip.cpp):
     a card whose texels all fail leaves an EMPTY tree (every ray misses: the frame is the environment colour), one with

@@ -81,10 +81,17 @@ class Scene:
         return cls(load_library().bdpt_scene_create_soup(seed, num_triangles, max_edge))
 
     @classmethod
-    def load(cls, path):
-        """`.fscene` / `.obj` ingestion (SharedUtils/SceneLoaderWrapper.cpp:56-103)."""
+    def load(cls, path, threads=None):
+        """`.fscene` / `.obj` ingestion (SharedUtils/SceneLoaderWrapper.cpp:56-103).  `threads`: host threads of the model
+        loader for this call (None: the default; the scene does not depend on it)."""
         msg = C.create_string_buffer(512)
-        h = load_library().bdpt_scene_load(str(path).encode(), msg, 512)
+        lib = load_library()
+        before = lib.bdpt_scene_load_threads(int(threads)) if threads is not None else None
+        try:
+            h = lib.bdpt_scene_load(str(path).encode(), msg, 512)
+        finally:
+            if before is not None:
+                lib.bdpt_scene_load_threads(before)
         if not h:
             raise BdptError("bdpt_scene_load: " + msg.value.decode(errors="replace"))
         return cls(h)

@@ -183,6 +183,7 @@ PROTOTYPES = {
     "bdpt_scene_create_courtyard": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
     "bdpt_scene_create_soup": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
     "bdpt_scene_load": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_uint32]),
+    "bdpt_scene_load_threads": (C.c_int, [C.c_int]),
     "bdpt_scene_destroy": (None, [C.c_void_p]),
     "bdpt_image_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64,
                                   C.c_char_p, C.c_uint32]),

@@ -151,7 +151,13 @@ int devUpload(bdpt_ctx* c, std::vector<void*>& pool, const T** out, const T* hos
   T* d = nullptr;
   int rc = devAlloc(c, pool, &d, count);
   if (rc) return rc;
-  if (count) HIPCHK(c, hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+  if (count) {  // (large arrays through pinned staging: bvhUploadStaged)
+    std::string e;
+    if (!bvhUploadStaged(d, host, count * sizeof(T), e)) {
+      fail(c, e);
+      return BDPT_E_HIP;
+    }
+  }
   *out = d;
   return BDPT_OK;
 }
@@ -411,7 +417,10 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
       u.err = hipMalloc(&q, std::max<size_t>(count * sizeof(**dst), 16));
       if (u.err != hipSuccess) return;
       u.pool.push_back(q);
-      if (count) u.err = hipMemcpy(q, host, count * sizeof(**dst), hipMemcpyHostToDevice);
+      if (count) {
+        std::string e;
+        if (!bvhUploadStaged(q, host, count * sizeof(**dst), e)) u.err = hipErrorUnknown;
+      }
       *dst = static_cast<std::remove_reference_t<decltype(*dst)>>(q);
     };
     u.err = hipSetDevice(c->device);

@@ -334,6 +334,8 @@ void bvhSetDefaultTreeBuilder(BvhTreeBuilder f, void* user);
 struct BvhDeviceBuild;
 BvhDeviceBuild* bvhDeviceBuildBegin(int device, bool collapseOnDevice = false);
 void bvhDeviceBuildEnd(BvhDeviceBuild* b);
+// pageable host memory -> the current device through pinned staging buffers and a few copy threads (bvh_device.hip)
+bool bvhUploadStaged(void* dst, const void* src, size_t bytes, std::string& err);
 bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
 bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err);
 bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs, std::string& err);

@@ -13,19 +13,124 @@
 // What the reference gets from Assimp/FreeImage and this loader does not: FBX and other model formats,
 // PNG/JPG/HDR images, smoothing groups (normals are taken from the file or set per face).
 #include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <sstream>
+#include <thread>
 #include <tuple>
+#include <vector>
 
 #include "../../include/bdpt_scene.h"
 #include "Scene.h"
 
 namespace bdpt {
 namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Host threads of the model loader (round 5).  A 10 M-triangle OBJ is 1.2 GB of text: read line by line through
+// iostreams by one thread (round 4: 0.87 M triangles per second) it took ten times as long as the device builds the
+// acceleration structure over it.  Everything below splits its input into `threads` contiguous ranges and is written so
+// that the RESULT DOES NOT DEPEND ON THE THREAD COUNT, bit for bit: per-range results are concatenated in range order,
+// and every order-dependent sum (smooth normals, bitangents) and every "first occurrence" (joined vertices) is taken in
+// the file's face order by the ONE thread that owns the target (orderedForEach).
+// BDPT_LOADER_THREADS (environment) or bdpt_scene_load_threads (C ABI) set the count; default: the host's cores, at most 32.
+// ---------------------------------------------------------------------------------------------
+int& loaderThreadsSetting() {
+  static int t = 0;
+  return t;
+}
+int loaderThreads() {
+  const int g_loaderThreads = loaderThreadsSetting();
+  int t = g_loaderThreads;
+  if (t <= 0)
+    if (const char* e = std::getenv("BDPT_LOADER_THREADS")) t = std::atoi(e);
+  if (t <= 0) t = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  return std::max(1, std::min(t, 256));
+}
+// A big array WITHOUT the one-thread zero fill std::vector does (the loops below write every element they read): for a
+// 10 M-triangle model the joins' scratch is over 1 GB, and page-faulting it in by one thread costs as much as the work.
+template <class T>
+struct Buf {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit Buf(size_t count) : p(static_cast<T*>(std::malloc(std::max<size_t>(count, 1) * sizeof(T)))), n(count) {
+    if (!p) throw std::bad_alloc();
+  }
+  ~Buf() { std::free(p); }
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+};
+// f(range index, begin, end) over [0, n) split into `threads` contiguous ranges
+template <class F>
+void parallelRanges(size_t n, int threads, const F& f) {
+  threads = std::max(1, threads);
+  if (threads == 1 || n < 4096) {
+    f(0, 0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 1; t < threads; t++) {
+    const size_t a = std::min(n, chunk * (size_t)t), b = std::min(n, a + chunk);
+    if (a < b) pool.emplace_back([&f, t, a, b] { f(t, a, b); });
+  }
+  f(0, 0, std::min(n, chunk));
+  for (std::thread& th : pool) th.join();
+}
+// f(task) for task in [0, count), handed out to `threads` workers (order of execution is free: tasks must be independent)
+template <class F>
+void parallelTasks(int count, int threads, const F& f) {
+  threads = std::max(1, std::min(threads, count));
+  if (threads == 1) {
+    for (int k = 0; k < count; k++) f(k);
+    return;
+  }
+  std::atomic<int> next{0};
+  auto work = [&] {
+    for (int k; (k = next.fetch_add(1)) < count;) f(k);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(work);
+  work();
+  for (std::thread& th : pool) th.join();
+}
+// For every item i in [0, n) with target(i) < numTargets (others are skipped): visit(i) is called by the one thread that
+// owns target(i), and the items of one target are visited in INCREASING i — so `out[target(i)] += value(i)` gives the sum a
+// serial loop over i gives, and "first item of a target" is well defined, whatever the thread count.
+// (Items are first dealt to (producer range, owner) lists in order; an owner then walks the producers' lists in order.)
+template <class Target, class Visit>
+void orderedForEach(size_t n, size_t numTargets, int threads, const Target& target, const Visit& visit) {
+  threads = std::max(1, threads);
+  if (threads == 1 || n < 65536) {
+    for (size_t i = 0; i < n; i++)
+      if (target(i) < numTargets) visit(i);
+    return;
+  }
+  const size_t T = (size_t)threads, per = (numTargets + T - 1) / T;
+  std::vector<std::vector<std::vector<uint32_t>>> lists(T, std::vector<std::vector<uint32_t>>(T));
+  parallelRanges(n, threads, [&](int t, size_t a, size_t b) {
+    for (auto& l : lists[(size_t)t]) l.reserve((b - a) / T + 16);
+    for (size_t i = a; i < b; i++) {
+      const size_t k = target(i);
+      if (k < numTargets) lists[(size_t)t][k / per].push_back((uint32_t)i);
+    }
+  });
+  parallelTasks(threads, threads, [&](int o) {
+    for (size_t t = 0; t < T; t++)
+      for (uint32_t i : lists[t][(size_t)o]) visit(i);
+  });
+}
 
 // ---------------------------------------------------------------------------------------------
 // minimal JSON (objects, arrays, strings, numbers, true/false/null)
@@ -161,6 +266,7 @@ std::string lower(std::string s) {
 bool endsWith(const std::string& s, const std::string& suf) { return s.size() >= suf.size() && lower(s).compare(s.size() - suf.size(), suf.size(), suf) == 0; }
 
 }  // namespace
+int& loaderThreadsSettingPublic() { return loaderThreadsSetting(); }  // (bdpt_scene_load_threads, below)
 // ImageDecode.cpp
 bool decodePng(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba8, int& channels, std::string& err);
 bool decodeJpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba8, int& channels, std::string& err);
@@ -293,6 +399,34 @@ struct ModelLoader {
   std::map<std::string, bool> mtlLoaded;
   ModelLoader(Scene& sc, const std::string& d, bool sg) : s(sc), dir(d), specGloss(sg) {}
 
+  // Image files decoded ahead of their use, all at once on the loader's threads (a real asset's 40 textures of 1024 x 1024
+  // take longer to inflate than its geometry to parse); texture() then takes them from here in the order the material
+  // library names them, so ids, messages and results are those of decoding one by one.
+  struct Decoded {
+    Scene::Texture tex;
+    bool alpha = false, ok = false;
+    std::string why;
+  };
+  std::map<std::string, Decoded> decoded;
+  static std::string texturePath(const std::string& dir, const std::string& file) {
+    std::string p = dir + "/" + file;
+    std::replace(p.begin(), p.end(), '\\', '/');
+    return p;
+  }
+  void predecode(const std::vector<std::string>& files) {
+    std::vector<std::string> todo;
+    for (const std::string& f : files) {
+      const std::string p = texturePath(dir, f);
+      if (!decoded.count(p) && std::find(todo.begin(), todo.end(), p) == todo.end()) todo.push_back(p);
+    }
+    std::vector<Decoded> out(todo.size());
+    parallelTasks((int)todo.size(), loaderThreads(), [&](int k) {
+      Decoded& d = out[(size_t)k];
+      d.ok = loadImage(todo[(size_t)k], d.tex, d.alpha, &d.why);
+    });
+    for (size_t k = 0; k < todo.size(); k++) decoded[todo[k]] = std::move(out[k]);
+  }
+
   int texture(const std::string& file, bool srgb, bool* hasAlpha) {
     std::string key = file + (srgb ? "|s" : "|l");
     auto it = texCache.find(key);
@@ -302,11 +436,20 @@ struct ModelLoader {
     }
     Scene::Texture t;
     bool a = false;
-    std::string p = dir + "/" + file;
-    std::replace(p.begin(), p.end(), '\\', '/');
+    const std::string p = texturePath(dir, file);
     int id = -1;
     std::string why;
-    if (loadImage(p, t, a, &why)) {
+    bool ok;
+    auto pre = decoded.find(p);
+    if (pre != decoded.end()) {  // (a file used both as colour and as linear data is decoded once and copied)
+      ok = pre->second.ok;
+      t = pre->second.tex;
+      a = pre->second.alpha;
+      why = pre->second.why;
+    } else {
+      ok = loadImage(p, t, a, &why);
+    }
+    if (ok) {
       t.srgb = srgb ? 1u : 0u;
       id = (int)s.textures.size();
       s.textures.push_back(std::move(t));
@@ -337,6 +480,25 @@ struct ModelLoader {
     std::ifstream f(dir + "/" + file);
     if (!f) return false;
     std::string line;
+    std::vector<std::string> lines;
+    while (std::getline(f, line)) lines.push_back(line);
+    {  // every image the library names, decoded side by side before the materials are read (predecode)
+      std::vector<std::string> files;
+      bool any = false;
+      for (const std::string& ln : lines) {
+        std::istringstream ss(ln);
+        std::string k;
+        if (!(ss >> k) || k[0] == '#') continue;
+        if (k == "newmtl") any = true;
+        if (!any || k.compare(0, 4, "map_") != 0) {
+          if (!(any && (k == "bump" || k == "norm" || k == "disp"))) continue;
+        }
+        std::string t, last;
+        while (ss >> t) last = t;
+        if (!last.empty()) files.push_back(last);
+      }
+      predecode(files);
+    }
     bdpt_material cur{};
     std::string curName;
     bool have = false, dbl = false;
@@ -351,8 +513,8 @@ struct ModelLoader {
       s.materials.push_back(cur);
       nrmBump = nrmNorm = nrmDisp = -1;
     };
-    while (std::getline(f, line)) {
-      std::istringstream ss(line);
+    for (const std::string& mtlLine : lines) {
+      std::istringstream ss(mtlLine);
       std::string k;
       if (!(ss >> k) || k[0] == '#') continue;
       if (k == "newmtl") {
@@ -404,16 +566,228 @@ struct ModelLoader {
     return true;
   }
 
+  // BDPT_LOADER_VERBOSE: where the load time goes (stderr)
+  std::chrono::steady_clock::time_point lapT = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    static const bool verbose = std::getenv("BDPT_LOADER_VERBOSE") != nullptr;
+    if (!verbose) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[loader] %-22s %.3f s\n", what, std::chrono::duration<double>(t - lapT).count());
+    lapT = t;
+  }
+
+  // ---- OBJ text, read in two parallel passes over line-aligned pieces of the file held in memory -----------------------
+  // pass 1 counts what a piece holds (v / vt / vn lines, triangles after fan triangulation, mtllib / usemtl lines): the
+  // prefix sums are every piece's place in the global arrays; pass 2 parses the numbers straight into those places.
+  // Relative (negative) indices and the "not yet defined" checks use the counts SO FAR, as the line-by-line reader did.
+  static bool isSpace(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+  struct Cursor {  // one line
+    const char *p, *end;
+    void skip() {
+      while (p < end && isSpace(*p)) p++;
+    }
+    bool token(const char*& a, const char*& b) {
+      skip();
+      if (p >= end) return false;
+      a = p;
+      while (p < end && !isSpace(*p)) p++;
+      b = p;
+      return true;
+    }
+    bool number(float& out) {  // what `stream >> float` reads: an optional sign, then a decimal floating-point number
+      const char *a, *b;
+      if (!token(a, b)) return false;
+      if (a < b && *a == '+') a++;
+      float v = 0.0f;
+      const auto r = std::from_chars(a, b, v);
+      if (r.ec != std::errc() && r.ec != std::errc::result_out_of_range) return false;
+      if (r.ec == std::errc::result_out_of_range) v = (float)std::strtod(std::string(a, b).c_str(), nullptr);
+      out = v;
+      return true;
+    }
+  };
+  static int atoiRange(const char* a, const char* b) {  // atoi on [a, b): optional sign, leading digits, rest ignored
+    bool neg = false;
+    if (a < b && (*a == '-' || *a == '+')) neg = *a++ == '-';
+    long v = 0;
+    while (a < b && *a >= '0' && *a <= '9' && v < (1l << 40)) v = v * 10 + (*a++ - '0');
+    v = neg ? -v : v;
+    return (int)std::max<long>(std::min<long>(v, 2147483647l), -2147483647l);
+  }
+  struct PieceCounts {
+    size_t v = 0, vt = 0, vn = 0, tris = 0, events = 0;
+  };
+  struct Event {  // a mtllib / usemtl line: applies from triangle `tri` (global index) on
+    bool lib;
+    std::string name;
+    size_t tri;
+  };
+  template <class Line>
+  static void forEachLine(const char* a, const char* e, const Line& fn) {
+    while (a < e) {
+      const char* nl = static_cast<const char*>(std::memchr(a, '\n', (size_t)(e - a)));
+      const char* le = nl ? nl : e;
+      fn(Cursor{a, le});
+      a = nl ? nl + 1 : e;
+    }
+  }
+  static int keyword(Cursor& c) {  // 1 v, 2 vn, 3 vt, 4 f, 5 mtllib, 6 usemtl, 0 anything else (comments included)
+    const char *a, *b;
+    if (!c.token(a, b) || *a == '#') return 0;
+    const size_t n = (size_t)(b - a);
+    if (n == 1) return *a == 'v' ? 1 : (*a == 'f' ? 4 : 0);
+    if (n == 2 && a[0] == 'v') return a[1] == 'n' ? 2 : (a[1] == 't' ? 3 : 0);
+    if (n == 6 && std::memcmp(a, "mtllib", 6) == 0) return 5;
+    if (n == 6 && std::memcmp(a, "usemtl", 6) == 0) return 6;
+    return 0;
+  }
+
   // appends the model transformed by `mat` (row-major 3x4) to the scene
   bool loadObj(const std::string& path, const float mat[12], const float nmat[9]) {
-    std::ifstream f(path);
-    if (!f) {
-      err = "cannot open " + path;
-      return false;
+    std::string text;
+    {
+      std::ifstream f(path, std::ios::binary);
+      if (!f) {
+        err = "cannot open " + path;
+        return false;
+      }
+      f.seekg(0, std::ios::end);
+      const std::streamoff n = f.tellg();
+      f.seekg(0, std::ios::beg);
+      text.resize((size_t)std::max<std::streamoff>(n, 0));
+      if (n > 0) f.read(&text[0], n);
     }
     dir = dirOf(path);
-    std::vector<float> P, N, T;
-    uint32_t curMat = 0xFFFFFFFFu;
+    const int threads = loaderThreads();
+    lapT = std::chrono::steady_clock::now();
+    if (std::getenv("BDPT_LOADER_VERBOSE")) std::fprintf(stderr, "[loader] %s: %zu bytes, %d threads\n", path.c_str(), text.size(), threads);
+    // line-aligned pieces: a fixed piece SIZE (not a piece count) so that nothing below depends on the thread count
+    constexpr size_t kPiece = 4u << 20;
+    std::vector<size_t> cut{0};
+    while (cut.back() < text.size()) {
+      size_t e = std::min(text.size(), cut.back() + kPiece);
+      if (e < text.size()) {
+        const void* nl = std::memchr(text.data() + e, '\n', text.size() - e);
+        e = nl ? (size_t)(static_cast<const char*>(nl) - text.data()) + 1 : text.size();
+      }
+      cut.push_back(e);
+    }
+    const int pieces = (int)cut.size() - 1;
+    std::vector<PieceCounts> cnt((size_t)std::max(pieces, 0)), base((size_t)std::max(pieces, 0) + 1);
+    parallelTasks(pieces, threads, [&](int k) {
+      PieceCounts c;
+      forEachLine(text.data() + cut[(size_t)k], text.data() + cut[(size_t)k + 1], [&](Cursor ln) {
+        switch (keyword(ln)) {
+          case 1: c.v++; break;
+          case 2: c.vn++; break;
+          case 3: c.vt++; break;
+          case 4: {
+            size_t corners = 0;
+            const char *a, *b;
+            while (ln.token(a, b)) corners++;
+            if (corners >= 3) c.tris += corners - 2;
+            break;
+          }
+          case 5: case 6: c.events++; break;
+          default: break;
+        }
+      });
+      cnt[(size_t)k] = c;
+    });
+    lap("pass 1 (count)");
+    for (int k = 0; k < pieces; k++) {
+      base[(size_t)k + 1].v = base[(size_t)k].v + cnt[(size_t)k].v;
+      base[(size_t)k + 1].vt = base[(size_t)k].vt + cnt[(size_t)k].vt;
+      base[(size_t)k + 1].vn = base[(size_t)k].vn + cnt[(size_t)k].vn;
+      base[(size_t)k + 1].tris = base[(size_t)k].tris + cnt[(size_t)k].tris;
+      base[(size_t)k + 1].events = base[(size_t)k].events + cnt[(size_t)k].events;
+    }
+    const PieceCounts total = base[(size_t)std::max(pieces, 0)];
+    if (total.v > 0x7fffffffull || total.vt > 0x7fffffffull || total.vn > 0x7fffffffull || total.tris * 3 > 0xffffffffull) {
+      err = "model too large in " + path;
+      return false;
+    }
+    std::vector<float> P(total.v * 3), N(total.vn * 3), T(total.vt * 2);
+    faces.assign(total.tris, Face{});
+    std::vector<Event> events(total.events);
+    std::atomic<bool> badIndex{false};
+    parallelTasks(pieces, threads, [&](int k) {
+      size_t iv = base[(size_t)k].v, ivt = base[(size_t)k].vt, ivn = base[(size_t)k].vn, itri = base[(size_t)k].tris, iev = base[(size_t)k].events;
+      std::vector<Corner> cs;
+      forEachLine(text.data() + cut[(size_t)k], text.data() + cut[(size_t)k + 1], [&](Cursor ln) {
+        const int kw = keyword(ln);
+        switch (kw) {
+          case 1: {
+            float a = 0, b = 0, c = 0;
+            (void)(ln.number(a) && ln.number(b) && ln.number(c));
+            P[iv * 3] = a;
+            P[iv * 3 + 1] = b;
+            P[iv * 3 + 2] = c;
+            iv++;
+            break;
+          }
+          case 2: {
+            float a = 0, b = 0, c = 0;
+            (void)(ln.number(a) && ln.number(b) && ln.number(c));
+            N[ivn * 3] = a;
+            N[ivn * 3 + 1] = b;
+            N[ivn * 3 + 2] = c;
+            ivn++;
+            break;
+          }
+          case 3: {
+            float a = 0, b = 0;
+            (void)(ln.number(a) && ln.number(b));
+            T[ivt * 2] = a;
+            T[ivt * 2 + 1] = b;
+            ivt++;
+            break;
+          }
+          case 4: {
+            cs.clear();
+            const char *a, *b;
+            const int nv = (int)iv, nt = (int)ivt, nn = (int)ivn;  // defined SO FAR
+            while (ln.token(a, b)) {
+              Corner c{0, 0, 0};
+              int* dst[3] = {&c.v, &c.t, &c.n};
+              const char* st = a;
+              for (int part = 0; part < 3 && st <= b; part++) {
+                const char* e = static_cast<const char*>(std::memchr(st, '/', (size_t)(b - st)));
+                const char* pe = e ? e : b;
+                if (pe > st) *dst[part] = atoiRange(st, pe);
+                if (!e) break;
+                st = e + 1;
+              }
+              if (c.v < 0) c.v = nv + c.v + 1;
+              if (c.t < 0) c.t = nt + c.t + 1;
+              if (c.n < 0) c.n = nn + c.n + 1;
+              if (c.v < 1 || c.v > nv) badIndex.store(true);
+              if (c.t > nt) c.t = 0;
+              if (c.n > nn) c.n = 0;
+              cs.push_back(c);
+            }
+            if (cs.size() < 3) break;
+            for (size_t k2 = 1; k2 + 1 < cs.size(); k2++) faces[itri++] = Face{{cs[0], cs[k2], cs[k2 + 1]}, 0xFFFFFFFFu};  // fan triangulation
+            break;
+          }
+          case 5: case 6: {
+            const char *a, *b;
+            std::string nm;
+            if (ln.token(a, b)) nm.assign(a, b);
+            events[iev++] = Event{kw == 5, nm, itri};
+            break;
+          }
+          default: break;
+        }
+      });
+    });
+    lap("pass 2 (parse)");
+    if (badIndex.load()) {
+      err = "face index out of range in " + path;
+      return false;
+    }
+    // materials: the few mtllib / usemtl lines, in file order, exactly as the line-by-line reader met them (a library is
+    // read when its line is met; the default material is created when the first face without one is met)
     auto defaultMat = [&]() -> uint32_t {
       auto it = matIndex.find("\x01" "default");
       if (it != matIndex.end()) return it->second;
@@ -428,65 +802,37 @@ struct ModelLoader {
       s.materials.push_back(m);
       return matIndex["\x01" "default"];
     };
-    faces.clear();
-    std::string line;
-    while (std::getline(f, line)) {
-      std::istringstream ss(line);
-      std::string k;
-      if (!(ss >> k) || k[0] == '#') continue;
-      if (k == "v") {
-        float a, b, c;
-        ss >> a >> b >> c;
-        P.insert(P.end(), {a, b, c});
-      } else if (k == "vn") {
-        float a, b, c;
-        ss >> a >> b >> c;
-        N.insert(N.end(), {a, b, c});
-      } else if (k == "vt") {
-        float a = 0, b = 0;
-        ss >> a >> b;
-        T.insert(T.end(), {a, b});
-      } else if (k == "mtllib") {
-        std::string m;
-        ss >> m;
-        if (!mtlLoaded[m]) loadMtl(m, matIndex);
-        mtlLoaded[m] = true;
-      } else if (k == "usemtl") {
-        std::string m;
-        ss >> m;
-        auto it = matIndex.find(m);
-        curMat = it != matIndex.end() ? it->second : defaultMat();
-      } else if (k == "f") {
-        std::vector<Corner> cs;
-        std::string tok;
-        while (ss >> tok) {
-          Corner c{0, 0, 0};
-          int* dst[3] = {&c.v, &c.t, &c.n};
-          size_t st = 0;
-          for (int part = 0; part < 3 && st <= tok.size(); part++) {
-            size_t e = tok.find('/', st);
-            std::string sub = tok.substr(st, e == std::string::npos ? std::string::npos : e - st);
-            if (!sub.empty()) *dst[part] = std::atoi(sub.c_str());
-            if (e == std::string::npos) break;
-            st = e + 1;
-          }
-          const int nv = (int)(P.size() / 3), nt = (int)(T.size() / 2), nn = (int)(N.size() / 3);
-          if (c.v < 0) c.v = nv + c.v + 1;
-          if (c.t < 0) c.t = nt + c.t + 1;
-          if (c.n < 0) c.n = nn + c.n + 1;
-          if (c.v < 1 || c.v > nv) {
-            err = "face index out of range in " + path;
-            return false;
-          }
-          if (c.t > nt) c.t = 0;
-          if (c.n > nn) c.n = 0;
-          cs.push_back(c);
+    struct Span {
+      size_t first, last;
+      uint32_t mat;
+    };
+    std::vector<Span> spans;
+    {
+      uint32_t curMat = 0xFFFFFFFFu;
+      size_t from = 0;
+      auto close = [&](size_t upTo) {  // triangles [from, upTo) were read under curMat
+        if (upTo > from) {
+          if (curMat == 0xFFFFFFFFu) curMat = defaultMat();
+          spans.push_back(Span{from, upTo, curMat});
         }
-        if (cs.size() < 3) continue;
-        if (curMat == 0xFFFFFFFFu) curMat = defaultMat();
-        for (size_t k2 = 1; k2 + 1 < cs.size(); k2++) faces.push_back({{cs[0], cs[k2], cs[k2 + 1]}, curMat});  // fan triangulation
+        from = upTo;
+      };
+      for (const Event& ev : events) {
+        close(ev.tri);
+        if (ev.lib) {
+          if (!mtlLoaded[ev.name]) loadMtl(ev.name, matIndex);
+          mtlLoaded[ev.name] = true;
+        } else {
+          auto it = matIndex.find(ev.name);
+          curMat = it != matIndex.end() ? it->second : defaultMat();
+        }
       }
+      close(faces.size());
     }
+    parallelTasks((int)spans.size(), threads, [&](int k) {
+      for (size_t f = spans[(size_t)k].first; f < spans[(size_t)k].last; f++) faces[f].mat = spans[(size_t)k].mat;
+    });
+    lap("materials + textures");
     emit(P, N, T, faces, mat, nmat);
     return true;
   }
@@ -523,9 +869,13 @@ struct ModelLoader {
   // Joins identical (position, texcoord, normal) corners per material (what Assimp's JoinIdenticalVertices leaves
   // Falcor with, one aiMesh per material), generates smooth normals when the file has none, and builds the
   // bitangent stream the way Falcor does (AssimpModelImporter.cpp:150-176 -> BinaryModelImporter.cpp:84-173),
-  // on the pre-transformed (world-space) vertices.
+  // on the pre-transformed (world-space) vertices.  Threaded; every "first occurrence" and every order-dependent float
+  // sum is taken in the file's face order by the thread that owns the target (orderedForEach), so the vertex and
+  // triangle lists are those of a one-thread run, bit for bit.
   void emit(const std::vector<float>& P, const std::vector<float>& N, const std::vector<float>& T, const std::vector<Face>& fs, const float mat[12],
             const float nmat[9]) {
+    const int threads = loaderThreads();
+    const size_t nF = fs.size(), nC = nF * 3;
     auto xf = [&](const float* p) -> float3 {
       return {mat[0] * p[0] + mat[1] * p[1] + mat[2] * p[2] + mat[3], mat[4] * p[0] + mat[5] * p[1] + mat[6] * p[2] + mat[7],
               mat[8] * p[0] + mat[9] * p[1] + mat[10] * p[2] + mat[11]};
@@ -536,84 +886,203 @@ struct ModelLoader {
       r = nrm(r);
       return invalid(r) ? float3{0, 1, 0} : r;
     };
-    // smooth normals per position index (area-weighted face normals), used for corners without vn
+    // smooth normals per position index (area-weighted face normals, added in face order), used for corners without vn
     std::vector<float3> smooth;
-    bool needSmooth = false;
-    for (const Face& f : fs)
-      for (int c = 0; c < 3; c++) needSmooth |= f.c[c].n <= 0;
-    if (needSmooth) {
+    std::atomic<bool> needSmooth{false};
+    parallelRanges(nF, threads, [&](int, size_t f0, size_t f1) {
+      bool need = false;
+      for (size_t f = f0; f < f1 && !need; f++)
+        for (int c = 0; c < 3; c++) need |= fs[f].c[c].n <= 0;
+      if (need) needSmooth.store(true);
+    });
+    if (needSmooth.load()) {
       smooth.assign(P.size() / 3, float3{0, 0, 0});
-      for (const Face& f : fs) {
-        float3 p[3];
-        for (int c = 0; c < 3; c++) p[c] = {P[(size_t)(f.c[c].v - 1) * 3], P[(size_t)(f.c[c].v - 1) * 3 + 1], P[(size_t)(f.c[c].v - 1) * 3 + 2]};
-        float3 fn = cross(sub(p[1], p[0]), sub(p[2], p[0]));
-        for (int c = 0; c < 3; c++) smooth[(size_t)f.c[c].v - 1] = add(smooth[(size_t)f.c[c].v - 1], fn);
-      }
+      Buf<float3> fn(nF);
+      parallelRanges(nF, threads, [&](int, size_t f0, size_t f1) {
+        for (size_t f = f0; f < f1; f++) {
+          float3 p[3];
+          for (int c = 0; c < 3; c++) p[c] = {P[(size_t)(fs[f].c[c].v - 1) * 3], P[(size_t)(fs[f].c[c].v - 1) * 3 + 1], P[(size_t)(fs[f].c[c].v - 1) * 3 + 2]};
+          fn[f] = cross(sub(p[1], p[0]), sub(p[2], p[0]));
+        }
+      });
+      orderedForEach(nC, smooth.size(), threads, [&](size_t i) { return (size_t)fs[i / 3].c[i % 3].v - 1; },
+                     [&](size_t i) {
+                       float3& d = smooth[(size_t)fs[i / 3].c[i % 3].v - 1];
+                       d = add(d, fn[i / 3]);
+                     });
     }
+    lap("smooth normals");
+    // joined vertices: corner i -> the FIRST corner with the same (material, v, vt, vn); a corner that is its own first
+    // becomes a vertex, numbered in corner order
     struct Key {
       uint32_t mat;
       int v, t, n;
-      bool operator<(const Key& o) const { return std::tie(mat, v, t, n) < std::tie(o.mat, o.v, o.t, o.n); }
+      bool operator==(const Key& o) const { return mat == o.mat && v == o.v && t == o.t && n == o.n; }
     };
-    std::map<Key, uint32_t> uniq;
-    std::vector<float3> pos, nor, bit;
-    std::vector<float> uvs;
-    std::vector<uint32_t> idx;
-    idx.reserve(fs.size() * 3);
-    for (const Face& f : fs) {
-      for (int c = 0; c < 3; c++) {
-        const Corner& cr = f.c[c];
-        Key k{f.mat, cr.v, cr.t, cr.n};
-        auto it = uniq.find(k);
-        if (it == uniq.end()) {
-          it = uniq.emplace(k, (uint32_t)pos.size()).first;
-          pos.push_back(xf(&P[(size_t)(cr.v - 1) * 3]));
-          float3 n = cr.n > 0 ? float3{N[(size_t)(cr.n - 1) * 3], N[(size_t)(cr.n - 1) * 3 + 1], N[(size_t)(cr.n - 1) * 3 + 2]} : smooth[(size_t)cr.v - 1];
-          nor.push_back(xn(n));
-          // aiProcess_FlipUVs (AssimpModelImporter.cpp:516): v -> 1 - v
-          uvs.push_back(cr.t > 0 ? T[(size_t)(cr.t - 1) * 2] : 0.0f);
-          uvs.push_back(cr.t > 0 ? 1.0f - T[(size_t)(cr.t - 1) * 2 + 1] : 0.0f);
-        }
-        idx.push_back(it->second);
+    auto keyOf = [&](size_t i) {
+      const Corner& cr = fs[i / 3].c[i % 3];
+      return Key{fs[i / 3].mat, cr.v, cr.t, cr.n};
+    };
+    auto hashOf = [](const Key& k) {
+      uint64_t h = (uint64_t)k.mat * 0x9E3779B97F4A7C15ull;
+      h ^= (uint64_t)(uint32_t)k.v * 0xC2B2AE3D27D4EB4Full;
+      h = (h << 31) | (h >> 33);
+      h ^= (uint64_t)(uint32_t)k.t * 0x165667B19E3779F9ull;
+      h = (h << 29) | (h >> 35);
+      h ^= (uint64_t)(uint32_t)k.n * 0x27D4EB2F165667C5ull;
+      h ^= h >> 32;
+      return h * 0x9E3779B97F4A7C15ull;
+    };
+    Buf<uint32_t> rep(nC);  // first corner of corner i's key
+    {
+      // owner of a key = a slice of the hash space; each owner keeps an open-addressing table of (first corner) slots
+      constexpr size_t kOwnersBits = 8;  // 256 owners whatever the thread count (only the assignment of owners to threads varies)
+      const size_t owners = (size_t)1 << kOwnersBits;
+      Buf<uint64_t> hs(nC);
+      parallelRanges(nC, threads, [&](int, size_t a0, size_t a1) {
+        for (size_t i = a0; i < a1; i++) hs[i] = hashOf(keyOf(i));
+      });
+      std::vector<uint32_t> perOwner(owners + 1, 0);
+      {
+        std::vector<std::vector<uint32_t>> local((size_t)threads, std::vector<uint32_t>(owners, 0));
+        parallelRanges(nC, threads, [&](int t, size_t a0, size_t a1) {
+          for (size_t i = a0; i < a1; i++) local[(size_t)t][hs[i] >> (64 - kOwnersBits)]++;
+        });
+        for (size_t o = 0; o < owners; o++)
+          for (int t = 0; t < threads; t++) perOwner[o + 1] += local[(size_t)t][o];
       }
+      std::vector<std::vector<uint32_t>> table(owners);
+      parallelTasks((int)owners, threads, [&](int o) {
+        size_t cap = 16;
+        while (cap < (size_t)perOwner[(size_t)o + 1] * 2) cap <<= 1;
+        table[(size_t)o].assign(cap, 0xFFFFFFFFu);
+      });
+      orderedForEach(nC, owners, threads, [&](size_t i) { return (size_t)(hs[i] >> (64 - kOwnersBits)); },
+                     [&](size_t i) {
+                       std::vector<uint32_t>& tb = table[hs[i] >> (64 - kOwnersBits)];
+                       const size_t mask = tb.size() - 1;
+                       const Key k = keyOf(i);
+                       for (size_t at = (size_t)hs[i] & mask;; at = (at + 1) & mask) {
+                         if (tb[at] == 0xFFFFFFFFu) {
+                           tb[at] = (uint32_t)i;  // corners of one key arrive in increasing i: this is the first
+                           rep[i] = (uint32_t)i;
+                           return;
+                         }
+                         if (keyOf(tb[at]) == k) {
+                           rep[i] = tb[at];
+                           return;
+                         }
+                       }
+                     });
     }
-    bit.assign(pos.size(), float3{0, 0, 0});
+    lap("join (first corners)");
+    // vertex number of a first corner = how many first corners precede it (two-level prefix sum)
+    Buf<uint32_t> vid(nC);
+    size_t nV = 0;
+    {
+      const size_t blocks = (nC + 65535) / 65536;
+      std::vector<uint32_t> blockCount(blocks + 1, 0);
+      parallelTasks((int)blocks, threads, [&](int b) {
+        uint32_t c = 0;
+        for (size_t i = (size_t)b * 65536, e = std::min(nC, i + 65536); i < e; i++) c += rep[i] == i ? 1u : 0u;
+        blockCount[(size_t)b + 1] = c;
+      });
+      for (size_t b = 0; b < blocks; b++) blockCount[b + 1] += blockCount[b];
+      nV = blockCount[blocks];
+      parallelTasks((int)blocks, threads, [&](int b) {
+        uint32_t c = blockCount[(size_t)b];
+        for (size_t i = (size_t)b * 65536, e = std::min(nC, i + 65536); i < e; i++)
+          if (rep[i] == i) vid[i] = c++;
+      });
+    }
+    Buf<float3> pos(nV), nor(nV), bit(nV);
+    Buf<float> uvs(nV * 2);
+    Buf<uint32_t> idx(nC);
+    parallelRanges(nV, threads, [&](int, size_t a0, size_t a1) {
+      for (size_t v = a0; v < a1; v++) bit[v] = float3{0, 0, 0};
+    });
+    parallelRanges(nC, threads, [&](int, size_t a0, size_t a1) {
+      for (size_t i = a0; i < a1; i++) {
+        idx[i] = vid[rep[i]];
+        if (rep[i] != i) continue;
+        const Corner& cr = fs[i / 3].c[i % 3];
+        const uint32_t v = vid[i];
+        pos[v] = xf(&P[(size_t)(cr.v - 1) * 3]);
+        float3 n = cr.n > 0 ? float3{N[(size_t)(cr.n - 1) * 3], N[(size_t)(cr.n - 1) * 3 + 1], N[(size_t)(cr.n - 1) * 3 + 2]} : smooth[(size_t)cr.v - 1];
+        nor[v] = xn(n);
+        // aiProcess_FlipUVs (AssimpModelImporter.cpp:516): v -> 1 - v
+        uvs[(size_t)v * 2] = cr.t > 0 ? T[(size_t)(cr.t - 1) * 2] : 0.0f;
+        uvs[(size_t)v * 2 + 1] = cr.t > 0 ? 1.0f - T[(size_t)(cr.t - 1) * 2 + 1] : 0.0f;
+      }
+    });
+    lap("vertices");
+    // bitangents: every face's contribution to its three corners (parallel), then added per vertex in face order
     const bool haveUv = !T.empty();
-    for (size_t f = 0; f < fs.size(); f++) {
-      const uint32_t* i3 = &idx[f * 3];
-      const float3 d0 = sub(pos[i3[1]], pos[i3[0]]), d1 = sub(pos[i3[2]], pos[i3[0]]);
-      float sx = 0, sy = 0, tx = 0, ty = 0;
-      if (haveUv) {
-        sx = uvs[i3[1] * 2] - uvs[i3[0] * 2];
-        sy = uvs[i3[1] * 2 + 1] - uvs[i3[0] * 2 + 1];
-        tx = uvs[i3[2] * 2] - uvs[i3[0] * 2];
-        ty = uvs[i3[2] * 2 + 1] - uvs[i3[0] * 2 + 1];
+    Buf<float3> contrib(nC);
+    Buf<uint8_t> contribOk(nF);
+    parallelRanges(nF, threads, [&](int, size_t f0, size_t f1) {
+      for (size_t f = f0; f < f1; f++) {
+        const uint32_t* i3 = &idx[f * 3];
+        const float3 d0 = sub(pos[i3[1]], pos[i3[0]]), d1 = sub(pos[i3[2]], pos[i3[0]]);
+        float sx = 0, sy = 0, tx = 0, ty = 0;
+        if (haveUv) {
+          sx = uvs[(size_t)i3[1] * 2] - uvs[(size_t)i3[0] * 2];
+          sy = uvs[(size_t)i3[1] * 2 + 1] - uvs[(size_t)i3[0] * 2 + 1];
+          tx = uvs[(size_t)i3[2] * 2] - uvs[(size_t)i3[0] * 2];
+          ty = uvs[(size_t)i3[2] * 2 + 1] - uvs[(size_t)i3[0] * 2 + 1];
+        }
+        float3 tangent, bitangent;
+        if ((sx == 0 && sy == 0) || (tx == 0 && ty == 0)) {
+          bitangent = projectNormalToBitangent(nor[i3[0]]);
+          tangent = cross(bitangent, nor[i3[0]]);
+        } else {
+          const float dc = 1.0f / (sx * ty - sy * tx);
+          tangent = mul(sub(mul(d0, ty), mul(d1, tx)), dc);
+          bitangent = mul(sub(mul(d1, sx), mul(d0, sy)), dc);  // sic: the reference uses s.y here, not t.x
+        }
+        contribOk[f] = invalid(bitangent) ? 0 : 1;
+        for (int c = 0; c < 3; c++) {
+          const float3 n = nor[i3[c]];
+          float3 lt = nrm(sub(tangent, mul(n, dot(tangent, n))));
+          float3 lb = nrm(sub(bitangent, mul(n, dot(bitangent, n))));
+          lb = nrm(sub(lb, mul(lt, dot(lb, lt))));
+          contrib[f * 3 + (size_t)c] = nrm(lb);
+        }
       }
-      float3 tangent, bitangent;
-      if ((sx == 0 && sy == 0) || (tx == 0 && ty == 0)) {
-        bitangent = projectNormalToBitangent(nor[i3[0]]);
-        tangent = cross(bitangent, nor[i3[0]]);
-      } else {
-        const float dc = 1.0f / (sx * ty - sy * tx);
-        tangent = mul(sub(mul(d0, ty), mul(d1, tx)), dc);
-        bitangent = mul(sub(mul(d1, sx), mul(d0, sy)), dc);  // sic: the reference uses s.y here, not t.x
-      }
-      for (int c = 0; c < 3; c++) {
-        const float3 n = nor[i3[c]];
-        float3 lt = nrm(sub(tangent, mul(n, dot(tangent, n))));
-        float3 lb = nrm(sub(bitangent, mul(n, dot(bitangent, n))));
-        lb = nrm(sub(lb, mul(lt, dot(lb, lt))));
-        if (!invalid(bitangent)) bit[i3[c]] = add(bit[i3[c]], nrm(lb));
-      }
-    }
+    });
+    orderedForEach(nC, nV, threads, [&](size_t i) { return contribOk[i / 3] ? (size_t)idx[i] : (size_t)-1; },
+                   [&](size_t i) { bit[idx[i]] = add(bit[idx[i]], contrib[i]); });
+    lap("bitangents");
     const uint32_t base = s.getVertexCount();
-    for (size_t v = 0; v < pos.size(); v++) {
-      float3 b = nrm(bit[v]);
-      if (invalid(b)) b = projectNormalToBitangent(nor[v]);
-      if (invalid(b)) b = float3{1, 0, 0};
-      s.addVertex(pos[v], nor[v], b, uvs[v * 2], uvs[v * 2 + 1]);
-    }
-    for (size_t f = 0; f < fs.size(); f++) s.addTriangle(base + idx[f * 3], base + idx[f * 3 + 1], base + idx[f * 3 + 2], fs[f].mat);
+    const size_t v0 = s.positions.size() / 3, t0 = s.indices.size() / 3;
+    s.positions.resize((v0 + nV) * 3);
+    s.normals.resize((v0 + nV) * 3);
+    s.bitangents.resize((v0 + nV) * 3);
+    s.texcoords.resize((v0 + nV) * 3);
+    s.indices.resize((t0 + nF) * 3);
+    s.triMaterial.resize(t0 + nF);
+    parallelRanges(nV, threads, [&](int, size_t a0, size_t a1) {
+      for (size_t v = a0; v < a1; v++) {
+        float3 b = nrm(bit[v]);
+        if (invalid(b)) b = projectNormalToBitangent(nor[v]);
+        if (invalid(b)) b = float3{1, 0, 0};
+        float* p = &s.positions[(v0 + v) * 3];
+        p[0] = pos[v].x, p[1] = pos[v].y, p[2] = pos[v].z;
+        float* n = &s.normals[(v0 + v) * 3];
+        n[0] = nor[v].x, n[1] = nor[v].y, n[2] = nor[v].z;
+        float* bb = &s.bitangents[(v0 + v) * 3];
+        bb[0] = b.x, bb[1] = b.y, bb[2] = b.z;
+        float* uv = &s.texcoords[(v0 + v) * 3];
+        uv[0] = uvs[v * 2], uv[1] = uvs[v * 2 + 1], uv[2] = 0.0f;
+      }
+    });
+    parallelRanges(nF, threads, [&](int, size_t f0, size_t f1) {
+      for (size_t f = f0; f < f1; f++) {
+        for (int c = 0; c < 3; c++) s.indices[(t0 + f) * 3 + (size_t)c] = base + idx[f * 3 + (size_t)c];
+        s.triMaterial[t0 + f] = fs[f].mat;
+      }
+    });
+    lap("append to scene");
   }
 };
 
@@ -845,6 +1314,12 @@ extern "C" int bdpt_image_load_hdr(const char* path, uint32_t* width, uint32_t* 
     if (msg && msgCap) std::snprintf(msg, msgCap, "internal error while decoding the image");
     return BDPT_E_INVALID;
   }
+}
+
+extern "C" int bdpt_scene_load_threads(int threads) {
+  const int before = bdpt::loaderThreadsSettingPublic();
+  bdpt::loaderThreadsSettingPublic() = threads < 0 ? 0 : threads;
+  return before;
 }
 
 extern "C" bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap) {

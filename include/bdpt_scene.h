@@ -53,6 +53,12 @@ bdpt_scene* bdpt_scene_create_soup(uint32_t seed, uint32_t numTriangles, float m
  * (SceneLoaderWrapper.cpp:60). */
 bdpt_scene* bdpt_scene_load(const char* path, char* msg, uint32_t msgCap);
 
+/* Host threads bdpt_scene_load parses and joins a model with (0 = default: BDPT_LOADER_THREADS, else the host's cores,
+ * at most 32); returns the previous setting.  The loaded scene does not depend on it, bit for bit
+ * (host/SceneLoader.cpp "Host threads of the model loader").  Assimp's importer, which the reference calls
+ * (AssimpModelImporter.cpp:509-530), is single-threaded; a 10 M-triangle OBJ is 1.2 GB of text. */
+int bdpt_scene_load_threads(int threads);
+
 /* Decode one texture image the way the loader does (PNG, baseline JPEG, PPM/PGM, TGA): RGBA8, row 0 first; *hasAlpha =
  * the file is a 32-bit image for Falcor (Utils/Bitmap.cpp:104-126).  rgba8 may be NULL to query the size.
  * Replaces Bitmap::createFromFile -> FreeImage_Load (Utils/Bitmap.cpp:45-140). */

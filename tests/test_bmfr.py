@@ -175,12 +175,41 @@ def test_bmfr_sequence_matches_oracle(pkg, ob, flags_name):
 
 
 @pytest.mark.gpu
-def test_bmfr_needs_full_frame_context(pkg):
+def test_bmfr_on_a_band_context_filters_whole_frame_buffers(pkg):
+    """A context that renders a band (or one rank's stripes) still denoises: bdpt_bmfr_execute takes WHOLE-FRAME buffers
+    whatever the context's tile (a tiled host gathers them first), and gives what a whole-frame context gives, bit for bit;
+    the history crosses a save / load (bdpt_bmfr_save_history / _load_history), and a blob of another frame size is refused."""
+    import torch
     scene = pkg.Scene.cornell()
-    pipe = pkg.FramePipeline(scene, 32, 32, max_depth=2, mat_index=1, tile=(0, 16))
-    with pytest.raises(pkg.BdptError, match="whole frame"):
-        pipe.ctx.bmfr_execute(_params(pkg, 0, 5), pipe.gb, C.c_void_p(pipe.output.data_ptr()), pipe._stream_ptr())
-    pipe.close()
+    W = H = 64
+    full = pkg.FramePipeline(scene, W, H, max_depth=2, mat_index=1)
+    band = pkg.FramePipeline(scene, W, H, max_depth=2, mat_index=1, tile=(0, 16))
+    lib = pkg.load_library()
+    outs = {}
+    for name, pipe in (("full", full), ("band", band)):
+        res = []
+        for k in range(3):
+            full.gbuffer_frame, full.bdpt_frame = 0xdead0000 + k, 0x1337 + k
+            full.render_frame()  # the whole-frame channels both contexts filter
+            torch.cuda.synchronize()
+            noisy = full.output.clone()
+            pipe.ctx.bmfr_execute(_params(pkg, k, 7), full.gb, C.c_void_p(noisy.data_ptr()), pipe._stream_ptr())
+            torch.cuda.synchronize()
+            res.append(noisy.cpu().numpy().copy())
+            if name == "band" and k == 1:  # the history survives a save, a reset and a load
+                n = C.c_uint64()
+                assert lib.bdpt_bmfr_history_bytes(pipe.ctx._h, C.byref(n)) == 0 and n.value == W * H * 16 * 4
+                blob = (C.c_uint8 * n.value)()
+                assert lib.bdpt_bmfr_save_history(pipe.ctx._h, blob, n.value) == 0
+                assert lib.bdpt_bmfr_reset(pipe.ctx._h) == 0
+                assert lib.bdpt_bmfr_load_history(pipe.ctx._h, blob, n.value - 16) != 0  # another frame size
+                assert lib.bdpt_bmfr_load_history(pipe.ctx._h, blob, n.value) == 0
+        outs[name] = res
+    for a, b in zip(outs["full"], outs["band"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert not np.array_equal(outs["full"][0], outs["full"][2])
+    full.close()
+    band.close()
     scene.close()
 
 

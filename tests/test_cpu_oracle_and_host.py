@@ -386,7 +386,7 @@ def test_library_holds_gfx950_code_object(pkg):
 def test_abi_struct_sizes(pkg):
     a = pkg.abi
     assert C.sizeof(a.Material) == 64 and C.sizeof(a.Light) == 64 and C.sizeof(a.Camera) == 48
-    assert C.sizeof(a.Params) == 40 and C.sizeof(a.Counters) == 15 * 8 and C.sizeof(a.BvhInfo) == 48
+    assert C.sizeof(a.Params) == 40 and C.sizeof(a.Counters) == 17 * 8 and C.sizeof(a.BvhInfo) == 48
     assert C.sizeof(a.GBuffer) == 48 and C.sizeof(a.Tile) == 8
 
 

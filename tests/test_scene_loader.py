@@ -294,6 +294,50 @@ def exported_atrium(pkg, tmp_path_factory):
     src.close()
 
 
+def test_loader_result_does_not_depend_on_the_thread_count(pkg, tmp_path):
+    """The model loader is threaded (host/SceneLoader.cpp: two-pass parse of line-aligned pieces, joined vertices by hash
+    owners, smooth normals / bitangents summed per vertex in face order): 1, 2, 3 and 8 threads must give the same scene
+    bit for bit — vertices in first-occurrence order, every float of every stream, triangles, materials — on a model of
+    several pieces (14 MB of OBJ text; the piece size is 4 MB) with texture coordinates and normals, and on a small one
+    WITHOUT normals (the smooth-normal path) that uses relative indices and polygons."""
+    import hashlib
+    ex = _export_tool()
+    src = pkg.Scene.atrium(3, 120000)
+    path = ex.export_scene(pkg, src, str(tmp_path / "big"))
+    assert sum(os.path.getsize(os.path.join(tmp_path / "big", f)) for f in os.listdir(tmp_path / "big") if f.endswith(".obj")) > (9 << 20)
+    small = tmp_path / "small.obj"
+    rng = np.random.default_rng(5)
+    lines = []
+    nv = 0
+    for q in range(3000):  # quads and pentagons over shared vertices, relative indices, no vn / vt
+        base = rng.uniform(-1, 1, 3)
+        k = 4 + q % 2
+        for j in range(k):
+            lines.append("v %.6f %.6f %.6f" % tuple(base + 0.1 * np.array([np.cos(j), np.sin(j), 0.1 * j])))
+        nv += k
+        lines.append("f " + " ".join(str(-(k - j)) for j in range(k)))
+        if q:  # a triangle that reuses a vertex of the previous polygon by its absolute index
+            lines.append("f %d %d %d" % (nv - k, nv - 1, nv))
+    small.write_text("\n".join(lines) + "\n")
+
+    def digest(scene):
+        a = ex.scene_arrays(scene.desc)
+        h = hashlib.sha256()
+        for k in ("positions", "normals", "bitangents", "texcoords", "indices", "tri_material"):
+            h.update(np.ascontiguousarray(a[k]).tobytes())
+        for m in a["materials"]:
+            h.update(bytes(m))
+        return h.hexdigest(), scene.desc.numVertices, scene.desc.numTriangles
+    for file in (path, str(small)):
+        got = []
+        for threads in (1, 2, 3, 8):
+            sc = pkg.Scene.load(file, threads=threads)
+            got.append(digest(sc))
+            sc.close()
+        assert got[0][2] > 0 and all(g == got[0] for g in got), (file, got)
+    src.close()
+
+
 def test_exported_scene_loads_back(pkg, exported_atrium):
     """Export the atrium, load the files through bdpt_scene_load: the geometry comes back bit for bit (positions and
     triangle order per shading model), normals / texture coordinates to the last place the importer's own rules leave

@@ -98,6 +98,10 @@ struct bdpt_ctx {
   // context's G-buffer pass and read by its light-tracing generator.  BDPT_NO_HINTS (environment) switches both kinds off.
   uint32_t* hintPix = nullptr;
   bool hints = true;
+  // a context that renders only part of the frame fills the hints of ALL frame pixels when its camera changes (its
+  // light-tracing rays aim anywhere); its own rows are refreshed by every G-buffer pass
+  bdpt_camera hintCam{};
+  bool hintCamValid = false;
 };
 
 namespace {
@@ -598,6 +602,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     }
   }
   if (c->hintPix) HIPCHK(c, hipMemset(c->hintPix, 0xFF, (size_t)c->W * c->H * sizeof(uint32_t)));
+  c->hintCamValid = false;
   lap("light maps");
   c->haveScene = true;
   return BDPT_OK;
@@ -814,6 +819,7 @@ int resizeRows(bdpt_ctx* c, uint32_t width, uint32_t height, uint32_t maxDepth) 
     if ((rc = devAlloc(c, c->frameAllocs, &P.lazyRay, (size_t)std::max<uint32_t>(batch, 1) * np))) return rc;
   }
   c->hintPix = nullptr;
+  c->hintCamValid = false;
   if (std::getenv("BDPT_NO_HINTS") == nullptr) {
     if ((rc = devAlloc(c, c->frameAllocs, &c->hintPix, (size_t)width * height))) return rc;
     HIPCHK(c, hipMemset(c->hintPix, 0xFF, (size_t)width * height * sizeof(uint32_t)));
@@ -858,6 +864,14 @@ int bdpt_gbuffer_execute(bdpt_ctx* c, const bdpt_gbuffer_params* gp, const bdpt_
   G.gb = *out;
   G.counters = nullptr;  // primary rays are tallied analytically by bdpt_get_counters (one per tile pixel)
   G.hintPix = c->hintPix;
+  if (c->hintPix && c->tileRows != c->H && (!c->hintCamValid || std::memcmp(&c->hintCam, &c->cam, sizeof(bdpt_camera)) != 0)) {
+    GBufferDev A = G;
+    A.Np = c->W * c->H;
+    A.pix = nullptr;
+    launchHintFill(c->S, A, st);
+    c->hintCam = c->cam;
+    c->hintCamValid = true;
+  }
   launchGBuffer(c->S, G, st);
   HIPCHK(c, hipGetLastError());
   c->lastStream = st;

@@ -1819,7 +1819,7 @@ void giveStage(void* p) {
 }
 }  // namespace
 bool uploadStagedImpl(void* dst, const void* src, size_t bytes, std::string& err) {
-  constexpr int kBufs = 2, kCopyThreads = 4;
+  constexpr int kBufs = 2, kCopyThreads = 8;
   auto bad = [&](hipError_t e) {
     err = std::string("upload: ") + hipGetErrorString(e);
     return false;

@@ -199,6 +199,8 @@ void launchBmfr(const BmfrDev& A, uint32_t flags, hipStream_t st);
 
 // launchers (kernels.hip)
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
+// FrameDev::hintPix of EVERY frame pixel (G.Np = W * H; nothing else is written): partial-tile contexts, on a camera change
+void launchHintFill(const SceneDev& S, const GBufferDev& G, hipStream_t st);
 // SceneDev::lightMap of every point / spot light of the scene (res texels per face edge), closest-hit rays from the light
 void launchLightMaps(const SceneDev& S, uint32_t* maps, uint32_t res, hipStream_t st);
 void launchInitPaths(const SceneDev& S, const FrameDev& F, const PathBuf& P, hipStream_t st);

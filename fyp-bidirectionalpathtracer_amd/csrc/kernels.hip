@@ -174,13 +174,16 @@ BD f3 envLookup(const float* envMap, uint32_t envW, uint32_t envH, f3 d) {
   return c;
 }
 
-template <bool COUNT>
+// HINT_ONLY: the primary ray of EVERY frame pixel (G.Np = W * H, no pixel list), and only its occluder-hint word is
+// written — what a context that renders a band or one rank's stripes runs when the camera has moved, so that its
+// light-tracing rays, which may aim at any pixel of the frame, find a hint outside its own rows too.
+template <bool COUNT, bool HINT_ONLY = false>
 __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G) {
   BDPT_ONE_WAVE_PER_GROUP();
   __shared__ int s_stack[kStackEntries * kWave];
   const uint32_t p = blockIdx.x * kWave + threadIdx.x;
   if (p >= G.Np) return;
-  const size_t pix = G.pix[p];
+  const size_t pix = HINT_ONLY ? (size_t)p : (size_t)G.pix[p];
   const uint32_t y = (uint32_t)(pix / G.W), x = (uint32_t)(pix - (size_t)y * G.W);
 
   const f3 U = ld3(G.cam.cameraU), V = ld3(G.cam.cameraV), Wv = ld3(G.cam.cameraW), camPos = ld3(G.cam.posW);
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(kWave) void gbuffer_kernel(SceneDev S, GBufferDev G
   }
   float4* oP = reinterpret_cast<float4*>(G.gb.worldPosition);
   if (G.hintPix) G.hintPix[pix] = (h.prim < 0) ? kNoHint : h.rec;  // occluder hint of light-tracing rays aimed at this pixel
+  if (HINT_ONLY) return;
   if (h.prim < 0) {
     const f3 c = G.gp.envMap ? envLookup(G.gp.envMap, G.gp.envWidth, G.gp.envHeight, d) : ld3(G.gp.envColor);
     oP[pix] = make_float4(0, 0, 0, 0);
@@ -1517,6 +1521,11 @@ void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st) {
     launchWave(gbuffer_kernel<true>, (uint32_t)(blocksFor(Np)), st, S, G);
   else
     launchWave(gbuffer_kernel<false>, (uint32_t)(blocksFor(Np)), st, S, G);
+}
+
+void launchHintFill(const SceneDev& S, const GBufferDev& G, hipStream_t st) {  // G.Np = W * H, G.pix unused
+  if (!G.Np || !G.hintPix) return;
+  launchWave(gbuffer_kernel<false, true>, (uint32_t)(blocksFor(G.Np)), st, S, G);
 }
 
 void launchLightMaps(const SceneDev& S, uint32_t* maps, uint32_t res, hipStream_t st) {

@@ -773,9 +773,15 @@ bool BlockwiseMultiOrderFeatureRegression::gatherWholeFrame(RenderContext* pRend
   }
   return true;
 }
-// [frame number][history bytes][history]: the denoiser switched off, or not run yet, saves no history
+// [frame number][switches][history bytes][history]: the denoiser switched off, or not run yet, saves no history; a state
+// written under other switches is refused (a run resumed with the denoiser on from frames rendered without it would
+// filter against a history that does not exist)
+static uint32_t bmfrSwitches(bool on, bool pre, bool reg, bool post, bool removeFeatures) {
+  return (on ? 1u : 0u) | (pre ? 2u : 0u) | (reg ? 4u : 0u) | (post ? 8u : 0u) | (removeFeatures ? 16u : 0u);
+}
 void BlockwiseMultiOrderFeatureRegression::saveState(RenderContext*, std::vector<uint8_t>& out) {
   put32(out, mAccumCount);
+  put32(out, bmfrSwitches(mDoDenoise, mBMFR_preprocess, mBMFR_regression, mBMFR_postprocess, mBMFR_removeFeatures));
   uint64_t bytes = 0;
   if (mDoDenoise && mpRays) (void)bdpt_bmfr_history_bytes(mpRays->ctx(), &bytes);
   std::vector<uint8_t> blob((size_t)bytes);
@@ -787,13 +793,14 @@ void BlockwiseMultiOrderFeatureRegression::saveState(RenderContext*, std::vector
   out.insert(out.end(), blob.begin(), blob.end());
 }
 bool BlockwiseMultiOrderFeatureRegression::loadState(RenderContext*, const uint8_t* data, size_t size) {
-  if (size < 12) return false;
-  const uint64_t bytes = get64(data + 4);
-  if (bytes != size - 12) return false;
+  if (size < 16) return false;
+  if (get32(data + 4) != bmfrSwitches(mDoDenoise, mBMFR_preprocess, mBMFR_regression, mBMFR_postprocess, mBMFR_removeFeatures)) return false;
+  const uint64_t bytes = get64(data + 8);
+  if (bytes != size - 16) return false;
   if (bytes) {
     if (!mpRays || !mpResManager) return false;
     if (!mpRays->ensureSize(mpResManager->getScreenSize().x, mpResManager->getScreenSize().y)) return false;
-    if (bdpt_bmfr_load_history(mpRays->ctx(), data + 12, bytes) != BDPT_OK) {
+    if (bdpt_bmfr_load_history(mpRays->ctx(), data + 16, bytes) != BDPT_OK) {
       std::fprintf(stderr, "[BMFR] %s\n", mpRays->lastError());
       return false;
     }

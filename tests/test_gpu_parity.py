@@ -677,7 +677,7 @@ def test_bench_gpus_2_starts_its_own_ranks(pkg):
 def test_cpp_host_checkpoint_resume_continues_bit_for_bit(pkg, tmp_path):
     """host/bdpt_render --checkpoint / --resume: 7 accumulated frames in one run == 3 frames, checkpoint, a new process
     resuming for 4 more (frame counters, jitter sequence and the running mean carry over); a checkpoint written for
-    another frame size is refused."""
+    another frame size, ray depth, material model, scene or denoiser setting is refused."""
     import os
     import subprocess
     import __graft_entry__ as ge
@@ -709,10 +709,14 @@ def test_cpp_host_checkpoint_resume_continues_bit_for_bit(pkg, tmp_path):
             args[args.index(other[k]) + 1] = other[k + 1]
         r = subprocess.run(args, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "cannot resume" in r.stderr, (other, r.stderr)
-    # the BMFR denoiser keeps a temporal history no checkpoint carries: with it switched on, neither writing nor resuming
+    # the BMFR denoiser's temporal history travels in the checkpoint since round 5
+    # (test_cpp_host_denoiser_under_tiling_and_across_a_checkpoint); what is still refused is resuming frames rendered
+    # WITHOUT the denoiser into a run with it (and the other way round): the history the filter would read does not exist
     r = run(["--frames", "2", "--denoise", "--checkpoint", str(tmp_path / "d.ckpt")])
-    assert r.returncode != 0 and "cannot write" in r.stderr and not os.path.exists(tmp_path / "d.ckpt")
+    assert r.returncode == 0 and os.path.exists(tmp_path / "d.ckpt"), r.stderr
     r = run(["--frames", "2", "--denoise", "--resume", str(tmp_path / "c.ckpt")])
+    assert r.returncode != 0 and "cannot resume" in r.stderr
+    r = run(["--frames", "2", "--resume", str(tmp_path / "d.ckpt")])
     assert r.returncode != 0 and "cannot resume" in r.stderr
     # a truncated or corrupt file is refused (section lengths are checked against what is left of the file)
     blob = open(tmp_path / "c.ckpt", "rb").read()

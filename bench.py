@@ -273,7 +273,7 @@ def other_config(pkg, torch, name, scene, W, H, D, mat, keep, frames=3, pmc_sub=
         agg = {}
         pipe.render_frame(accumulate=True)
         for k, v in pipe.ctx.stage_times():
-            agg[k] = v
+            agg[k] = agg.get(k, 0.0) + v  # (a stage name occurs once per launch: the lazy rounds' three times)
         pipe.ctx.enable_stage_timing(False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -280,6 +280,7 @@ int bdpt_create(int device_ordinal, bdpt_ctx** out_ctx) {
     bdpt_destroy(c);
     return BDPT_E_NOMEM;
   }
+  bvhPrewarmStaging(device_ordinal);  // (the pinned staging buffers bdpt_set_scene's uploads go through)
   *out_ctx = c;
   return BDPT_OK;
 }
@@ -536,44 +537,25 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     if ((rc = devUpload(c, c->sceneAllocs, &c->S.matTex, matTex.data(), matTex.size()))) return rc;
   }
   {
-    std::vector<float> alphaRecs(std::max<size_t>(alphaTris.size(), 1) * 16, 0.0f);
-    hostParallelFor(alphaTris.size(), [&](size_t i0, size_t i1) {
-      for (size_t i = i0; i < i1; i++) {
-        const uint32_t t = alphaTris[i];
-        const bdpt_material& m = d->materials[d->triMaterial[t]];
-        float* r = alphaRecs.data() + i * 16;
-        for (int k = 0; k < 3; k++) {
-          const uint32_t vi = d->indices[(size_t)t * 3 + k];
-          r[k * 2] = d->texcoords ? d->texcoords[(size_t)vi * 3] : 0.0f;
-          r[k * 2 + 1] = d->texcoords ? d->texcoords[(size_t)vi * 3 + 1] : 0.0f;
-        }
-        r[6] = m.alphaThreshold;
-        r[7] = m.baseColor[3];
-        const uint32_t type = BDPT_FLAG_DIFFUSE_TYPE(m.flags);
-        uint32_t mode = 0, tw = 0, th = 0;
-        unsigned long long px = 0;
-        if (type == BDPT_CHANNEL_UNUSED) {
-          mode = 0;
-        } else if (type == BDPT_CHANNEL_CONST || m.texBaseColor < 0) {
-          mode = 1;
-        } else {
-          mode = 2;
-          const TexDev& td = texs[(size_t)m.texBaseColor];
-          tw = td.w;
-          th = td.h;
-          px = (unsigned long long)reinterpret_cast<uintptr_t>(td.px);
-        }
-        const uint32_t lo = (uint32_t)(px & 0xffffffffull), hi = (uint32_t)(px >> 32);
-        std::memcpy(&r[8], &mode, 4);
-        std::memcpy(&r[9], &tw, 4);
-        std::memcpy(&r[10], &th, 4);
-        std::memcpy(&r[12], &lo, 4);
-        std::memcpy(&r[13], &hi, 4);
+    // the alpha-test records of the non-opaque triangles, made on the device from the shading records and the material
+    // tables already there (kernels.hip alpha_recs_kernel): only the list of those triangles crosses the bus
+    float4* dAlpha = nullptr;
+    if ((rc = devAlloc(c, c->sceneAllocs, &dAlpha, std::max<size_t>(alphaTris.size(), 1) * 4))) return rc;
+    if (alphaTris.empty()) {
+      HIPCHK(c, hipMemset(dAlpha, 0, 4 * sizeof(float4)));
+    } else {
+      const uint32_t* dList = nullptr;
+      std::vector<void*> scratch;
+      if ((rc = devUpload(c, scratch, &dList, alphaTris.data(), alphaTris.size()))) {
+        freePool(scratch);
+        return rc;
       }
-    });
-    const float* dAlpha;
-    if ((rc = devUpload(c, c->sceneAllocs, &dAlpha, alphaRecs.data(), alphaRecs.size()))) return rc;
-    c->S.alphaRecs = reinterpret_cast<const float4*>(dAlpha);
+      launchAlphaRecs(c->S, dList, (uint32_t)alphaTris.size(), dAlpha, nullptr);
+      const hipError_t e = hipDeviceSynchronize();
+      freePool(scratch);
+      HIPCHK(c, e);
+    }
+    c->S.alphaRecs = dAlpha;
   }
   lap("indices, textures, alpha");
   SceneConst sc;

@@ -318,6 +318,14 @@ struct BvhRefInput {
   uint32_t* numDroppedOut;          // (with splits == null) receives the number of dropped triangles
   double gridLo[3], gridExt[3];      // the scene box: the split planes are its spatial medians
   const BvhRefClipper* clipper;      // for the non-opaque triangles; may be null
+  // What triRecs / triBox were made from (buildBvh's inputs; numVertices 0: not given).  A maker that works on another
+  // device can make the two arrays there from these — (12 numVertices + 20 numTris) bytes to hand over instead of
+  // 72 numTris — with the loop of buildBvh "Triangle records", which is plain fp32 arithmetic (bit-identical).
+  const float* positions = nullptr;
+  const uint32_t* indices = nullptr;
+  const uint32_t* triFlags = nullptr;  // may be null (all 0)
+  const uint32_t* triAux = nullptr;    // may be null (all 0)
+  uint32_t numVertices = 0;
 };
 using BvhRefMaker = bool (*)(void* user, const BvhRefInput& in, uint32_t& numRefs, std::string& err);
 // Quantises the child boxes and packs nodes and leaf triangles into the device's record array — what the host code does
@@ -336,6 +344,8 @@ BvhDeviceBuild* bvhDeviceBuildBegin(int device, bool collapseOnDevice = false);
 void bvhDeviceBuildEnd(BvhDeviceBuild* b);
 // pageable host memory -> the current device through pinned staging buffers and a few copy threads (bvh_device.hip)
 bool bvhUploadStaged(void* dst, const void* src, size_t bytes, std::string& err);
+// pins the staging buffers of bvhUploadStaged on a thread of its own (once per process; bdpt_create calls it)
+void bvhPrewarmStaging(int device);
 bool buildBinaryTreeOnDevice(void* user, const BvhBuildRef* refs, uint32_t n, BigVec<uint32_t>& order, BigVec<BvhBuildNode>& nodes, std::string& err);
 bool packOnDevice(void* user, const BvhPackInput& in, Bvh& out, std::string& err);
 bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs, std::string& err);
@@ -347,6 +357,7 @@ struct BvhBuildOptions {
   float splitBudget = -1.0f;      // < 0: the build default (BDPT_SPLIT_BUDGET)
   float splitBudgetAlpha = -1.0f; // < 0: the build default (BDPT_SPLIT_BUDGET_ALPHA)
   const BvhRefClipper* clipper = nullptr;  // applied to the pieces of triangles flagged kTriNonOpaque
+  uint32_t numVertices = 0;                // vertices `positions` holds (0: unknown; only a plugged-in reference maker asks)
   BvhTreeBuilder treeBuilder = nullptr;    // null: the host code builds the binary tree
   bool prioritiesInRefMaker = false;       // (with a refMaker) it also classifies, rates and assigns the split counts (BvhRefInput::splits = null)
   BvhRefMaker refMaker = nullptr;          // (with a treeBuilder and a packer only) null: the host code makes the references

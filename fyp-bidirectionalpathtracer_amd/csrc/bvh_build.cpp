@@ -828,6 +828,11 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       in.gridExt[a] = G.ext[a];
     }
     in.clipper = opt.clipper;
+    in.positions = positions;
+    in.indices = indices;
+    in.triFlags = triFlags;
+    in.triAux = triAux;
+    in.numVertices = opt.numVertices;
     std::string err;
     if (!refMaker(opt.treeBuilderUser, in, madeElsewhere, err)) {
       if (opt.error) *opt.error = err.empty() ? "reference maker failed" : err;

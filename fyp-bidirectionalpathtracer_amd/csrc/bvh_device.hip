@@ -1011,6 +1011,39 @@ struct RefArgs {
   const DevMask* masks;
 };
 
+// buildBvh "Triangle records" (bvh_build.cpp) on the device: v0, e1 = v1 - v0, e2 = v2 - v0, ids; the box of the five
+// points the host takes (v0, v0 + e1, v0 + e2, v1, v2), with its min / max spelled as BvhBox::grow spells them.
+__global__ void k_tri_recs(const float* __restrict__ pos, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ flags,
+                           const uint32_t* __restrict__ aux, uint32_t n, BvhTri* __restrict__ recs, BvhBox* __restrict__ boxes) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float* a = pos + (size_t)idx[(size_t)t * 3] * 3;
+  const float* b = pos + (size_t)idx[(size_t)t * 3 + 1] * 3;
+  const float* c = pos + (size_t)idx[(size_t)t * 3 + 2] * 3;
+  BvhTri r;
+  BvhBox bx;
+  for (int k = 0; k < 3; k++) {
+    const float va = a[k], vb = b[k], vc = c[k];
+    r.v0[k] = va;
+    r.e1[k] = vb - va;
+    r.e2[k] = vc - va;
+    const float p1 = r.v0[k] + r.e1[k], p2 = r.v0[k] + r.e2[k];
+    float lo = 1e30f, hi = -1e30f;
+    const float pts[5] = {va, p1, p2, vb, vc};
+    for (int j = 0; j < 5; j++) {
+      lo = pts[j] < lo ? pts[j] : lo;
+      hi = hi < pts[j] ? pts[j] : hi;
+    }
+    bx.lo[k] = lo;
+    bx.hi[k] = hi;
+  }
+  r.prim = t;
+  r.flags = flags ? flags[t] : 0u;
+  r.aux = aux ? aux[t] : 0u;
+  recs[t] = r;
+  boxes[t] = bx;
+}
+
 BDV float floatDownD(double x) {
   float f = (float)x;
   if ((double)f > x) {  // nextafterf(f, -inf)
@@ -1797,9 +1830,25 @@ namespace {
 constexpr size_t kUpStage = 32u << 20;
 std::mutex gStageLock;
 std::vector<void*> gStageFree;  // pinned buffers of kUpStage bytes, this device's (the pool is per process: one GPU per process)
+// bvhPrewarmStaging (bdpt_create): four buffers pinned on a thread of their own while the host does other things —
+// pinning 128 MB takes the driver over 0.1 s, which the first bdpt_set_scene of a process would otherwise wait for
+struct Prewarm {
+  std::thread th;
+  std::once_flag once;
+  ~Prewarm() {
+    if (th.joinable()) th.join();
+  }
+} gPrewarm;
 void* takeStage() {
   {
-    std::lock_guard<std::mutex> g(gStageLock);
+    std::unique_lock<std::mutex> g(gStageLock);
+    if (gStageFree.empty() && gPrewarm.th.joinable()) {  // the warm-up has not delivered yet: wait for it rather than pin more
+      g.unlock();
+      static std::mutex joinLock;
+      std::lock_guard<std::mutex> j(joinLock);
+      if (gPrewarm.th.joinable()) gPrewarm.th.join();
+      g.lock();
+    }
     if (!gStageFree.empty()) {
       void* p = gStageFree.back();
       gStageFree.pop_back();
@@ -2347,14 +2396,28 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
     }
     build->triRecs = static_cast<BvhTri*>(q);
     build->numTris = nT;
-    if (!uploadStagedImpl(build->triRecs, in.triRecs, (size_t)nT * sizeof(BvhTri), err)) return false;
   }
   A.triRecs = build->triRecs;
   BvhBox* dTriBox = nullptr;
   uint32_t* dSplits = nullptr;
   uint8_t* dState = nullptr;
+  uint32_t* dIdxAll = nullptr;  // the index list, shared with the clipper's tables below when they name the same array
   const bool decideHere = in.splits == nullptr;  // classification, priorities and split counts happen here too
-  if (!upload(&dTriBox, in.triBox, nT)) return false;
+  // BDPT_UPLOAD_TRI_RECS (measurement knob): hand the host's records and boxes over instead of making them here
+  if (in.positions && in.indices && in.numVertices && nT && std::getenv("BDPT_UPLOAD_TRI_RECS") == nullptr) {
+    // records and boxes made here from what they are made of: 12 B per vertex + 20 B per triangle cross the bus
+    // instead of 72 B per triangle
+    float* dPos = nullptr;
+    uint32_t *dFlags = nullptr, *dAux = nullptr;
+    if (!upload(&dPos, in.positions, (size_t)in.numVertices * 3) || !upload(&dIdxAll, in.indices, (size_t)nT * 3)) return false;
+    if (in.triFlags && !upload(&dFlags, in.triFlags, nT)) return false;
+    if (in.triAux && !upload(&dAux, in.triAux, nT)) return false;
+    if (!devAllocT(pool, &dTriBox, nT, err)) return false;
+    hipLaunchKernelGGL(k_tri_recs, dim3((nT + 255) / 256), dim3(256), 0, nullptr, dPos, dIdxAll, dFlags, dAux, nT, build->triRecs, dTriBox);
+  } else {
+    if (!uploadStagedImpl(build->triRecs, in.triRecs, (size_t)nT * sizeof(BvhTri), err)) return false;
+    if (!upload(&dTriBox, in.triBox, nT)) return false;
+  }
   if (decideHere ? (!devAllocT(pool, &dSplits, nT, err) || !devAllocT(pool, &dState, nT, err)) : (!upload(&dSplits, in.splits, nT) || !upload(&dState, in.state, nT))) return false;
   A.triBox = dTriBox;
   A.splits = dSplits;
@@ -2374,7 +2437,11 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
     float* dTex = nullptr;
     int32_t *dMask = nullptr, *dVerdict = nullptr;
     DevMask* dMasks = nullptr;
-    if (!upload(&dMat, tb.triMaterial, nT) || !upload(&dIdx, tb.indices, (size_t)nT * 3) || !upload(&dMask, tb.matMask.data(), tb.matMask.size()) ||
+    if (dIdxAll && tb.indices == in.indices)
+      dIdx = dIdxAll;  // (already here)
+    else if (!upload(&dIdx, tb.indices, (size_t)nT * 3))
+      return false;
+    if (!upload(&dMat, tb.triMaterial, nT) || !upload(&dMask, tb.matMask.data(), tb.matMask.size()) ||
         !upload(&dVerdict, tb.matVerdict.data(), tb.matVerdict.size()))
       return false;
     if (tb.texcoords && !upload(&dTex, tb.texcoords, (size_t)tb.numVertices * 3)) return false;
@@ -2498,5 +2565,17 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
 }
 
 bool bvhUploadStaged(void* dst, const void* src, size_t bytes, std::string& err) { return uploadStagedImpl(dst, src, bytes, err); }
+void bvhPrewarmStaging(int device) {
+  std::call_once(gPrewarm.once, [device] {
+    gPrewarm.th = std::thread([device] {
+      if (hipSetDevice(device) != hipSuccess) return;
+      for (int i = 0; i < 4; i++) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kUpStage, hipHostMallocDefault) != hipSuccess) return;
+        giveStage(p);
+      }
+    });
+  });
+}
 
 }  // namespace bdpt

@@ -199,6 +199,8 @@ void launchBmfr(const BmfrDev& A, uint32_t flags, hipStream_t st);
 
 // launchers (kernels.hip)
 void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st);
+// SceneDev::alphaRecs (4 float4 per non-opaque triangle, in the order of alphaTris) from the shading records and material tables
+void launchAlphaRecs(const SceneDev& S, const uint32_t* alphaTris, uint32_t n, float4* out, hipStream_t st);
 // FrameDev::hintPix of EVERY frame pixel (G.Np = W * H; nothing else is written): partial-tile contexts, on a camera change
 void launchHintFill(const SceneDev& S, const GBufferDev& G, hipStream_t st);
 // SceneDev::lightMap of every point / spot light of the scene (res texels per face edge), closest-hit rays from the light

@@ -1523,6 +1523,43 @@ void launchGBuffer(const SceneDev& S, const GBufferDev& G, hipStream_t st) {
     launchWave(gbuffer_kernel<false>, (uint32_t)(blocksFor(Np)), st, S, G);
 }
 
+// The 64-byte alpha-test record of every non-opaque triangle (device_scene.hpp alphaTestFails: the triangle's three texture
+// coordinates, the material's threshold and constant alpha, how its base colour is given, the texture's size and address)
+// from what is on the device already — the triangle's shading record and the material tables — instead of 64 B per
+// triangle built by the host and copied over (0.32 GB for the 10 M-triangle courtyard).
+__global__ void alpha_recs_kernel(SceneDev S, const uint32_t* __restrict__ alphaTris, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t t = alphaTris[i];
+  const float4* sr = S.shade + (size_t)t * kShadeRecF4;  // 3 x (pos, normal, uv) + material id: floats 6, 7 of each vertex = uv
+  const float4 a1 = sr[1], b1 = sr[3], c1 = sr[5], m6 = sr[6];
+  const uint32_t mid = __float_as_uint(m6.x);
+  const bdpt_material& m = S.materials[mid];
+  const uint32_t type = BDPT_FLAG_DIFFUSE_TYPE(m.flags);
+  uint32_t mode = 0, tw = 0, th = 0;
+  unsigned long long px = 0;
+  if (type == BDPT_CHANNEL_UNUSED) {
+    mode = 0;
+  } else if (type == BDPT_CHANNEL_CONST || m.texBaseColor < 0) {
+    mode = 1;
+  } else {
+    mode = 2;
+    const TexDev td = S.matTex[(size_t)mid * 4];
+    tw = td.w;
+    th = td.h;
+    px = (unsigned long long)reinterpret_cast<uintptr_t>(td.px);
+  }
+  float4* r = out + (size_t)i * 4;
+  r[0] = make_float4(a1.z, a1.w, b1.z, b1.w);
+  r[1] = make_float4(c1.z, c1.w, m.alphaThreshold, m.baseColor[3]);
+  r[2] = make_float4(__uint_as_float(mode), __uint_as_float(tw), __uint_as_float(th), 0.0f);
+  r[3] = make_float4(__uint_as_float((uint32_t)(px & 0xffffffffull)), __uint_as_float((uint32_t)(px >> 32)), 0.0f, 0.0f);
+}
+void launchAlphaRecs(const SceneDev& S, const uint32_t* alphaTris, uint32_t n, float4* out, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(alpha_recs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S, alphaTris, n, out);
+}
+
 void launchHintFill(const SceneDev& S, const GBufferDev& G, hipStream_t st) {  // G.Np = W * H, G.pix unused
   if (!G.Np || !G.hintPix) return;
   launchWave(gbuffer_kernel<false, true>, (uint32_t)(blocksFor(G.Np)), st, S, G);

@@ -88,6 +88,7 @@ void buildSceneBvh(const bdpt_scene_desc* d, int threads, float splitBudget, flo
   opt.splitBudget = splitBudget;
   opt.splitBudgetAlpha = splitBudgetAlpha;
   opt.clipper = classify ? out.clipper.get() : nullptr;
+  opt.numVertices = d->numVertices;
   opt.treeBuilder = treeBuilder;
   opt.treeBuilderUser = treeBuilderUser;
   opt.packer = packer;

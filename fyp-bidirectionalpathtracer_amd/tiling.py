@@ -108,7 +108,7 @@ class TileRenderer:
 
     `inflight` contexts render the same tile (interleaved stripes of rows; with one rank the whole frame), each with one
     frame in flight on its own stream: the persistent launches of one frame ramp up and drain (a sub-path is up to D rays
-    in series) and a tile leaves the chip underfilled (DESIGN.md section 5), so frames overlap; they stay independent
+    in series) and a tile leaves the chip underfilled (DESIGN.md section 6), so frames overlap; they stay independent
     until the running mean, which is applied in frame order through an event chain.
 
     dist: an initialised ``torch.distributed`` module (backend "nccl" = RCCL, or gloo for rehearsals) or None for a

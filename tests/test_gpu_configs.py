@@ -334,6 +334,41 @@ def test_striped_tiles_equal_full_frame(pkg):
     atrium.close()
 
 
+def test_tile_pack_all_gather_unpack_is_the_identity_for_every_world_size(pkg):
+    """bdpt_tile_pack / bdpt_tile_unpack — the device side of "tile framebuffers gathered" that the tiled denoiser uses every
+    frame — for worlds of 1, 2, 3, 5 and 8 ranks on one GPU: every rank's stripe context packs its rows of a whole-frame
+    buffer into its chunk (chunkRows x W, zero padded), the chunks are laid out rank-major as ncclAllGather leaves them,
+    and ONE context unpacks every owner's chunk: the frame must come back bit for bit, for 16-, 8- and 4-byte pixels and
+    frames whose last stripe is short or whose last ranks have no rows (RCCL with more than one rank cannot run here; the
+    index maths of the world > 1 path is what can be pinned)."""
+    import torch
+    scene = pkg.Scene.cornell()
+    lib = pkg.load_library()
+    for (W, H) in ((40, 37), (24, 3), (64, 45)):
+        for world in (1, 2, 3, 5, 8):
+            R = pkg.tiling.stripe_rows(H, world)
+            chunk_rows = pkg.tiling.chunk_rows(H, world)
+            pipes = [pkg.FramePipeline(scene, W, H, max_depth=2, mat_index=1, stripes=(R, world, r)) for r in range(world)]
+            for bpp, dt in ((16, torch.float32), (8, torch.float16), (4, torch.int32)):
+                ch = {16: 4, 8: 4, 4: 1}[bpp]
+                frame = torch.arange(W * H * ch, device="cuda").remainder(30011).to(dt).reshape(H, W, ch).contiguous()
+                gathered = torch.full((world, chunk_rows, W, ch), 77, dtype=dt, device="cuda")
+                for r, pp in enumerate(pipes):
+                    assert pp.ctx.tile_info().chunkRows == chunk_rows
+                    gathered[r].zero_()
+                    assert lib.bdpt_tile_pack(pp.ctx._h, C.c_void_p(frame.data_ptr()), C.c_void_p(gathered[r].data_ptr()), bpp, pp._stream_ptr()) == 0
+                back = torch.full_like(frame, 55)
+                for r in range(world):
+                    assert lib.bdpt_tile_unpack(pipes[0].ctx._h, r, C.c_void_p(gathered[r].data_ptr()), C.c_void_p(back.data_ptr()), bpp, pipes[0]._stream_ptr()) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(back.view(torch.uint8), frame.view(torch.uint8)), (W, H, world, bpp)
+            assert lib.bdpt_tile_unpack(pipes[0].ctx._h, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(back.data_ptr()), 16, None) != 0  # no such owner
+            assert lib.bdpt_tile_pack(pipes[0].ctx._h, C.c_void_p(frame.data_ptr()), C.c_void_p(gathered.data_ptr()), 12, None) != 0  # 4, 8 or 16 bytes
+            for pp in pipes:
+                pp.close()
+    scene.close()
+
+
 def test_config4_full_size_stripes_equal_full_frame(pkg):
     """configs[3] shape (Bistro-class: 2.8 M triangles, 3840x2160, depth 12) tiled the way the 8-GPU run tiles it:
     eight owners' interleaved stripes + the exact integer sum of their owner-major splat buffers == the full frame."""

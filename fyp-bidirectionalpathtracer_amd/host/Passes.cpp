@@ -592,6 +592,8 @@ void BDPTPass::execute(RenderContext* pRenderContext) {
   p.flags |= BDPT_PARAM_DEFER_RESOLVE | BDPT_PARAM_DEFER_TAIL;
   bool ok = bdpt_execute(mpRays->ctx(), &p, &gb, out, stream) == BDPT_OK;
   ok = ok && bdpt_splat_buffer(mpRays->ctx(), &full, &fullWords) == BDPT_OK && fullWords == mpRays->tileInfo().splatU64;
+  // this rank cannot enter the frame's collective: its peers must not wait in theirs (TileExchange::abort)
+  if (!ok && !x->aborted()) x->abort(std::string("the BDPT pass failed before the splat exchange: ") + mpRays->lastError());
   if (ok && !x->reduceScatter(full, mpRays->tileSplat(), mpRays->tileInfo().chunkU64, stream, slot)) {
     std::fprintf(stderr, "[BDPTPass] splat exchange failed: %s\n", x->lastError().c_str());
     ok = false;
@@ -750,6 +752,7 @@ bool BlockwiseMultiOrderFeatureRegression::gatherWholeFrame(RenderContext* pRend
         hipMalloc((void**)&mFullNoisy, n * 16) != hipSuccess || hipMalloc((void**)&mFullPos, n * 16) != hipSuccess ||
         hipMalloc((void**)&mFullNorm, n * 8) != hipSuccess || hipMalloc((void**)&mFullAlb, n * 8) != hipSuccess) {
       freeGather();
+      mpRays->exchange()->abort("out of device memory for the denoiser's whole-frame buffers");  // peers: do not wait
       return false;
     }
     mGatherW = W;
@@ -760,7 +763,10 @@ bool BlockwiseMultiOrderFeatureRegression::gatherWholeFrame(RenderContext* pRend
   void* full[4] = {mFullNoisy, mFullPos, mFullNorm, mFullAlb};
   size_t off = 0;
   for (int k = 0; k < 4; k++) {
-    if (bdpt_tile_pack(mpRays->ctx(), src[k], mPackedMine + off, kBpp[k], st) != BDPT_OK) return false;
+    if (bdpt_tile_pack(mpRays->ctx(), src[k], mPackedMine + off, kBpp[k], st) != BDPT_OK) {
+      mpRays->exchange()->abort(std::string("packing the denoiser's channels failed: ") + mpRays->lastError());  // peers: do not wait
+      return false;
+    }
     off += px * kBpp[k];
   }
   if (!mpRays->exchange()->allGather((const float*)mPackedMine, (float*)mPackedAll, chunk / 4, st)) return false;
@@ -893,6 +899,7 @@ bool RenderingPipeline::initialize(Scene::SharedPtr pScene) {
     mpRays = RayLaunch::create(&mContext);
     TileExchange::SharedPtr x = TileExchange::create(mContext.getDevice(), mTileRank, mTileWorld, mTileComm);
     if (!mpRays || !x) return false;
+    if (mTileAbort) x->setAbortHandler(mTileAbort);
     mpRays->setTiling(x);
   }
   if (mFramesInFlight > 1) {  // frame slots: channels, launcher contexts and streams, one set per frame in flight

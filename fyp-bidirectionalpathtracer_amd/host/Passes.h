@@ -224,6 +224,8 @@ class RenderingPipeline {
   // their per-frame order (SharedUtils/RenderingPipeline.cpp:611-695) are unchanged; what is replaced is the single
   // DispatchRays of the reference (Falcor API/D3D12/D3D12RenderContext.cpp:350-384).  Same image as one GPU, bit for bit.
   bool setTiling(uint32_t rank, uint32_t world, ncclComm_t comm);
+  // what TileExchange::abort calls instead of ncclCommAbort when this rank has to leave a collective (before initialize())
+  void setTilingAbortHandler(std::function<void()> f) { mTileAbort = std::move(f); }
   bool isTiled() const { return mTileWorld > 0; }
   // RenderingPipeline::run (RenderingPipeline.cpp:697-712) without a window: size the channels from the config,
   // load the scene named by BDPT_SCENE (a .fscene / .obj path, "atrium", default the Cornell box), render BDPT_FRAMES
@@ -260,6 +262,7 @@ class RenderingPipeline {
   RayLaunch::SharedPtr mpRays;             // kept to switch the launcher's slot
   bool inFlightActive();
   uint32_t mTileRank = 0, mTileWorld = 0;  // world 0: not tiled
+  std::function<void()> mTileAbort;
   ncclComm_t mTileComm = nullptr;
   std::string rankPath(const std::string& path) const;  // checkpoints of a tiled pipeline are per rank
 };

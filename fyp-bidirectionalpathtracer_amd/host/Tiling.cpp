@@ -40,7 +40,20 @@ TileExchange::~TileExchange() {
   }
 }
 
+void TileExchange::abort(const std::string& why) {
+  if (mAborted) return;
+  mAborted = true;
+  mError = "aborted: " + why;
+  std::fprintf(stderr, "[TileExchange] rank %u leaves the group: %s\n", mRank, why.c_str());
+  if (mOnAbort)
+    mOnAbort();  // the host program aborts the job's communicators (each once)
+  else if (mComm)
+    (void)ncclCommAbort(mComm);  // (the host program owns the communicator and must not destroy it again)
+  mComm = nullptr;
+}
+
 bool TileExchange::reduceScatter(const uint64_t* full, uint64_t* mine, uint64_t chunkU64, hipStream_t renderStream, uint32_t slot) {
+  if (mAborted) return false;
   if (slot >= kMaxSlots || !full || !mine) return false;
   if (hipEventRecord(mReady[slot], renderStream) != hipSuccess) return false;
   if (hipStreamWaitEvent(mStream, mReady[slot], 0) != hipSuccess) return false;
@@ -61,6 +74,7 @@ void TileExchange::waitFor(hipStream_t renderStream, uint32_t slot) {
 }
 
 bool TileExchange::allGather(const float* mine, float* all, size_t count, hipStream_t stream) {
+  if (mAborted) return false;
   if (mComm) {
     const ncclResult_t r = ncclAllGather(mine, all, count, ncclFloat32, mComm, stream);
     if (r != ncclSuccess) {

@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -47,6 +48,15 @@ class TileExchange {
   // every rank's `count` floats -> all (world * count floats, rank-major), on `stream`
   bool allGather(const float* mine, float* all, size_t count, hipStream_t stream);
   const std::string& lastError() const { return mError; }
+  // This rank cannot take part in a collective its peers are about to enter (a launch or an allocation failed on it):
+  // ncclCommAbort on its communicator, so that the peers' collectives return with an error instead of waiting for
+  // ever.  Every later reduceScatter / allGather of this object fails at once.  (No communicator: nothing to do.)
+  // A host program that keeps several communicators (ranks as threads) or has its own teardown installs a handler: it is
+  // called INSTEAD of ncclCommAbort and must see to it that every communicator of the job is aborted exactly once
+  // (bdpt_render: RankGroup::abort -> the watcher).
+  void abort(const std::string& why);
+  bool aborted() const { return mAborted; }
+  void setAbortHandler(std::function<void()> f) { mOnAbort = std::move(f); }
 
  private:
   TileExchange() = default;
@@ -56,6 +66,8 @@ class TileExchange {
   hipStream_t mStream = nullptr;  // the exchange stream
   hipEvent_t mReady[kMaxSlots] = {}, mDone[kMaxSlots] = {};
   std::string mError;
+  bool mAborted = false;
+  std::function<void()> mOnAbort;
 };
 
 // Rows per stripe for a frame of `height` rows dealt to `world` ranks: bdpt_stripe_rows (include/bdpt.h), the same rule

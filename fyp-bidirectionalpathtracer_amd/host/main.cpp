@@ -74,10 +74,12 @@ struct RankEnv {
   bool barrier() const { return group ? group->wait() : true; }
   // a failure after the agreement point
   void failLate() const {
-    if (group)
-      group->abort();
-    else if (comm && world > 1)
-      ncclCommAbort(comm);
+    if (group) {
+      group->abort();  // (idempotent; the watcher aborts every communicator once)
+    } else if (comm && world > 1) {
+      static std::atomic<bool> once{false};  // one rank per process: its one communicator is aborted once
+      if (!once.exchange(true)) ncclCommAbort(comm);
+    }
   }
 };
 
@@ -148,6 +150,8 @@ RankResult runRank(const Options& o, int device, const RankEnv& env) {
   const uint32_t rank = env.rank, world = env.world;
   const bool tiled = world > 0, writer = !tiled || rank == 0;
   std::unique_ptr<RenderingPipeline> pipeline(new RenderingPipeline());
+  // a rank that has to leave a collective later (TileExchange::abort) releases its peers the same way a failed read-back does
+  pipeline->setTilingAbortHandler([env] { env.failLate(); });
   const bool setUp = !env.injected("setup") && setUpRank(o, device, rank, world, env.comm, pipeline.get());
   // agreement point: a rank whose set-up failed (scene, tiling, a hipMalloc in initialize, the environment map, the
   // checkpoint) says so HERE, and every rank leaves — none enters a barrier or a collective its peer will never reach

@@ -160,6 +160,45 @@ int main(int argc, char** argv) {
     bdpt_scene* bad = bdpt_scene_load((tmp + "/missing.fscene").c_str(), msg, sizeof(msg));
     if (bad) rc |= 1;
   }
+  {  // the threaded OBJ reader on mutated and truncated model text (host/SceneLoader.cpp parses raw memory with memchr /
+     // from_chars): a corrupt file may be refused or load as something else, never read or write out of bounds; and an
+     // intact one gives the same scene for 1, 3 and 8 threads
+    std::string good = "mtllib san.mtl\n# comment\nv 0 0 0\nv 1 0 0\r\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl a\n"
+                       "f 1/1/1 2/2/1 3/3/1 4/4/1\nusemtl b.DoubleSided\nf -1 -4 -3\nf 1//1 5//1 2//1\ng grp\ns off\nusemtl nope\nf 1 5 2 3 4\nf +1 2 3\n";
+    for (int k = 0; k < 400; k++) good += "v " + std::to_string(k % 7) + ".5 " + std::to_string(k % 5) + " -" + std::to_string(k % 3) + "e-1\nf -1 -2 -3\n";
+    uint32_t state = 777u;
+    auto rnd = [&]() { return state = state * 1664525u + 1013904223u; };
+    int loaded = 0, refused = 0;
+    uint32_t trisGood[3] = {0, 0, 0};
+    for (int k = 0; k < 600; k++) {
+      std::string d = good;
+      if (k >= 3) {
+        const int flips = 1 + (int)(rnd() % 6);
+        static const char pool[] = "0123456789-+/. \n\rvftnemusl#e";
+        for (int i = 0; i < flips; i++) d[rnd() % d.size()] = (rnd() % 3) ? pool[rnd() % (sizeof(pool) - 1)] : (char)(rnd() >> 24);
+        if (k % 4 == 0) d.resize(1 + rnd() % d.size());
+      }
+      std::ofstream(tmp + "/mut.obj", std::ios::binary).write(d.data(), (std::streamsize)d.size());
+      bdpt_scene_load_threads(k % 3 == 0 ? 1 : (k % 3 == 1 ? 3 : 8));
+      char msg[256] = {0};
+      bdpt_scene* sc = bdpt_scene_load((tmp + "/mut.obj").c_str(), msg, sizeof(msg));
+      if (sc) {
+        bdpt_scene_desc dd{};
+        bdpt_scene_get_desc(sc, &dd);
+        for (uint32_t t = 0; t < dd.numTriangles * 3; t++)
+          if (dd.indices[t] >= dd.numVertices) rc |= 1;  // whatever was loaded is a consistent scene
+        if (k < 3) trisGood[k] = dd.numTriangles;
+        loaded++;
+        bdpt_scene_destroy(sc);
+      } else {
+        refused++;
+        if (k < 3) rc |= 1;  // the unmodified file must load
+      }
+    }
+    bdpt_scene_load_threads(0);
+    if (trisGood[0] == 0 || trisGood[0] != trisGood[1] || trisGood[0] != trisGood[2]) rc |= 1;
+    std::printf("obj reader: %d loaded, %d refused, %u triangles in the intact file\n", loaded, refused, trisGood[0]);
+  }
   {  // image decoders: the files tests/test_sanitizers.py wrote, then byte-mutated and truncated copies of them (a corrupt
      // file may be refused or decoded to garbage, never read or written out of bounds)
     uint32_t state = 12345u;

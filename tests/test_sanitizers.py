@@ -49,3 +49,7 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sanitizer run finished rc=0" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
+    # the threaded OBJ reader met 600 intact, mutated and truncated model files with 1 / 3 / 8 threads
+    import re
+    m = re.search(r"obj reader: (\d+) loaded, (\d+) refused, (\d+) triangles", r.stdout)
+    assert m and int(m.group(1)) + int(m.group(2)) == 600 and int(m.group(1)) > 100 and int(m.group(3)) > 400, r.stdout[-1500:]

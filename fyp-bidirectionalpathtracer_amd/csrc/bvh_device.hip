@@ -1787,7 +1787,7 @@ bool downloadStaged(void* dst, const void* src, size_t bytes, std::string& err) 
   hipStream_t st = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
   for (int i = 0; i < kBufs && e == hipSuccess; i++) {
-    e = hipHostMalloc(&stage[i], kStage, hipHostMallocDefault);
+    e = hipHostMalloc(&stage[i], kStage, hipHostMallocPortable);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
   }
   const size_t nChunks = (bytes + kStage - 1) / kStage;
@@ -1829,7 +1829,7 @@ bool downloadStaged(void* dst, const void* src, size_t bytes, std::string& err) 
 namespace {
 constexpr size_t kUpStage = 32u << 20;
 std::mutex gStageLock;
-std::vector<void*> gStageFree;  // pinned buffers of kUpStage bytes, this device's (the pool is per process: one GPU per process)
+std::vector<void*> gStageFree;  // pinned buffers of kUpStage bytes, hipHostMallocPortable: one pool for every device of the process
 // bvhPrewarmStaging (bdpt_create): four buffers pinned on a thread of their own while the host does other things —
 // pinning 128 MB takes the driver over 0.1 s, which the first bdpt_set_scene of a process would otherwise wait for
 struct Prewarm {
@@ -1856,7 +1856,7 @@ void* takeStage() {
     }
   }
   void* p = nullptr;
-  return hipHostMalloc(&p, kUpStage, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+  return hipHostMalloc(&p, kUpStage, hipHostMallocPortable) == hipSuccess ? p : nullptr;
 }
 void giveStage(void* p) {
   if (!p) return;
@@ -2571,7 +2571,7 @@ void bvhPrewarmStaging(int device) {
       if (hipSetDevice(device) != hipSuccess) return;
       for (int i = 0; i < 4; i++) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, kUpStage, hipHostMallocDefault) != hipSuccess) return;
+        if (hipHostMalloc(&p, kUpStage, hipHostMallocPortable) != hipSuccess) return;
         giveStage(p);
       }
     });

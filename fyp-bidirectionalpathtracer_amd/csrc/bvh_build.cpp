@@ -608,10 +608,28 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   out.deviceRecs = nullptr;
   out.deviceNumRecs = 0;
 
+  auto budgetDefault = [](const char* env, float dflt) {
+    if (const char* e = std::getenv(env)) {
+      const float v = (float)std::atof(e);
+      if (v >= 0.0f && v <= 64.0f) return v;
+    }
+    return dflt;
+  };
+  const float budgetOpaque = opt.splitBudget >= 0.0f ? opt.splitBudget : budgetDefault("BDPT_SPLIT_BUDGET", (float)BDPT_SPLIT_BUDGET);
+  const float budgetAlpha = opt.splitBudgetAlpha >= 0.0f ? opt.splitBudgetAlpha : budgetDefault("BDPT_SPLIT_BUDGET_ALPHA", (float)BDPT_SPLIT_BUDGET_ALPHA);
+  // (a plugged-in reference maker — bdpt_set_scene: the device — may do all of the reference stage, pass 1 and the split counts, itself)
+  const BvhRefMaker refMaker = (opt.treeBuilder && opt.packer) ? opt.refMaker : nullptr;
+  const bool decideElsewhere = refMaker && opt.prioritiesInRefMaker;
+  // ... and then makes the triangle records and their boxes where it works, from positions + indices (BvhRefInput), and
+  // the packer of the same pipeline reads them there: this side only needs the scene's box, not 72 bytes per triangle
+  // written and page-faulted in (0.05-0.15 s of a 10 M-triangle bdpt_set_scene).
+  const bool recsElsewhere = decideElsewhere && opt.collapseInPacker && opt.numVertices != 0 && !(budgetOpaque > 0.0f) &&
+                             std::getenv("BDPT_UPLOAD_TRI_RECS") == nullptr;
+
   // Triangle records exactly as the device intersects them: the "actual" triangle is
   // (v0, v0+e1, v0+e2) in fp32, so bounds are taken from those points.
-  BigVec<BvhTri> recs(nTris);  // (every field of every record is written by the loop below)
-  BigVec<Box> triBox(nTris);
+  BigVec<BvhTri> recs(recsElsewhere ? 0 : nTris);  // (every field of every record is written by the loop below)
+  BigVec<Box> triBox(recsElsewhere ? 0 : nTris);
   Box scene;
   scene.reset();
   {
@@ -624,7 +642,7 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         const float* a = positions + (size_t)indices[t * 3] * 3;
         const float* b = positions + (size_t)indices[t * 3 + 1] * 3;
         const float* c = positions + (size_t)indices[t * 3 + 2] * 3;
-        BvhTri& r = recs[t];
+        BvhTri r;
         float p1[3], p2[3];
         for (int k = 0; k < 3; k++) {
           r.v0[k] = a[k];
@@ -643,7 +661,10 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
         bx.grow(p2);
         bx.grow(b);
         bx.grow(c);
-        triBox[t] = bx;
+        if (!recsElsewhere) {
+          recs[t] = r;
+          triBox[t] = bx;
+        }
         acc.grow(bx);
       }
       part[(size_t)th].grow(acc);
@@ -661,15 +682,6 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
 
   // ---- references (see "References" above): the whole triangle, shrunk by the clipper where it is non-opaque,
   // then split s_t times
-  auto budgetDefault = [](const char* env, float dflt) {
-    if (const char* e = std::getenv(env)) {
-      const float v = (float)std::atof(e);
-      if (v >= 0.0f && v <= 64.0f) return v;
-    }
-    return dflt;
-  };
-  const float budgetOpaque = opt.splitBudget >= 0.0f ? opt.splitBudget : budgetDefault("BDPT_SPLIT_BUDGET", (float)BDPT_SPLIT_BUDGET);
-  const float budgetAlpha = opt.splitBudgetAlpha >= 0.0f ? opt.splitBudgetAlpha : budgetDefault("BDPT_SPLIT_BUDGET_ALPHA", (float)BDPT_SPLIT_BUDGET_ALPHA);
   SplitGrid G;
   for (int a = 0; a < 3; a++) {
     G.lo[a] = nTris ? (double)scene.lo[a] : 0.0;
@@ -686,9 +698,6 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
       outlierArea = (float)BDPT_SPLIT_OUTLIER * areas[areas.size() / 2];
     }
   }
-  // (a plugged-in reference maker — bdpt_set_scene: the device — may do all of this, pass 1 and the split counts, itself)
-  const BvhRefMaker refMaker = (opt.treeBuilder && opt.packer) ? opt.refMaker : nullptr;
-  const bool decideElsewhere = refMaker && opt.prioritiesInRefMaker;
   const size_t nHere = decideElsewhere ? 0 : nTris;
   // (sized without being touched, filled side by side: 130 MB of one-thread value-initialisation at 10 M triangles otherwise)
   BigVec<double> prio(nHere);
@@ -814,8 +823,8 @@ void buildBvh(const float* positions, const uint32_t* indices, uint32_t nTris, c
   uint32_t madeElsewhere = 0, droppedElsewhere = 0;
   if (refMaker) {
     BvhRefInput in;
-    in.triRecs = recs.data();
-    in.triBox = triBox.data();
+    in.triRecs = recsElsewhere ? nullptr : recs.data();
+    in.triBox = recsElsewhere ? nullptr : triBox.data();
     in.splits = decideElsewhere ? nullptr : splits.data();
     in.state = decideElsewhere ? nullptr : state.data();
     in.budgetOpaque = budgetOpaque;

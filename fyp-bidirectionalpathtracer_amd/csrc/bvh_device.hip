@@ -2415,6 +2415,10 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
     if (!devAllocT(pool, &dTriBox, nT, err)) return false;
     hipLaunchKernelGGL(k_tri_recs, dim3((nT + 255) / 256), dim3(256), 0, nullptr, dPos, dIdxAll, dFlags, dAux, nT, build->triRecs, dTriBox);
   } else {
+    if (!in.triRecs || !in.triBox) {
+      err = "device reference maker: neither triangle records nor what they are made of were handed over";
+      return false;
+    }
     if (!uploadStagedImpl(build->triRecs, in.triRecs, (size_t)nT * sizeof(BvhTri), err)) return false;
     if (!upload(&dTriBox, in.triBox, nT)) return false;
   }

@@ -157,10 +157,11 @@ def roofline_kernels(kernel_ms, alg, fetched, pmc):
             # counter bytes / kernel time / 8 TB/s: what of the HBM roof this kernel really uses
             r["hbm_side_frac"] = round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)
         fr = {"hbm": r.get("hbm_side_frac")}
-        if name in fetched and tot("TCP_TOTAL_CACHE_ACCESSES_sum"):
-            fb = fetched[name]
-            r["fetched"] = {"bytes_per_frame": int(fb), "rate_gbs": round(fb / sec / 1e9, 1),
-                            "note": "bytes at the record sizes this build loads (48-B nodes and triangles) / time; most are served by L1 / L2"}
+        if tot("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            if name in fetched:
+                fb = fetched[name]
+                r["fetched"] = {"bytes_per_frame": int(fb), "rate_gbs": round(fb / sec / 1e9, 1),
+                                "note": "bytes at the record sizes this build loads (48-B nodes and triangles) / time; most are served by L1 / L2"}
             req = tot("TCP_TCC_READ_REQ_sum")
             l1 = tot("TCP_TOTAL_CACHE_ACCESSES_sum")
             miss = tot("TCC_MISS_sum")
@@ -170,8 +171,10 @@ def roofline_kernels(kernel_ms, alg, fetched, pmc):
                             "infinity_cache_gather_peak_gbs": MALL_GATHER_GBS,
                             "l1_hit": round(1.0 - req / l1, 3) if l1 else None,
                             "l2_hit": round(1.0 - miss / max(1.0, tot("TCC_HIT_sum") + miss), 3)}
-            fr["l2_gather"] = round(req * 128 / sec / 1e9 / L2_GATHER_GBS, 3)
-            fr["infinity_cache_gather"] = round(miss * 128 / sec / 1e9 / MALL_GATHER_GBS, 3)
+            gathers = name in fetched  # the gather ceilings apply to the traversal kernels; the others stream
+            if gathers:
+                fr["l2_gather"] = round(req * 128 / sec / 1e9 / L2_GATHER_GBS, 3)
+                fr["infinity_cache_gather"] = round(miss * 128 / sec / 1e9 / MALL_GATHER_GBS, 3)
             clks = sec * SHADER_CLK_HZ
             lane_loads = l1 / (NUM_CUS * clks) if clks else 0.0
             fast = tot("SQ_INSTS_VALU_FAST")
@@ -184,11 +187,17 @@ def roofline_kernels(kernel_ms, alg, fetched, pmc):
                           if tot("SQ_ACTIVE_INST_VALU") else None,
                           "wait_any": round(tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"), 3) if tot("SQ_WAVE_CYCLES") else None,
                           "shader_clock_hz_assumed": SHADER_CLK_HZ}
-            fr["vmem_address_unit"] = round(lane_loads / LANE_LOADS_PER_CLK_PER_CU, 3)
+            if gathers:
+                fr["vmem_address_unit"] = round(lane_loads / LANE_LOADS_PER_CLK_PER_CU, 3)
             if valu and tot("SQ_INSTS_VALU_FAST"):
                 fr["valu_issue"] = round((fast * VALU_CLK_FAST + slow * VALU_CLK_SLOW) / (NUM_SIMDS * clks), 3) if clks else None
         r["fractions"] = fr
         r["bound"] = max(((v, k) for k, v in fr.items() if v is not None), default=(0, "hbm"))[1]
+        top = max((v for v in fr.values() if v is not None), default=0.0)
+        if top < 0.5 and "issue" in r:
+            r["bound_note"] = ("no ceiling above half: short kernels of dependent loads (vertex record -> hint / material -> queue cursor), "
+                               "waves waiting %.2f of their cycles — latency, not a rate, sets their time; they run beside the traversal "
+                               "kernels and take little of what those are short of" % (r["issue"]["wait_any"] or 0.0))
         return r
 
     return {k: roof(k) for k in kernel_ms}

@@ -560,6 +560,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
+            # value counts every ray query of the integrator the pass answered; the ones an occluder hint answered by one
+            # triangle test (no traversal) are shown apart, and so is the rate without them
+            "value_traversals_only": round((rays_all - hinted_all) / elapsed_max / 1e6, 2),
+            "rays_hinted_per_frame": int(hinted_all / K),
             "dtype": "f32",
             "data": "file" if args.scene_file else "synthetic",
             "config": {

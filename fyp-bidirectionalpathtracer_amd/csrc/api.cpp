@@ -389,6 +389,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     const uint32_t* indices = nullptr;
     const float* bitangents = nullptr;
     hipError_t err = hipSuccess;
+    std::string what;  // the staged upload's own message, when that is what failed
   };
   // (BDPT_SET_SCENE_SERIAL: measurement knob — the same work at the point where its results are needed, on this thread)
   std::future<SideUploads> side = std::async(std::getenv("BDPT_SET_SCENE_SERIAL") ? std::launch::deferred : std::launch::async, [c, d]() {
@@ -424,7 +425,10 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
       u.pool.push_back(q);
       if (count) {
         std::string e;
-        if (!bvhUploadStaged(q, host, count * sizeof(**dst), e)) u.err = hipErrorUnknown;
+        if (!bvhUploadStaged(q, host, count * sizeof(**dst), e)) {
+          u.err = hipErrorUnknown;
+          u.what = e;
+        }
       }
       *dst = static_cast<std::remove_reference_t<decltype(*dst)>>(q);
     };
@@ -500,7 +504,7 @@ static int setSceneImpl(bdpt_ctx* c, const bdpt_scene_desc* d) {
     SideUploads u = side.get();  // (a std::bad_alloc of that thread is rethrown here: bdpt_set_scene's catch)
     c->sceneAllocs.insert(c->sceneAllocs.end(), u.pool.begin(), u.pool.end());
     if (u.err != hipSuccess) {
-      fail(c, std::string("scene upload: ") + hipGetErrorString(u.err));
+      fail(c, std::string("scene upload: ") + (u.what.empty() ? std::string(hipGetErrorString(u.err)) : u.what));
       return u.err == hipErrorOutOfMemory ? BDPT_E_NOMEM : BDPT_E_HIP;
     }
     c->S.shade = reinterpret_cast<const float4*>(u.shade);

@@ -1833,27 +1833,31 @@ std::vector<void*> gStageFree;  // pinned buffers of kUpStage bytes, hipHostMall
 // bvhPrewarmStaging (bdpt_create): four buffers pinned on a thread of their own while the host does other things —
 // pinning 128 MB takes the driver over 0.1 s, which the first bdpt_set_scene of a process would otherwise wait for
 struct Prewarm {
-  std::thread th;
+  std::thread th;             // touched under joinLock only (and by the destructor, after main)
+  std::mutex joinLock;
   std::once_flag once;
+  std::atomic<bool> pending{false};  // started and not joined yet
   ~Prewarm() {
     if (th.joinable()) th.join();
   }
 } gPrewarm;
+void waitForPrewarm() {
+  if (!gPrewarm.pending.load(std::memory_order_acquire)) return;
+  std::lock_guard<std::mutex> j(gPrewarm.joinLock);
+  if (gPrewarm.th.joinable()) gPrewarm.th.join();
+  gPrewarm.pending.store(false, std::memory_order_release);
+}
 void* takeStage() {
-  {
-    std::unique_lock<std::mutex> g(gStageLock);
-    if (gStageFree.empty() && gPrewarm.th.joinable()) {  // the warm-up has not delivered yet: wait for it rather than pin more
-      g.unlock();
-      static std::mutex joinLock;
-      std::lock_guard<std::mutex> j(joinLock);
-      if (gPrewarm.th.joinable()) gPrewarm.th.join();
-      g.lock();
+  for (int attempt = 0; attempt < 2; attempt++) {
+    {
+      std::lock_guard<std::mutex> g(gStageLock);
+      if (!gStageFree.empty()) {
+        void* p = gStageFree.back();
+        gStageFree.pop_back();
+        return p;
+      }
     }
-    if (!gStageFree.empty()) {
-      void* p = gStageFree.back();
-      gStageFree.pop_back();
-      return p;
-    }
+    if (attempt == 0) waitForPrewarm();  // the warm-up has not delivered yet: wait for it rather than pin more
   }
   void* p = nullptr;
   return hipHostMalloc(&p, kUpStage, hipHostMallocPortable) == hipSuccess ? p : nullptr;
@@ -2571,6 +2575,8 @@ bool makeReferencesOnDevice(void* user, const BvhRefInput& in, uint32_t& numRefs
 bool bvhUploadStaged(void* dst, const void* src, size_t bytes, std::string& err) { return uploadStagedImpl(dst, src, bytes, err); }
 void bvhPrewarmStaging(int device) {
   std::call_once(gPrewarm.once, [device] {
+    std::lock_guard<std::mutex> j(gPrewarm.joinLock);
+    gPrewarm.pending.store(true, std::memory_order_release);
     gPrewarm.th = std::thread([device] {
       if (hipSetDevice(device) != hipSuccess) return;
       for (int i = 0; i < 4; i++) {

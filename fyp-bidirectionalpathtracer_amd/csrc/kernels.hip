@@ -1444,6 +1444,12 @@ __global__ __launch_bounds__(kWave) void test_trace_kernel(SceneDev S, const flo
   const float* r = rays + (size_t)i * 8;
   uint32_t a = 0, b = 0;
   Hit h = traverse<MODE, false>(S, ld3(r), ld3(r + 3), r[6], r[7], s_stack + threadIdx.x, a, b);
+  // Hit::rec (what the occluder hints of light-tracing rays are made of) must name the record of the primitive hit: a
+  // query whose record word says otherwise reports primitive -2, which no oracle answer equals
+  if (MODE != 2 && h.prim >= 0) {
+    const bool named = h.rec < S.numRecs && (int)__float_as_uint(reinterpret_cast<const float4*>(S.recs)[(size_t)h.rec * kRecF4].w) == h.prim;
+    if (!named) h.prim = -2;
+  }
   prim[i] = h.prim;
   const bool rec = (MODE != 2) && h.prim >= 0;
   tuv[(size_t)i * 3] = rec ? h.t : 0.0f;
